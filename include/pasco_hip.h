@@ -1,0 +1,189 @@
+/*
+ * pasco_hip.h -- flat C ABI of libpascohip.so (MI355X / gfx950 sparse-voxel operator library).
+ *
+ * This is the drop-in boundary of the hot path: the entry points a
+ * MinkowskiEngine-style Python frontend binds instead of upstream's pybind11 module
+ * `MinkowskiEngineBackend._C` (CoordinateMapManager / ConvolutionForward / LocalPoolingForward /
+ * PruningForward ...).  MinkowskiEngine v0.5.4 is pinned by the reference at README.md:90 and is
+ * NOT vendored under /root/reference, so each entry point cites the PaSCo call site whose
+ * `ME.*` operator it serves.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed / torch.cuda storage) unless named `h_*`;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises;
+ *   - the library never allocates or frees caller tensors; scratch comes in through `ws`;
+ *   - coordinates are int32 rows (batch, x, y, z); features are fp32 row-major [N, C];
+ *   - row indices are int32; "-1" means "no row";
+ *   - return value 0 = ok, non-zero = error, text via ph_last_error() (thread local).
+ *
+ * The same header is compiled with -DPH_ORACLE by oracle/ to give the CPU restatement the
+ * identical signatures under the `pho_` prefix (host pointers, `stream` ignored).  The oracle
+ * is test infrastructure only.
+ */
+#ifndef PASCO_HIP_H_
+#define PASCO_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifdef PH_ORACLE
+#define PH_FN(name) pho_##name
+#else
+#define PH_FN(name) ph_##name
+#endif
+
+#define PH_ABI_VERSION 1
+#define PH_MAX_KVOL 64 /* largest kernel volume served (4x4x4 max-pool window) */
+
+/* activation codes for fused prologue / epilogue */
+#define PH_ACT_NONE 0
+#define PH_ACT_RELU 1
+#define PH_ACT_LEAKY 2 /* negative slope passed separately */
+
+typedef void *ph_stream_t;
+
+int PH_FN(abi_version)(void);
+const char *PH_FN(last_error)(void);
+
+/* Scratch bytes any call below may need for `n` rows. */
+int64_t PH_FN(workspace_bytes)(int64_t n);
+
+/* ---------------------------------------------------------------------------------------------
+ * Coordinate hash map (serves every `ME.SparseTensor(features, coordinates)` constructor:
+ * pasco/models/net_panoptic_sparse.py:549, augmenter.py:26, unet3d_sparse_v2.py:207-212,
+ * decoder_v3.py:141-146, transformer_predictor_v2.py:203-205,231,258-262, ensembler.py:122).
+ *
+ * Table = open-addressing, linear probing; `tkeys[cap]` packed 64-bit coordinate keys,
+ * `tvals[cap]` row index.  cap must be a power of two >= 2*n.  Duplicated coordinates keep the
+ * FIRST occurrence (upstream default quantisation mode); unique rows keep their input order.
+ *   row2uniq[n]   out: unique-row index of every input row
+ *   uniq_rows[n]  out: input row of unique row j (first n_uniq entries valid)
+ *   n_uniq        out: device scalar
+ * ------------------------------------------------------------------------------------------- */
+int PH_FN(map_insert)(const int32_t *coords, int64_t n, uint64_t *tkeys, int32_t *tvals,
+                      int64_t cap, int32_t *row2uniq, int32_t *uniq_rows, int32_t *n_uniq,
+                      void *ws, int64_t ws_bytes, ph_stream_t stream);
+
+/* Look up `n` query coordinates; out_rows[i] = row or -1.  (Union add decoder_v3.py:163,
+ * attention-mask lookup transformer_predictor_v2.py:276-279.) */
+int PH_FN(map_find)(const int32_t *query, int64_t n, const uint64_t *tkeys, const int32_t *tvals,
+                    int64_t cap, int32_t *out_rows, ph_stream_t stream);
+
+/* out = floor(c / ts) * ts on x,y,z (batch kept).  Coordinates of a strided conv / pool output
+ * (k=2,s=2 down-convs mink.py:509-511 used at encoder_v2.py:124,133,142; MinkowskiMaxPooling
+ * transformer_predictor_v2.py:100-102). */
+int PH_FN(coords_floor)(const int32_t *coords, int64_t n, int32_t ts, int32_t *out,
+                        ph_stream_t stream);
+
+/* Generative expansion: out[i*8 + k] = c_i + delta_k * ts_out, delta_k in {0,1}^3, x fastest.
+ * (`MinkowskiConvolutionTranspose(k=2, stride=2, expand_coordinates=True)`, mink.py:524-527.) */
+int PH_FN(coords_expand)(const int32_t *coords, int64_t n, int32_t ts_out, int32_t *out,
+                         ph_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel map.  Output-stationary neighbour table nbr[kvol][n_out]:
+ *     nbr[k][o] = row of (c_o + offsets[k]) in the input map, or -1.
+ * `h_offsets` is a HOST array [kvol][3] of coordinate offsets already multiplied by the tensor
+ * stride (and negated for transposed convs).  Offset enumeration order (x fastest; odd kernels
+ * centred, even kernels start at 0) is fixed by the Python frontend.
+ * Serves every MinkowskiConvolution / ConvolutionTranspose / MaxPooling with kernel volume > 1.
+ * ------------------------------------------------------------------------------------------- */
+int PH_FN(nbr_build)(const int32_t *out_coords, int64_t n_out, const uint64_t *in_tkeys,
+                     const int32_t *in_tvals, int64_t in_cap, const int32_t *h_offsets,
+                     int32_t kvol, int32_t *nbr, ph_stream_t stream);
+
+/* COO kernel map in upstream's form: for every offset k the (in_row, out_row) pairs, sorted by
+ * out_row.  pairs_in / pairs_out have kvol*n_out capacity, segment k starts at k*n_out;
+ * counts[kvol] is a device array. */
+int PH_FN(kmap_compact)(const int32_t *nbr, int32_t kvol, int64_t n_out, int32_t *pairs_in,
+                        int32_t *pairs_out, int32_t *counts, void *ws, int64_t ws_bytes,
+                        ph_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sparse convolution forward (MinkowskiConvolution k=3 mink.py:625-638, decoder_v3.py:267-282;
+ * k=2,s=2 mink.py:509-511; transposed k=2,s=2 mink.py:524-527; k=1 encoder_v2.py:109-111,
+ * decoder_v3.py:103-105,133-135).
+ *
+ *   out[o,:] = epi( sum_k [nbr[k][o] >= 0] * pro(in[nbr[k][o], :]) @ W[k] + bias )
+ *   pro(x)  = act_pro(x * pro_scale + pro_shift)          (per input channel; BN-eval + ReLU)
+ *   epi(y)  = act_res( act_epi(y * epi_scale + epi_shift) + residual[o,:] )
+ *
+ * nbr == NULL means the identity map (kernel volume 1, n_out == n_in).  Any of pro_scale /
+ * pro_shift / bias / epi_scale / epi_shift / residual may be NULL.  W is [kvol, cin, cout].
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ph_conv_desc {
+  const float *in;       /* [n_in, cin] */
+  const float *weight;   /* [kvol, cin, cout] */
+  const int32_t *nbr;    /* [kvol, n_out] or NULL */
+  float *out;            /* [n_out, cout] */
+  int64_t n_in;
+  int64_t n_out;
+  int32_t cin;
+  int32_t cout;
+  int32_t kvol;
+  int32_t pro_act;       /* PH_ACT_* applied after pro_scale/pro_shift */
+  const float *pro_scale; /* [cin] */
+  const float *pro_shift; /* [cin] */
+  const float *bias;      /* [cout] */
+  const float *epi_scale; /* [cout] */
+  const float *epi_shift; /* [cout] */
+  int32_t epi_act;
+  float epi_slope;        /* negative slope for PH_ACT_LEAKY (pro and epi) */
+  const float *residual;  /* [n_out, cout] added after epi_act */
+  int32_t res_act;        /* activation after the residual add */
+  int32_t reserved;
+} ph_conv_desc;
+
+int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);
+
+/* Local max pooling over a neighbour table (MinkowskiMaxPooling,
+ * transformer_predictor_v2.py:100-102,234-236).  Rows without any neighbour give 0. */
+int PH_FN(maxpool_fwd)(const float *in, int32_t c, const int32_t *nbr, int32_t kvol,
+                       int64_t n_out, float *out, ph_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pruning / row movement (ME.MinkowskiPruning decoder_v3.py:159,421,427,432,496-497,
+ * misc.py:17,26; SparseTensor.__add__ decoder_v3.py:163).
+ * ------------------------------------------------------------------------------------------- */
+/* Stable compaction of a byte mask: keep_rows[j] = j-th row with mask != 0. */
+int PH_FN(mask_compact)(const uint8_t *mask, int64_t n, int32_t *keep_rows, int32_t *n_keep,
+                        void *ws, int64_t ws_bytes, ph_stream_t stream);
+
+/* dst[j,:] = src[rows[j],:]   (rows[j] == -1 -> zeros).  4-byte elements, c per row. */
+int PH_FN(gather_rows)(const void *src, int32_t c, const int32_t *rows, int64_t n_out, void *dst,
+                       ph_stream_t stream);
+
+/* dst[rows[i],:] += src[i,:] for rows[i] >= 0; rows must be unique (no atomics). */
+int PH_FN(scatter_add_rows)(const float *src, int32_t c, const int32_t *rows, int64_t n_src,
+                            float *dst, ph_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense <-> sparse (SparseTensor.dense augmenter.py:17-18, unet3d_sparse_v2.py:196-198,
+ * transformer_predictor_v2.py:263-274; ME.to_sparse augmenter.py:22, unet3d_sparse_v2.py:202,
+ * ensembler.py:117).
+ * dense layout [B, C, X, Y, Z] fp32.  to_dense does NOT zero `dense` (caller zero-fills).
+ * Site of row i: ((c_i - min) / ts) on each axis; rows falling outside are skipped.
+ * ------------------------------------------------------------------------------------------- */
+int PH_FN(to_dense)(const float *feats, const int32_t *coords, int64_t n, int32_t c,
+                    const int32_t *h_min3, int32_t ts, const int32_t *h_dims4 /*B,X,Y,Z*/,
+                    float *dense, ph_stream_t stream);
+
+/* to_sparse: rows for sites with any non-zero channel, lexicographic (b,x,y,z) order.
+ *   site_rows[B*X*Y*Z] scratch/out: row of each site or -1
+ *   out_coords[n_sites,4] (capacity B*X*Y*Z), n_rows device scalar.
+ * Features are then read with dense_gather. */
+int PH_FN(to_sparse_coords)(const float *dense, int32_t c, const int32_t *h_dims4,
+                            int32_t *out_coords, int32_t *n_rows, void *ws, int64_t ws_bytes,
+                            ph_stream_t stream);
+
+/* feats[i, ch] = dense[b_i, ch, x_i, y_i, z_i] for coords given in site units. */
+int PH_FN(dense_gather)(const float *dense, int32_t c, const int32_t *h_dims4,
+                        const int32_t *site_coords, int64_t n, float *feats, ph_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PASCO_HIP_H_ */

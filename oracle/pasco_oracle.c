@@ -1,0 +1,374 @@
+/*
+ * pasco_oracle.c -- CPU restatement of the sparse-voxel operator semantics on PaSCo's hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under pasco_amd/ imports, links or executes this file; it is
+ * used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker.
+ *
+ * PARITY UNPINNED at the operator layer: the arithmetic of this path lives in MinkowskiEngine
+ * v0.5.4 (pinned by the reference at README.md:90, imported e.g. at
+ * pasco/models/unet3d_sparse_v2.py:6), which is neither vendored under /root/reference nor
+ * installed, and the reference holds no tests or golden vectors for it (SURVEY.md section 4 and
+ * 8(c)).  This file restates upstream's published semantics as used by the reference's call
+ * sites; tests/test_oracle_dense.py pins it against an independent dense formulation
+ * (torch conv3d / conv_transpose3d / max_pool3d on zero-filled grids).
+ *
+ * Semantics restated (one function each):
+ *   a1  coordinate map: int32 (b,x,y,z) rows, duplicates keep the first occurrence, unique rows
+ *       keep input order                      -> pho_map_insert   (net_panoptic_sparse.py:549)
+ *   a3  strided output coordinates floor(c/ts)*ts   -> pho_coords_floor (mink.py:509-511)
+ *   a5  generative expansion c + {0,1}^3 * ts_out   -> pho_coords_expand (mink.py:524-527)
+ *   a2-a5 kernel map: offsets enumerated x fastest, odd kernels centred, even kernels from 0;
+ *       correlation (no flip); W[k] is [cin, cout]  -> pho_nbr_build / pho_kmap_compact / pho_conv_fwd
+ *       (mink.py:625-638, decoder_v3.py:267-282, encoder_v2.py:109-111)
+ *   a6  eval BatchNorm / ReLU / LeakyReLU as per-channel affine + activation (conv prologue/epilogue)
+ *   a7  pruning keeps row order                      -> pho_mask_compact + pho_gather_rows
+ *   a8  union add                                    -> pho_map_insert + pho_scatter_add_rows
+ *   a9  dense / to_sparse (lexicographic b,x,y,z)     -> pho_to_dense / pho_to_sparse_coords / pho_dense_gather
+ *   a10 local max pooling                            -> pho_maxpool_fwd (transformer_predictor_v2.py:100-102)
+ *
+ * Same C ABI as include/pasco_hip.h with the `pho_` prefix; pointers are host pointers and the
+ * stream argument is ignored.  Plain C + OpenMP.
+ */
+#define PH_ORACLE 1
+#include "../include/pasco_hip.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static __thread char g_err[512];
+
+static int fail(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+int pho_abi_version(void) { return PH_ABI_VERSION; }
+const char *pho_last_error(void) { return g_err; }
+int64_t pho_workspace_bytes(int64_t n) { return 9 * (n < 0 ? 0 : n) + 4096; }
+
+/* ---- coordinate key (same packing as the device table so tables are interchangeable) -------- */
+#define EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define COORD_BIAS (1 << 17)
+
+static uint64_t pack(int b, int x, int y, int z) {
+  return ((uint64_t)((uint32_t)b & 0x3FFu) << 54) |
+         ((uint64_t)((uint32_t)(x + COORD_BIAS) & 0x3FFFFu) << 36) |
+         ((uint64_t)((uint32_t)(y + COORD_BIAS) & 0x3FFFFu) << 18) |
+         ((uint64_t)((uint32_t)(z + COORD_BIAS) & 0x3FFFFu));
+}
+
+static uint64_t mix(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return k;
+}
+
+static int is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static int find(const uint64_t *tkeys, const int32_t *tvals, uint64_t mask, uint64_t key) {
+  uint64_t slot = mix(key) & mask;
+  for (;;) {
+    uint64_t k = tkeys[slot];
+    if (k == key) return tvals[slot];
+    if (k == EMPTY_KEY) return -1;
+    slot = (slot + 1) & mask;
+  }
+}
+
+/* a1: sequential insert => first occurrence wins, unique rows numbered in input order. */
+int pho_map_insert(const int32_t *coords, int64_t n, uint64_t *tkeys, int32_t *tvals, int64_t cap,
+                   int32_t *row2uniq, int32_t *uniq_rows, int32_t *n_uniq, void *ws,
+                   int64_t ws_bytes, ph_stream_t stream) {
+  (void)ws; (void)ws_bytes; (void)stream;
+  if (!is_pow2(cap) || cap < 2 * n || cap < 2) return fail("map_insert: cap must be pow2 >= 2n");
+  for (int64_t s = 0; s < cap; ++s) { tkeys[s] = EMPTY_KEY; tvals[s] = INT_MAX; }
+  uint64_t mask = (uint64_t)cap - 1;
+  int32_t count = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t *c = coords + 4 * i;
+    uint64_t key = pack(c[0], c[1], c[2], c[3]);
+    uint64_t slot = mix(key) & mask;
+    while (tkeys[slot] != EMPTY_KEY && tkeys[slot] != key) slot = (slot + 1) & mask;
+    if (tkeys[slot] == EMPTY_KEY) {
+      tkeys[slot] = key;
+      tvals[slot] = uniq_rows ? count : (int32_t)i;
+      if (uniq_rows) uniq_rows[count] = (int32_t)i;
+      ++count;
+    } else if (!uniq_rows) {
+      return fail("map_insert: duplicate coordinate at row %lld but caller promised unique", (long long)i);
+    }
+    if (row2uniq) row2uniq[i] = tvals[slot];
+  }
+  if (n_uniq) *n_uniq = count;
+  return 0;
+}
+
+int pho_map_find(const int32_t *query, int64_t n, const uint64_t *tkeys, const int32_t *tvals,
+                 int64_t cap, int32_t *out_rows, ph_stream_t stream) {
+  (void)stream;
+  if (!is_pow2(cap)) return fail("map_find: cap must be pow2");
+  uint64_t mask = (uint64_t)cap - 1;
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t *c = query + 4 * i;
+    out_rows[i] = find(tkeys, tvals, mask, pack(c[0], c[1], c[2], c[3]));
+  }
+  return 0;
+}
+
+static int floor_div(int v, int ts) {
+  int q = v / ts;
+  if ((v % ts) != 0 && ((v < 0) != (ts < 0))) --q;
+  return q;
+}
+
+/* a3 */
+int pho_coords_floor(const int32_t *coords, int64_t n, int32_t ts, int32_t *out, ph_stream_t stream) {
+  (void)stream;
+  if (ts <= 0) return fail("coords_floor: ts must be > 0");
+  for (int64_t i = 0; i < n; ++i) {
+    out[4 * i] = coords[4 * i];
+    for (int a = 1; a < 4; ++a) out[4 * i + a] = floor_div(coords[4 * i + a], ts) * ts;
+  }
+  return 0;
+}
+
+/* a5 */
+int pho_coords_expand(const int32_t *coords, int64_t n, int32_t ts_out, int32_t *out, ph_stream_t stream) {
+  (void)stream;
+  if (ts_out <= 0) return fail("coords_expand: ts_out must be > 0");
+  for (int64_t i = 0; i < n; ++i)
+    for (int k = 0; k < 8; ++k) {
+      int32_t *o = out + 4 * (i * 8 + k);
+      o[0] = coords[4 * i];
+      o[1] = coords[4 * i + 1] + (k & 1) * ts_out;
+      o[2] = coords[4 * i + 2] + ((k >> 1) & 1) * ts_out;
+      o[3] = coords[4 * i + 3] + ((k >> 2) & 1) * ts_out;
+    }
+  return 0;
+}
+
+int pho_nbr_build(const int32_t *out_coords, int64_t n_out, const uint64_t *in_tkeys,
+                  const int32_t *in_tvals, int64_t in_cap, const int32_t *h_offsets, int32_t kvol,
+                  int32_t *nbr, ph_stream_t stream) {
+  (void)stream;
+  if (kvol < 1 || kvol > PH_MAX_KVOL) return fail("nbr_build: kvol out of range");
+  if (!is_pow2(in_cap)) return fail("nbr_build: cap must be pow2");
+  uint64_t mask = (uint64_t)in_cap - 1;
+#pragma omp parallel for schedule(static)
+  for (int64_t o = 0; o < n_out; ++o) {
+    const int32_t *c = out_coords + 4 * o;
+    for (int k = 0; k < kvol; ++k) {
+      const int32_t *d = h_offsets + 3 * k;
+      nbr[(int64_t)k * n_out + o] = find(in_tkeys, in_tvals, mask, pack(c[0], c[1] + d[0], c[2] + d[1], c[3] + d[2]));
+    }
+  }
+  return 0;
+}
+
+int pho_kmap_compact(const int32_t *nbr, int32_t kvol, int64_t n_out, int32_t *pairs_in,
+                     int32_t *pairs_out, int32_t *counts, void *ws, int64_t ws_bytes,
+                     ph_stream_t stream) {
+  (void)ws; (void)ws_bytes; (void)stream;
+  for (int k = 0; k < kvol; ++k) {
+    int64_t base = (int64_t)k * n_out;
+    int32_t cnt = 0;
+    for (int64_t o = 0; o < n_out; ++o)
+      if (nbr[base + o] >= 0) {
+        pairs_in[base + cnt] = nbr[base + o];
+        pairs_out[base + cnt] = (int32_t)o;
+        ++cnt;
+      }
+    counts[k] = cnt;
+  }
+  return 0;
+}
+
+static float act_apply(float v, int act, float slope) {
+  if (act == PH_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == PH_ACT_LEAKY) return v > 0.f ? v : v * slope;
+  return v;
+}
+
+/* a2-a5: per output row, per kernel offset, row-vector x W[k] accumulate (fp32, like upstream's
+ * CPU gather -> SGEMM -> scatter-add). Rows are processed in blocks so W[k] stays cache resident. */
+int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
+  (void)stream;
+  if (!d) return fail("conv_fwd: null desc");
+  if (d->cin <= 0 || d->cout <= 0 || d->kvol < 1 || d->kvol > PH_MAX_KVOL) return fail("conv_fwd: bad shape");
+  if (!d->nbr && !(d->kvol == 1 && d->n_in == d->n_out)) return fail("conv_fwd: identity map needs kvol == 1");
+  const int cin = d->cin, cout = d->cout;
+  const int64_t n_out = d->n_out;
+  enum { RB = 32 };
+  const int64_t nblocks = (n_out + RB - 1) / RB;
+  const int has_pro = d->pro_scale || d->pro_shift || d->pro_act != PH_ACT_NONE;
+#pragma omp parallel
+  {
+    float *acc = (float *)malloc(sizeof(float) * RB * cout);
+    float *arow = (float *)malloc(sizeof(float) * cin);
+#pragma omp for schedule(dynamic, 4)
+    for (int64_t blk = 0; blk < nblocks; ++blk) {
+      const int64_t o0 = blk * RB;
+      const int rows = (int)((n_out - o0) < RB ? (n_out - o0) : RB);
+      memset(acc, 0, sizeof(float) * RB * cout);
+      for (int k = 0; k < d->kvol; ++k) {
+        const float *wk = d->weight + (int64_t)k * cin * cout;
+        for (int r = 0; r < rows; ++r) {
+          const int64_t o = o0 + r;
+          const int idx = d->nbr ? d->nbr[(int64_t)k * n_out + o] : (int)o;
+          if (idx < 0) continue;
+          const float *src = d->in + (int64_t)idx * cin;
+          const float *a = src;
+          if (has_pro) {
+            for (int c = 0; c < cin; ++c) {
+              float v = src[c] * (d->pro_scale ? d->pro_scale[c] : 1.f) + (d->pro_shift ? d->pro_shift[c] : 0.f);
+              arow[c] = act_apply(v, d->pro_act, d->epi_slope);
+            }
+            a = arow;
+          }
+          float *out = acc + (int64_t)r * cout;
+          for (int c = 0; c < cin; ++c) {
+            const float av = a[c];
+            const float *w = wk + (int64_t)c * cout;
+            for (int n = 0; n < cout; ++n) out[n] += av * w[n];
+          }
+        }
+      }
+      for (int r = 0; r < rows; ++r) {
+        const int64_t o = o0 + r;
+        for (int n = 0; n < cout; ++n) {
+          float v = acc[(int64_t)r * cout + n] + (d->bias ? d->bias[n] : 0.f);
+          v = v * (d->epi_scale ? d->epi_scale[n] : 1.f) + (d->epi_shift ? d->epi_shift[n] : 0.f);
+          v = act_apply(v, d->epi_act, d->epi_slope);
+          if (d->residual) v = act_apply(v + d->residual[o * cout + n], d->res_act, d->epi_slope);
+          d->out[o * cout + n] = v;
+        }
+      }
+    }
+    free(acc);
+    free(arow);
+  }
+  return 0;
+}
+
+/* a10 */
+int pho_maxpool_fwd(const float *in, int32_t c, const int32_t *nbr, int32_t kvol, int64_t n_out,
+                    float *out, ph_stream_t stream) {
+  (void)stream;
+  if (c <= 0 || kvol < 1 || kvol > PH_MAX_KVOL) return fail("maxpool_fwd: bad shape");
+#pragma omp parallel for schedule(static)
+  for (int64_t o = 0; o < n_out; ++o) {
+    float *dst = out + o * c;
+    int any = 0;
+    for (int ch = 0; ch < c; ++ch) dst[ch] = 0.f;
+    for (int k = 0; k < kvol; ++k) {
+      int r = nbr[(int64_t)k * n_out + o];
+      if (r < 0) continue;
+      const float *src = in + (int64_t)r * c;
+      for (int ch = 0; ch < c; ++ch) dst[ch] = (!any || src[ch] > dst[ch]) ? src[ch] : dst[ch];
+      any = 1;
+    }
+  }
+  return 0;
+}
+
+/* a7 */
+int pho_mask_compact(const uint8_t *mask, int64_t n, int32_t *keep_rows, int32_t *n_keep, void *ws,
+                     int64_t ws_bytes, ph_stream_t stream) {
+  (void)ws; (void)ws_bytes; (void)stream;
+  int32_t cnt = 0;
+  for (int64_t i = 0; i < n; ++i)
+    if (mask[i]) keep_rows[cnt++] = (int32_t)i;
+  *n_keep = cnt;
+  return 0;
+}
+
+int pho_gather_rows(const void *src, int32_t c, const int32_t *rows, int64_t n_out, void *dst,
+                    ph_stream_t stream) {
+  (void)stream;
+  if (c <= 0) return fail("gather_rows: c must be > 0");
+  const uint32_t *s = (const uint32_t *)src;
+  uint32_t *d = (uint32_t *)dst;
+  for (int64_t j = 0; j < n_out; ++j) {
+    if (rows[j] >= 0) memcpy(d + j * c, s + (int64_t)rows[j] * c, 4 * (size_t)c);
+    else memset(d + j * c, 0, 4 * (size_t)c);
+  }
+  return 0;
+}
+
+/* a8 (feature side) */
+int pho_scatter_add_rows(const float *src, int32_t c, const int32_t *rows, int64_t n_src, float *dst,
+                         ph_stream_t stream) {
+  (void)stream;
+  if (c <= 0) return fail("scatter_add_rows: c must be > 0");
+  for (int64_t i = 0; i < n_src; ++i) {
+    if (rows[i] < 0) continue;
+    float *d = dst + (int64_t)rows[i] * c;
+    for (int ch = 0; ch < c; ++ch) d[ch] += src[i * c + ch];
+  }
+  return 0;
+}
+
+/* a9 */
+int pho_to_dense(const float *feats, const int32_t *coords, int64_t n, int32_t c, const int32_t *h_min3,
+                 int32_t ts, const int32_t *h_dims4, float *dense, ph_stream_t stream) {
+  (void)stream;
+  if (c <= 0 || ts <= 0) return fail("to_dense: bad c/ts");
+  const int B = h_dims4[0], X = h_dims4[1], Y = h_dims4[2], Z = h_dims4[3];
+  const int64_t per_b = (int64_t)X * Y * Z;
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t *p = coords + 4 * i;
+    int x = floor_div(p[1] - h_min3[0], ts), y = floor_div(p[2] - h_min3[1], ts), z = floor_div(p[3] - h_min3[2], ts);
+    if (p[0] < 0 || p[0] >= B || x < 0 || x >= X || y < 0 || y >= Y || z < 0 || z >= Z) continue;
+    int64_t site = ((int64_t)x * Y + y) * Z + z;
+    for (int ch = 0; ch < c; ++ch) dense[((int64_t)p[0] * c + ch) * per_b + site] = feats[i * c + ch];
+  }
+  return 0;
+}
+
+int pho_to_sparse_coords(const float *dense, int32_t c, const int32_t *h_dims4, int32_t *out_coords,
+                         int32_t *n_rows, void *ws, int64_t ws_bytes, ph_stream_t stream) {
+  (void)ws; (void)ws_bytes; (void)stream;
+  const int B = h_dims4[0], X = h_dims4[1], Y = h_dims4[2], Z = h_dims4[3];
+  const int64_t per_b = (int64_t)X * Y * Z;
+  int32_t cnt = 0;
+  for (int b = 0; b < B; ++b)
+    for (int x = 0; x < X; ++x)
+      for (int y = 0; y < Y; ++y)
+        for (int z = 0; z < Z; ++z) {
+          int64_t site = ((int64_t)x * Y + y) * Z + z;
+          int any = 0;
+          for (int ch = 0; ch < c && !any; ++ch) any = dense[((int64_t)b * c + ch) * per_b + site] != 0.f;
+          if (any) {
+            int32_t *o = out_coords + 4 * (int64_t)cnt;
+            o[0] = b; o[1] = x; o[2] = y; o[3] = z;
+            ++cnt;
+          }
+        }
+  *n_rows = cnt;
+  return 0;
+}
+
+int pho_dense_gather(const float *dense, int32_t c, const int32_t *h_dims4, const int32_t *site_coords,
+                     int64_t n, float *feats, ph_stream_t stream) {
+  (void)stream;
+  if (c <= 0) return fail("dense_gather: bad c");
+  const int B = h_dims4[0], X = h_dims4[1], Y = h_dims4[2], Z = h_dims4[3];
+  const int64_t per_b = (int64_t)X * Y * Z;
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t *p = site_coords + 4 * i;
+    int ok = p[0] >= 0 && p[0] < B && p[1] >= 0 && p[1] < X && p[2] >= 0 && p[2] < Y && p[3] >= 0 && p[3] < Z;
+    int64_t site = ok ? ((int64_t)p[1] * Y + p[2]) * Z + p[3] : 0;
+    for (int ch = 0; ch < c; ++ch) feats[i * c + ch] = ok ? dense[((int64_t)p[0] * c + ch) * per_b + site] : 0.f;
+  }
+  return 0;
+}

@@ -1,0 +1,310 @@
+// Sparse convolution forward for gfx950: output-stationary gather -> LDS tile -> fp32 MFMA.
+//
+//   out[o,:] = epi( sum_k [nbr[k][o] >= 0] * pro(in[nbr[k][o],:]) @ W[k] + bias )
+//
+// One workgroup (256 threads = 4 wave64) owns BM = 128 output rows x BN output channels and walks
+// the (kernel offset, input-channel chunk) stages.  Per stage the 128 neighbour rows are gathered
+// with 16-byte coalesced loads (a 32-float chunk of a row = 8 lanes x float4) into an LDS A tile,
+// the matching W[k] slab goes into an LDS B tile, and the waves run v_mfma_f32_32x32x2_f32
+// (exact fp32, SURVEY.md 8(d): C >= 128 layers are FLOP-bound in fp32, C = 64 sits at the ridge).
+// The output tile lives in accumulator registers for the whole kernel-offset loop and is written
+// exactly once -- no scatter-add, no atomics, HBM traffic = B_alg of SURVEY.md 8(d).
+// BN/ReLU of the producing layer is fused as a gather prologue (valid rows only), bias / BN /
+// activation / residual as the epilogue, so ResidualBlocks (mink.py:618-658) need no elementwise
+// passes.
+//
+// LDS layouts (bank maths in MI355X_MICROARCH.md "LDS"):
+//   As[BM][BKC + 4]  row-major; a lane reads its 4 k-values with one ds_read_b128; row stride of
+//                    36 dwords makes any 16 rows with distinct (row mod 16) hit distinct 16-byte
+//                    slots -> conflict free for the b128 lane groups.
+//   Bs[BKC][BN + 4]  k-major; lanes 0..31 read 32 consecutive dwords (ds_read_b32).
+// The contraction index inside an 8-wide step is permuted (hardware k-half h <-> k = 4h + s) so
+// that A needs one wide read per 4 MFMAs; A and B use the same permutation.
+#include "ph_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int CV_THREADS = 256;
+constexpr int BM = 128;
+constexpr int BKC = 32;
+constexpr int A_LD = BKC + 4;
+
+struct ConvArgs {
+  const float *in;
+  const float *w;
+  const int32_t *nbr;
+  float *out;
+  int64_t n_in, n_out;
+  int cin, cout, kvol;
+  int pro_act;
+  const float *pro_scale, *pro_shift, *bias, *epi_scale, *epi_shift, *residual;
+  int epi_act, res_act;
+  float slope;
+  int n_row_tiles, n_col_tiles;
+};
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+  if (act == PH_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == PH_ACT_LEAKY) return v > 0.f ? v : v * slope;
+  return v;
+}
+
+// WM x WN waves, each TM x TN tiles of 32x32.  WM*TM*32 == BM.
+template <int WM, int WN, int TM, int TN, bool VEC_A, bool VEC_B>
+__global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
+  constexpr int BN = WN * TN * 32;
+  constexpr int B_LD = BN + 4;
+  constexpr int A_PASSES = BM * (BKC / 4) / CV_THREADS;  // float4 slots per thread (4)
+  constexpr int B_SLOTS = BKC * (BN / 4) / CV_THREADS;   // float4 slots per thread
+  static_assert(WM * WN == 4 && WM * TM * 32 == BM, "tile shape");
+
+  __shared__ __attribute__((aligned(16))) float As[BM * A_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BKC * B_LD];
+
+  // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of
+  // tiles so that neighbouring row tiles (shared gathered rows) meet in one L2.
+  const int nwg = gridDim.x;
+  const int cpx = nwg >> 3;  // grid is padded to a multiple of 8
+  const int bid = blockIdx.x;
+  const int tile = (bid & 7) * cpx + (bid >> 3);
+  const int ntiles = a.n_row_tiles * a.n_col_tiles;
+  if (tile >= ntiles) return;
+  const int row_tile = tile / a.n_col_tiles;
+  const int col_tile = tile - row_tile * a.n_col_tiles;
+  const int64_t m0 = (int64_t)row_tile * BM;
+  const int n0 = col_tile * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int h = lane >> 5;   // MFMA k-half
+  const int l31 = lane & 31;
+
+  const int cin = a.cin, cout = a.cout;
+  const int nchunks = (cin + BKC - 1) / BKC;
+  const int nstages = a.kvol * nchunks;
+
+  // A loader mapping: 8 float4 per row chunk, 32 rows per pass
+  const int a_c4 = tid & 7;
+  const int a_r0 = tid >> 3;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[A_PASSES];
+  float4 rb[B_SLOTS];
+  unsigned a_valid = 0;
+  int cur_c0 = 0;
+
+  auto load_stage = [&](int s) {
+    const int k = s / nchunks;
+    const int c0 = (s - k * nchunks) * BKC;
+    cur_c0 = c0;
+    a_valid = 0;
+    const int cbase = c0 + a_c4 * 4;
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      const int64_t row = m0 + a_r0 + p * 32;
+      int idx = -1;
+      if (row < a.n_out) idx = a.nbr ? a.nbr[(int64_t)k * a.n_out + row] : (int)row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx >= 0) {
+        a_valid |= (1u << p);
+        const float *src = a.in + (int64_t)idx * cin + cbase;
+        if (VEC_A) {
+          if (cbase < cin) v = *reinterpret_cast<const float4 *>(src);
+        } else {
+          if (cbase + 0 < cin) v.x = src[0];
+          if (cbase + 1 < cin) v.y = src[1];
+          if (cbase + 2 < cin) v.z = src[2];
+          if (cbase + 3 < cin) v.w = src[3];
+        }
+      }
+      ra[p] = v;
+    }
+    const float *wk = a.w + (int64_t)k * cin * cout;
+#pragma unroll
+    for (int q = 0; q < B_SLOTS; ++q) {
+      const int slot = tid + q * CV_THREADS;
+      const int kr = slot / (BN / 4);
+      const int n4 = slot - kr * (BN / 4);
+      const int c = c0 + kr;
+      const int n = n0 + n4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < cin) {
+        const float *src = wk + (int64_t)c * cout + n;
+        if (VEC_B) {
+          if (n < cout) v = *reinterpret_cast<const float4 *>(src);
+        } else {
+          if (n + 0 < cout) v.x = src[0];
+          if (n + 1 < cout) v.y = src[1];
+          if (n + 2 < cout) v.z = src[2];
+          if (n + 3 < cout) v.w = src[3];
+        }
+      }
+      rb[q] = v;
+    }
+  };
+
+  auto store_stage = [&]() {
+    const int cbase = cur_c0 + a_c4 * 4;
+    float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool has_pro = (a.pro_scale != nullptr) || (a.pro_shift != nullptr) || a.pro_act != PH_ACT_NONE;
+    if (has_pro) {
+      float s4[4] = {1.f, 1.f, 1.f, 1.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (cbase + j < cin) {
+          if (a.pro_scale) s4[j] = a.pro_scale[cbase + j];
+          if (a.pro_shift) b4[j] = a.pro_shift[cbase + j];
+        }
+      }
+      ps = make_float4(s4[0], s4[1], s4[2], s4[3]);
+      pb = make_float4(b4[0], b4[1], b4[2], b4[3]);
+    }
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      float4 v = ra[p];
+      if (has_pro && ((a_valid >> p) & 1u)) {
+        v.x = act_apply(v.x * ps.x + pb.x, a.pro_act, a.slope);
+        v.y = act_apply(v.y * ps.y + pb.y, a.pro_act, a.slope);
+        v.z = act_apply(v.z * ps.z + pb.z, a.pro_act, a.slope);
+        v.w = act_apply(v.w * ps.w + pb.w, a.pro_act, a.slope);
+        // channels beyond cin must stay zero
+        if (cbase + 0 >= cin) v.x = 0.f;
+        if (cbase + 1 >= cin) v.y = 0.f;
+        if (cbase + 2 >= cin) v.z = 0.f;
+        if (cbase + 3 >= cin) v.w = 0.f;
+      }
+      *reinterpret_cast<float4 *>(&As[(a_r0 + p * 32) * A_LD + a_c4 * 4]) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < B_SLOTS; ++q) {
+      const int slot = tid + q * CV_THREADS;
+      const int kr = slot / (BN / 4);
+      const int n4 = slot - kr * (BN / 4);
+      *reinterpret_cast<float4 *>(&Bs[kr * B_LD + n4 * 4]) = rb[q];
+    }
+  };
+
+  auto compute_stage = [&]() {
+#pragma unroll
+    for (int k8 = 0; k8 < BKC / 8; ++k8) {
+      float4 av[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + l31;
+        av[i] = *reinterpret_cast<const float4 *>(&As[row * A_LD + k8 * 8 + h * 4]);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float bv[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bv[j] = Bs[(k8 * 8 + h * 4 + s) * B_LD + (wn * TN + j) * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float aval = (s == 0) ? av[i].x : (s == 1) ? av[i].y : (s == 2) ? av[i].z : av[i].w;
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bv[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  load_stage(0);
+  for (int s = 0; s < nstages; ++s) {
+    store_stage();
+    __syncthreads();
+    if (s + 1 < nstages) load_stage(s + 1);
+    compute_stage();
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + l31;
+    if (col >= cout) continue;
+    const float bias = a.bias ? a.bias[col] : 0.f;
+    const float es = a.epi_scale ? a.epi_scale[col] : 1.f;
+    const float eb = a.epi_shift ? a.epi_shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= a.n_out) continue;
+        float v = acc[i][j][r] + bias;
+        v = act_apply(v * es + eb, a.epi_act, a.slope);
+        if (a.residual) v = act_apply(v + a.residual[row * cout + col], a.res_act, a.slope);
+        a.out[row * cout + col] = v;
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_conv(const ConvArgs &a, hipStream_t st) {
+  constexpr int BN = WN * TN * 32;
+  ConvArgs args = a;
+  args.n_row_tiles = (int)((a.n_out + BM - 1) / BM);
+  args.n_col_tiles = (a.cout + BN - 1) / BN;
+  const int ntiles = args.n_row_tiles * args.n_col_tiles;
+  const int grid = ((ntiles + 7) / 8) * 8;
+  const bool va = (a.cin % 4 == 0) && (((uintptr_t)a.in & 15) == 0);
+  const bool vb = (a.cout % 4 == 0) && (((uintptr_t)a.w & 15) == 0);
+  if (va && vb)
+    hipLaunchKernelGGL((k_conv_mfma<WM, WN, TM, TN, true, true>), dim3(grid), dim3(CV_THREADS), 0, st, args);
+  else if (va)
+    hipLaunchKernelGGL((k_conv_mfma<WM, WN, TM, TN, true, false>), dim3(grid), dim3(CV_THREADS), 0, st, args);
+  else if (vb)
+    hipLaunchKernelGGL((k_conv_mfma<WM, WN, TM, TN, false, true>), dim3(grid), dim3(CV_THREADS), 0, st, args);
+  else
+    hipLaunchKernelGGL((k_conv_mfma<WM, WN, TM, TN, false, false>), dim3(grid), dim3(CV_THREADS), 0, st, args);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ph_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
+  PH_REQUIRE(d != nullptr, "conv_fwd: null desc");
+  PH_REQUIRE(d->cin > 0 && d->cout > 0 && d->kvol >= 1 && d->kvol <= PH_MAX_KVOL,
+             "conv_fwd: bad shape cin=%d cout=%d kvol=%d", d->cin, d->cout, d->kvol);
+  PH_REQUIRE(d->n_out >= 0 && d->n_out < 0x7FFFFF00, "conv_fwd: bad n_out");
+  PH_REQUIRE(d->nbr != nullptr || (d->kvol == 1 && d->n_in == d->n_out),
+             "conv_fwd: identity map needs kvol == 1 and n_in == n_out");
+  PH_REQUIRE(d->in && d->weight && d->out, "conv_fwd: null tensor");
+  if (d->n_out == 0) return 0;
+  ConvArgs a;
+  a.in = d->in;
+  a.w = d->weight;
+  a.nbr = d->nbr;
+  a.out = d->out;
+  a.n_in = d->n_in;
+  a.n_out = d->n_out;
+  a.cin = d->cin;
+  a.cout = d->cout;
+  a.kvol = d->kvol;
+  a.pro_act = d->pro_act;
+  a.pro_scale = d->pro_scale;
+  a.pro_shift = d->pro_shift;
+  a.bias = d->bias;
+  a.epi_scale = d->epi_scale;
+  a.epi_shift = d->epi_shift;
+  a.residual = d->residual;
+  a.epi_act = d->epi_act;
+  a.res_act = d->res_act;
+  a.slope = d->epi_slope;
+  a.n_row_tiles = a.n_col_tiles = 0;
+  hipStream_t st = ph_stream(stream);
+  if (d->cout <= 32) return launch_conv<4, 1, 1, 1>(a, st);
+  if (d->cout <= 64) return launch_conv<4, 1, 1, 2>(a, st);
+  return launch_conv<2, 2, 2, 2>(a, st);
+}

@@ -1,0 +1,372 @@
+// Coordinate maps and kernel maps for gfx950: hash insert / find, strided and generative
+// coordinate generation, output-stationary neighbour tables and their COO compaction.
+//
+// Everything here is HBM / latency bound integer work:
+// one thread per coordinate row, 16-byte row loads, wave64 ballot + popcount prefix sums for the
+// order-preserving compactions, no atomics on the output side.
+#include <stdarg.h>
+
+#include "ph_common.h"
+
+// ---- error plumbing ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void ph_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int ph_abi_version(void) { return PH_ABI_VERSION; }
+extern "C" const char *ph_last_error(void) { return g_err; }
+
+// ---- stable compaction --------------------------------------------------------------------------
+constexpr int CP_THREADS = 256;
+constexpr int CP_ROUNDS = 8;
+constexpr int CP_TILE = CP_THREADS * CP_ROUNDS;
+
+extern "C" int64_t ph_workspace_bytes(int64_t n) {
+  if (n < 0) n = 0;
+  // flags (n) + row_slot (4n) + rank_of (4n) + block counters (PH_MAX_KVOL segments) + slack
+  int64_t nb = n / CP_TILE + 2;
+  return 9 * n + (int64_t)PH_MAX_KVOL * nb * 4 + 4096;
+}
+
+template <class Pred>
+__global__ void __launch_bounds__(CP_THREADS)
+    k_compact_count(Pred pred, int64_t n, int32_t *__restrict__ block_counts) {
+  const int seg = blockIdx.y;
+  const int nb = gridDim.x;
+  const int64_t base = (int64_t)blockIdx.x * CP_TILE;
+  int cnt = 0;
+#pragma unroll
+  for (int r = 0; r < CP_ROUNDS; ++r) {
+    int64_t i = base + r * CP_THREADS + threadIdx.x;
+    bool p = (i < n) && pred(seg, i);
+    cnt += __popcll(__ballot(p));
+  }
+  __shared__ int wcnt[CP_THREADS / PH_WAVE];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) wcnt[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[(int64_t)seg * nb + blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+// exclusive scan of each segment's block counters in place; totals[seg] = segment sum
+__global__ void __launch_bounds__(256)
+    k_compact_scan(int32_t *__restrict__ block_counts, int nb, int32_t *__restrict__ totals) {
+  const int seg = blockIdx.x;
+  int32_t *c = block_counts + (int64_t)seg * nb;
+  __shared__ int wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int carry = 0;
+  for (int base = 0; base < nb; base += 256) {
+    int i = base + threadIdx.x;
+    int v = (i < nb) ? c[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (i < nb) c[i] = carry + woff + x - v;
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[seg] = carry;
+}
+
+template <class Pred, class Emit>
+__global__ void __launch_bounds__(CP_THREADS)
+    k_compact_scatter(Pred pred, Emit emit, int64_t n, const int32_t *__restrict__ block_offsets) {
+  const int seg = blockIdx.y;
+  const int nb = gridDim.x;
+  const int64_t base = (int64_t)blockIdx.x * CP_TILE;
+  __shared__ int wcnt[CP_THREADS / PH_WAVE];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int running = block_offsets[(int64_t)seg * nb + blockIdx.x];
+#pragma unroll 1
+  for (int r = 0; r < CP_ROUNDS; ++r) {
+    int64_t i = base + r * CP_THREADS + threadIdx.x;
+    bool p = (i < n) && pred(seg, i);
+    unsigned long long b = __ballot(p);
+    int wtot = __popcll(b);
+    int wpre = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[wave] = wtot;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wcnt[w];
+    int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (i < n) emit(seg, i, p ? running + woff + wpre : -1);
+    running += tot;
+    __syncthreads();
+  }
+}
+
+template <class Pred, class Emit>
+static int compact_run(Pred pred, Emit emit, int64_t n, int segs, int32_t *totals, void *ws,
+                       int64_t ws_bytes, hipStream_t st) {
+  int64_t nb = (n + CP_TILE - 1) / CP_TILE;
+  if (nb < 1) nb = 1;
+  PH_REQUIRE(ws_bytes >= (int64_t)segs * nb * 4, "compaction workspace too small (%lld < %lld)",
+             (long long)ws_bytes, (long long)(segs * nb * 4));
+  int32_t *block_counts = (int32_t *)ws;
+  dim3 grid((unsigned)nb, (unsigned)segs);
+  hipLaunchKernelGGL(k_compact_count<Pred>, grid, dim3(CP_THREADS), 0, st, pred, n, block_counts);
+  PH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_compact_scan, dim3(segs), dim3(256), 0, st, block_counts, (int)nb, totals);
+  PH_LAUNCH_CHECK();
+  hipLaunchKernelGGL((k_compact_scatter<Pred, Emit>), grid, dim3(CP_THREADS), 0, st, pred, emit, n,
+                     block_counts);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+struct PredFlag {
+  const uint8_t *flags;
+  __device__ bool operator()(int, int64_t i) const { return flags[i] != 0; }
+};
+struct EmitRows {
+  int32_t *keep_rows;
+  int32_t *rank_of;  // may be null
+  __device__ void operator()(int, int64_t i, int rank) const {
+    if (rank >= 0) keep_rows[rank] = (int32_t)i;
+    if (rank_of) rank_of[i] = rank;
+  }
+};
+
+int ph_compact_flags(const uint8_t *flags, int64_t n, int32_t *keep_rows, int32_t *rank_of,
+                     int32_t *n_keep, void *ws, int64_t ws_bytes, hipStream_t st) {
+  return compact_run(PredFlag{flags}, EmitRows{keep_rows, rank_of}, n, 1, n_keep, ws, ws_bytes, st);
+}
+
+extern "C" int ph_mask_compact(const uint8_t *mask, int64_t n, int32_t *keep_rows, int32_t *n_keep,
+                               void *ws, int64_t ws_bytes, ph_stream_t stream) {
+  PH_REQUIRE(n >= 0 && n < 0x7FFFFFFF, "mask_compact: bad n");
+  if (n == 0) {
+    PH_CHECK_HIP(hipMemsetAsync(n_keep, 0, 4, ph_stream(stream)));
+    return 0;
+  }
+  return ph_compact_flags(mask, n, keep_rows, nullptr, n_keep, ws, ws_bytes, ph_stream(stream));
+}
+
+// ---- hash insert --------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_insert(const int4 *__restrict__ coords, int64_t n, unsigned long long *__restrict__ tkeys,
+             int32_t *__restrict__ tvals, uint64_t mask, int32_t *__restrict__ row_slot) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = coords[i];
+  uint64_t key = ph_pack(c.x, c.y, c.z, c.w);
+  uint64_t slot = ph_hash(key) & mask;
+  for (;;) {
+    unsigned long long prev = atomicCAS(&tkeys[slot], (unsigned long long)PH_EMPTY_KEY,
+                                        (unsigned long long)key);
+    if (prev == PH_EMPTY_KEY || prev == key) break;
+    slot = (slot + 1) & mask;
+  }
+  atomicMin(&tvals[slot], (int32_t)i);
+  if (row_slot) row_slot[i] = (int32_t)slot;
+}
+
+struct PredFirst {
+  const int32_t *tvals;
+  const int32_t *row_slot;
+  __device__ bool operator()(int, int64_t i) const { return tvals[row_slot[i]] == (int32_t)i; }
+};
+
+__global__ void __launch_bounds__(256)
+    k_assign_rank(int64_t n, const int32_t *__restrict__ rank_of,
+                  const int32_t *__restrict__ row_slot, int32_t *__restrict__ tvals) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int r = rank_of[i];
+  if (r >= 0) tvals[row_slot[i]] = r;
+}
+
+__global__ void __launch_bounds__(256)
+    k_row2uniq(int64_t n, const int32_t *__restrict__ row_slot, const int32_t *__restrict__ tvals,
+               int32_t *__restrict__ row2uniq) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  row2uniq[i] = tvals[row_slot[i]];
+}
+
+static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
+extern "C" int ph_map_insert(const int32_t *coords, int64_t n, uint64_t *tkeys, int32_t *tvals,
+                             int64_t cap, int32_t *row2uniq, int32_t *uniq_rows, int32_t *n_uniq,
+                             void *ws, int64_t ws_bytes, ph_stream_t stream) {
+  hipStream_t st = ph_stream(stream);
+  PH_REQUIRE(n >= 0 && n < 0x3FFFFFFF, "map_insert: bad n=%lld", (long long)n);
+  PH_REQUIRE(ph_is_pow2(cap) && cap >= 2 * n && cap >= 2, "map_insert: cap=%lld must be pow2 >= 2n",
+             (long long)cap);
+  PH_CHECK_HIP(hipMemsetAsync(tkeys, 0xFF, (size_t)cap * 8, st));
+  PH_CHECK_HIP(hipMemsetAsync(tvals, 0x7F, (size_t)cap * 4, st));
+  if (n == 0) {
+    if (n_uniq) PH_CHECK_HIP(hipMemsetAsync(n_uniq, 0, 4, st));
+    return 0;
+  }
+  const uint64_t mask = (uint64_t)cap - 1;
+  if (uniq_rows == nullptr) {
+    // caller guarantees unique coordinates: rows keep their index.
+    hipLaunchKernelGGL(k_insert, dim3(nblk(n, 256)), dim3(256), 0, st, (const int4 *)coords, n,
+                       (unsigned long long *)tkeys, tvals, mask, (int32_t *)nullptr);
+    PH_LAUNCH_CHECK();
+    return 0;
+  }
+  PH_REQUIRE(row2uniq && n_uniq, "map_insert: row2uniq / n_uniq required with uniq_rows");
+  PH_REQUIRE(ws_bytes >= ph_workspace_bytes(n), "map_insert: workspace too small");
+  // carve: row_slot[n] | rank_of[n] | block counters
+  int32_t *row_slot = (int32_t *)ws;
+  int32_t *rank_of = row_slot + n;
+  char *rest = (char *)(rank_of + n);
+  int64_t rest_bytes = ws_bytes - 8 * n;
+  hipLaunchKernelGGL(k_insert, dim3(nblk(n, 256)), dim3(256), 0, st, (const int4 *)coords, n,
+                     (unsigned long long *)tkeys, tvals, mask, row_slot);
+  PH_LAUNCH_CHECK();
+  int rc = compact_run(PredFirst{tvals, row_slot}, EmitRows{uniq_rows, rank_of}, n, 1, n_uniq, rest,
+                       rest_bytes, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_assign_rank, dim3(nblk(n, 256)), dim3(256), 0, st, n, rank_of, row_slot, tvals);
+  PH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_row2uniq, dim3(nblk(n, 256)), dim3(256), 0, st, n, row_slot, tvals, row2uniq);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- find ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_find(const int4 *__restrict__ q, int64_t n, const uint64_t *__restrict__ tkeys,
+           const int32_t *__restrict__ tvals, uint64_t mask, int32_t *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = q[i];
+  out[i] = ph_find(tkeys, tvals, mask, ph_pack(c.x, c.y, c.z, c.w));
+}
+
+extern "C" int ph_map_find(const int32_t *query, int64_t n, const uint64_t *tkeys,
+                           const int32_t *tvals, int64_t cap, int32_t *out_rows,
+                           ph_stream_t stream) {
+  PH_REQUIRE(ph_is_pow2(cap), "map_find: cap must be pow2");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_find, dim3(nblk(n, 256)), dim3(256), 0, ph_stream(stream),
+                     (const int4 *)query, n, tkeys, tvals, (uint64_t)cap - 1, out_rows);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- coordinate generation ----------------------------------------------------------------------
+__device__ __forceinline__ int floor_to(int v, int ts) {
+  int q = v / ts;
+  if ((v % ts) != 0 && ((v < 0) != (ts < 0))) --q;
+  return q * ts;
+}
+
+__global__ void __launch_bounds__(256)
+    k_coords_floor(const int4 *__restrict__ in, int64_t n, int ts, int4 *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int4 c = in[i];
+  out[i] = make_int4(c.x, floor_to(c.y, ts), floor_to(c.z, ts), floor_to(c.w, ts));
+}
+
+extern "C" int ph_coords_floor(const int32_t *coords, int64_t n, int32_t ts, int32_t *out,
+                               ph_stream_t stream) {
+  PH_REQUIRE(ts > 0, "coords_floor: ts must be > 0");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_coords_floor, dim3(nblk(n, 256)), dim3(256), 0, ph_stream(stream),
+                     (const int4 *)coords, n, ts, (int4 *)out);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void __launch_bounds__(256)
+    k_coords_expand(const int4 *__restrict__ in, int64_t n, int ts, int4 *__restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 8) return;
+  int64_t i = t >> 3;
+  int k = (int)(t & 7);
+  int4 c = in[i];
+  out[t] = make_int4(c.x, c.y + (k & 1) * ts, c.z + ((k >> 1) & 1) * ts, c.w + ((k >> 2) & 1) * ts);
+}
+
+extern "C" int ph_coords_expand(const int32_t *coords, int64_t n, int32_t ts_out, int32_t *out,
+                                ph_stream_t stream) {
+  PH_REQUIRE(ts_out > 0, "coords_expand: ts_out must be > 0");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_coords_expand, dim3(nblk(n * 8, 256)), dim3(256), 0, ph_stream(stream),
+                     (const int4 *)coords, n, ts_out, (int4 *)out);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- neighbour table ----------------------------------------------------------------------------
+struct NbrOffsets {
+  int32_t d[PH_MAX_KVOL][3];
+};
+
+__global__ void __launch_bounds__(256)
+    k_nbr_build(const int4 *__restrict__ out_coords, int64_t n_out,
+                const uint64_t *__restrict__ tkeys, const int32_t *__restrict__ tvals,
+                uint64_t mask, NbrOffsets off, int32_t *__restrict__ nbr) {
+  const int k = blockIdx.y;
+  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_out) return;
+  int4 c = out_coords[o];
+  uint64_t key = ph_pack(c.x, c.y + off.d[k][0], c.z + off.d[k][1], c.w + off.d[k][2]);
+  nbr[(int64_t)k * n_out + o] = ph_find(tkeys, tvals, mask, key);
+}
+
+extern "C" int ph_nbr_build(const int32_t *out_coords, int64_t n_out, const uint64_t *in_tkeys,
+                            const int32_t *in_tvals, int64_t in_cap, const int32_t *h_offsets,
+                            int32_t kvol, int32_t *nbr, ph_stream_t stream) {
+  PH_REQUIRE(kvol >= 1 && kvol <= PH_MAX_KVOL, "nbr_build: kvol=%d out of range", kvol);
+  PH_REQUIRE(ph_is_pow2(in_cap), "nbr_build: cap must be pow2");
+  if (n_out == 0) return 0;
+  NbrOffsets off;
+  memset(&off, 0, sizeof(off));
+  memcpy(off.d, h_offsets, sizeof(int32_t) * 3 * kvol);
+  dim3 grid(nblk(n_out, 256), (unsigned)kvol);
+  hipLaunchKernelGGL(k_nbr_build, grid, dim3(256), 0, ph_stream(stream), (const int4 *)out_coords,
+                     n_out, in_tkeys, in_tvals, (uint64_t)in_cap - 1, off, nbr);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- COO kernel map ------------------------------------------------------------------------------
+struct PredNbr {
+  const int32_t *nbr;
+  int64_t n_out;
+  __device__ bool operator()(int seg, int64_t i) const { return nbr[(int64_t)seg * n_out + i] >= 0; }
+};
+struct EmitPairs {
+  const int32_t *nbr;
+  int64_t n_out;
+  int32_t *pairs_in;
+  int32_t *pairs_out;
+  __device__ void operator()(int seg, int64_t i, int rank) const {
+    if (rank < 0) return;
+    int64_t base = (int64_t)seg * n_out;
+    pairs_in[base + rank] = nbr[base + i];
+    pairs_out[base + rank] = (int32_t)i;
+  }
+};
+
+extern "C" int ph_kmap_compact(const int32_t *nbr, int32_t kvol, int64_t n_out, int32_t *pairs_in,
+                               int32_t *pairs_out, int32_t *counts, void *ws, int64_t ws_bytes,
+                               ph_stream_t stream) {
+  PH_REQUIRE(kvol >= 1 && kvol <= PH_MAX_KVOL, "kmap_compact: kvol=%d out of range", kvol);
+  if (n_out == 0) {
+    PH_CHECK_HIP(hipMemsetAsync(counts, 0, 4 * kvol, ph_stream(stream)));
+    return 0;
+  }
+  return compact_run(PredNbr{nbr, n_out}, EmitPairs{nbr, n_out, pairs_in, pairs_out}, n_out, kvol,
+                     counts, ws, ws_bytes, ph_stream(stream));
+}

@@ -1,0 +1,216 @@
+// Row movement, local max pooling and dense <-> sparse conversion kernels (gfx950).
+// All of these are pure HBM-bound copies: one float per lane with the
+// channel index fastest so that a row of C floats is read/written as contiguous 4*C bytes.
+#include "ph_common.h"
+
+static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
+// ---- gather / scatter-add -------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+    k_gather_rows(const T *__restrict__ src, int c, const int32_t *__restrict__ rows, int64_t n_out,
+                  T *__restrict__ dst) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out * c) return;
+  int64_t j = t / c;
+  int ch = (int)(t - j * c);
+  int r = rows[j];
+  T v;
+  memset(&v, 0, sizeof(T));
+  if (r >= 0) v = src[(int64_t)r * c + ch];
+  dst[t] = v;
+}
+
+extern "C" int ph_gather_rows(const void *src, int32_t c, const int32_t *rows, int64_t n_out,
+                              void *dst, ph_stream_t stream) {
+  PH_REQUIRE(c > 0, "gather_rows: c must be > 0");
+  if (n_out == 0) return 0;
+  hipStream_t st = ph_stream(stream);
+  if (c % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    int c4 = c / 4;
+    hipLaunchKernelGGL(k_gather_rows<float4>, dim3(nblk(n_out * c4, 256)), dim3(256), 0, st,
+                       (const float4 *)src, c4, rows, n_out, (float4 *)dst);
+  } else {
+    hipLaunchKernelGGL(k_gather_rows<float>, dim3(nblk(n_out * c, 256)), dim3(256), 0, st,
+                       (const float *)src, c, rows, n_out, (float *)dst);
+  }
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void __launch_bounds__(256)
+    k_scatter_add_rows(const float *__restrict__ src, int c, const int32_t *__restrict__ rows,
+                       int64_t n_src, float *__restrict__ dst) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_src * c) return;
+  int64_t i = t / c;
+  int ch = (int)(t - i * c);
+  int r = rows[i];
+  if (r >= 0) dst[(int64_t)r * c + ch] += src[t];
+}
+
+extern "C" int ph_scatter_add_rows(const float *src, int32_t c, const int32_t *rows, int64_t n_src,
+                                   float *dst, ph_stream_t stream) {
+  PH_REQUIRE(c > 0, "scatter_add_rows: c must be > 0");
+  if (n_src == 0) return 0;
+  hipLaunchKernelGGL(k_scatter_add_rows, dim3(nblk(n_src * c, 256)), dim3(256), 0,
+                     ph_stream(stream), src, c, rows, n_src, dst);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- local max pooling ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_maxpool(const float *__restrict__ in, int c, const int32_t *__restrict__ nbr, int kvol,
+              int64_t n_out, float *__restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out * c) return;
+  int64_t o = t / c;
+  int ch = (int)(t - o * c);
+  float m = 0.f;
+  bool any = false;
+  for (int k = 0; k < kvol; ++k) {
+    int r = nbr[(int64_t)k * n_out + o];
+    if (r >= 0) {
+      float v = in[(int64_t)r * c + ch];
+      m = any ? fmaxf(m, v) : v;
+      any = true;
+    }
+  }
+  out[t] = m;
+}
+
+extern "C" int ph_maxpool_fwd(const float *in, int32_t c, const int32_t *nbr, int32_t kvol,
+                              int64_t n_out, float *out, ph_stream_t stream) {
+  PH_REQUIRE(c > 0 && kvol >= 1 && kvol <= PH_MAX_KVOL, "maxpool_fwd: bad shape");
+  if (n_out == 0) return 0;
+  hipLaunchKernelGGL(k_maxpool, dim3(nblk(n_out * c, 256)), dim3(256), 0, ph_stream(stream), in, c,
+                     nbr, kvol, n_out, out);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- dense <-> sparse -------------------------------------------------------------------------------
+struct Dims4 {
+  int b, x, y, z;
+};
+
+__device__ __forceinline__ int floor_div(int v, int ts) {
+  int q = v / ts;
+  if ((v % ts) != 0 && ((v < 0) != (ts < 0))) --q;
+  return q;
+}
+
+__global__ void __launch_bounds__(256)
+    k_to_dense(const float *__restrict__ feats, const int4 *__restrict__ coords, int64_t n, int c,
+               int mx, int my, int mz, int ts, Dims4 d, float *__restrict__ dense) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * c) return;
+  int64_t i = t / c;
+  int ch = (int)(t - i * c);
+  int4 p = coords[i];
+  int x = floor_div(p.y - mx, ts), y = floor_div(p.z - my, ts), z = floor_div(p.w - mz, ts);
+  if (p.x < 0 || p.x >= d.b || x < 0 || x >= d.x || y < 0 || y >= d.y || z < 0 || z >= d.z) return;
+  int64_t site = ((int64_t)x * d.y + y) * d.z + z;
+  dense[((int64_t)p.x * c + ch) * ((int64_t)d.x * d.y * d.z) + site] = feats[t];
+}
+
+extern "C" int ph_to_dense(const float *feats, const int32_t *coords, int64_t n, int32_t c,
+                           const int32_t *h_min3, int32_t ts, const int32_t *h_dims4, float *dense,
+                           ph_stream_t stream) {
+  PH_REQUIRE(c > 0 && ts > 0, "to_dense: bad c/ts");
+  if (n == 0) return 0;
+  Dims4 d{h_dims4[0], h_dims4[1], h_dims4[2], h_dims4[3]};
+  hipLaunchKernelGGL(k_to_dense, dim3(nblk(n * c, 256)), dim3(256), 0, ph_stream(stream), feats,
+                     (const int4 *)coords, n, c, h_min3[0], h_min3[1], h_min3[2], ts, d, dense);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+// flags[site] = any channel != 0 ; sites are enumerated (b, x, y, z) lexicographically
+__global__ void __launch_bounds__(256)
+    k_site_flags(const float *__restrict__ dense, int c, int64_t nsite_per_b, int64_t nsites,
+                 uint8_t *__restrict__ flags) {
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsites) return;
+  int64_t b = s / nsite_per_b;
+  int64_t site = s - b * nsite_per_b;
+  const float *p = dense + b * c * nsite_per_b + site;
+  bool any = false;
+  for (int ch = 0; ch < c; ++ch) any |= (p[(int64_t)ch * nsite_per_b] != 0.f);
+  flags[s] = any ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+    k_sites_to_coords(const int32_t *__restrict__ keep_rows, const int32_t *__restrict__ n_rows,
+                      Dims4 d, int4 *__restrict__ out_coords) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= *n_rows) return;
+  int64_t s = keep_rows[j];
+  int z = (int)(s % d.z);
+  s /= d.z;
+  int y = (int)(s % d.y);
+  s /= d.y;
+  int x = (int)(s % d.x);
+  s /= d.x;
+  out_coords[j] = make_int4((int)s, x, y, z);
+}
+
+extern "C" int ph_to_sparse_coords(const float *dense, int32_t c, const int32_t *h_dims4,
+                                   int32_t *out_coords, int32_t *n_rows, void *ws,
+                                   int64_t ws_bytes, ph_stream_t stream) {
+  Dims4 d{h_dims4[0], h_dims4[1], h_dims4[2], h_dims4[3]};
+  int64_t per_b = (int64_t)d.x * d.y * d.z;
+  int64_t nsites = per_b * d.b;
+  PH_REQUIRE(c > 0 && nsites < 0x7FFFFF00, "to_sparse_coords: bad shape");
+  hipStream_t st = ph_stream(stream);
+  if (nsites == 0) {
+    PH_CHECK_HIP(hipMemsetAsync(n_rows, 0, 4, st));
+    return 0;
+  }
+  PH_REQUIRE(ws_bytes >= ph_workspace_bytes(nsites), "to_sparse_coords: workspace too small");
+  // carve: flags[nsites] (padded to 16) | keep_rows[nsites] | block counters
+  uint8_t *flags = (uint8_t *)ws;
+  int64_t fpad = (nsites + 15) & ~(int64_t)15;
+  int32_t *keep_rows = (int32_t *)(flags + fpad);
+  char *rest = (char *)(keep_rows + nsites);
+  int64_t rest_bytes = ws_bytes - fpad - 4 * nsites;
+  hipLaunchKernelGGL(k_site_flags, dim3(nblk(nsites, 256)), dim3(256), 0, st, dense, c, per_b, nsites,
+                     flags);
+  PH_LAUNCH_CHECK();
+  int rc = ph_compact_flags(flags, nsites, keep_rows, nullptr, n_rows, rest, rest_bytes, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sites_to_coords, dim3(nblk(nsites, 256)), dim3(256), 0, st, keep_rows, n_rows, d,
+                     (int4 *)out_coords);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void __launch_bounds__(256)
+    k_dense_gather(const float *__restrict__ dense, int c, Dims4 d, const int4 *__restrict__ sc,
+                   int64_t n, float *__restrict__ feats) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * c) return;
+  int64_t i = t / c;
+  int ch = (int)(t - i * c);
+  int4 p = sc[i];
+  float v = 0.f;
+  if (p.x >= 0 && p.x < d.b && p.y >= 0 && p.y < d.x && p.z >= 0 && p.z < d.y && p.w >= 0 && p.w < d.z) {
+    int64_t per_b = (int64_t)d.x * d.y * d.z;
+    int64_t site = ((int64_t)p.y * d.y + p.z) * d.z + p.w;
+    v = dense[((int64_t)p.x * c + ch) * per_b + site];
+  }
+  feats[t] = v;
+}
+
+extern "C" int ph_dense_gather(const float *dense, int32_t c, const int32_t *h_dims4,
+                               const int32_t *site_coords, int64_t n, float *feats,
+                               ph_stream_t stream) {
+  PH_REQUIRE(c > 0, "dense_gather: bad c");
+  if (n == 0) return 0;
+  Dims4 d{h_dims4[0], h_dims4[1], h_dims4[2], h_dims4[3]};
+  hipLaunchKernelGGL(k_dense_gather, dim3(nblk(n * c, 256)), dim3(256), 0, ph_stream(stream), dense, c,
+                     d, (const int4 *)site_coords, n, feats);
+  PH_LAUNCH_CHECK();
+  return 0;
+}

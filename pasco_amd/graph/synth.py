@@ -1,0 +1,129 @@
+"""Synthetic scene S10 and MIMO subnet inputs: the measurement workload.
+
+No dataset is available offline, so the benchmark scene is generated: a 256x256x32 grid with a wavy
+two-voxel ground sheet and hollow boxes dropped on it until ~10 % of the sites are occupied
+(N1 ~ 210 k, N2 ~ 44 k, N4 ~ 8.9 k).  Input voxels are a Bernoulli(0.30) subset (LiDAR-like), points
+are 1 + Poisson(1) per input voxel with N(0,1) features.  Subnet i sees the scene through the rigid
+transform T_i exactly as the reference's data pipeline does
+(pasco/data/semantic_kitti/kitti_dataset.py:173-177,428-430; pasco/models/transform_utils.py:60-74).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+GRID = (256, 256, 32)
+VOXEL_SIZE = 0.2
+VOX_ORIGIN = np.array([0.0, -25.6, -2.0])
+THETAS_DEG = (0, 10, -10, 20, -20, 30, -30, 5)
+
+
+def make_occupancy(seed: int = 0, grid=GRID, target: float = 0.10) -> np.ndarray:
+    """bool [X,Y,Z] completed-scene occupancy."""
+    rng = np.random.default_rng(seed)
+    X, Y, Z = grid
+    occ = np.zeros(grid, dtype=bool)
+    xs, ys = np.meshgrid(np.arange(X), np.arange(Y), indexing="ij")
+    h = np.floor(9 + 2 * np.sin(xs / 40.0) + 2 * np.cos(ys / 55.0)).astype(np.int64)
+    h = np.clip(h * Z // 32, 1, Z - 2)
+    cols = rng.random((X, Y)) < 0.9
+    for dz in (0, 1):
+        zz = np.clip(h + dz, 0, Z - 1)
+        occ[xs[cols], ys[cols], zz[cols]] = True
+    total = occ.size
+    guard = 0
+    while occ.sum() / total < target and guard < 10000:
+        guard += 1
+        sx, sy = rng.integers(4, 30, size=2)
+        sz = rng.integers(3, 16)
+        sx, sy, sz = min(sx, X - 1), min(sy, Y - 1), min(sz, Z - 2)
+        x0 = rng.integers(0, X - sx)
+        y0 = rng.integers(0, Y - sy)
+        z0 = int(min(h[x0, y0] + 2, Z - sz))
+        box = np.zeros((sx, sy, sz), dtype=bool)
+        box[[0, -1], :, :] = True
+        box[:, [0, -1], :] = True
+        box[:, :, [0, -1]] = True
+        occ[x0:x0 + sx, y0:y0 + sy, z0:z0 + sz] |= box
+    return occ
+
+
+def generate_transformation(rot_deg: float, translation) -> np.ndarray:
+    """4x4 rigid transform: yaw about z by rot_deg, then translation (metres).
+    Mirrors the reference's generate_transformation (transform_utils.py:7-29) for the flip-free,
+    unit-scale case used at test time."""
+    th = math.radians(rot_deg)
+    T = np.eye(4)
+    T[0, 0], T[0, 1], T[1, 0], T[1, 1] = math.cos(th), -math.sin(th), math.sin(th), math.cos(th)
+    T[:3, 3] = translation
+    return T
+
+
+def transform_coords(coords: np.ndarray, T: np.ndarray) -> np.ndarray:
+    """Voxel indices -> metres (voxel centres) -> T -> voxel indices (rounded).
+    Follows pasco/models/transform_utils.py:60-74."""
+    pts = (coords.astype(np.float64) + 0.5) * VOXEL_SIZE + VOX_ORIGIN
+    pts_h = np.concatenate([pts, np.ones((pts.shape[0], 1))], axis=1)
+    out = (T @ pts_h.T).T[:, :3]
+    return np.round((out - VOX_ORIGIN) / VOXEL_SIZE - 0.5).astype(np.int64)
+
+
+@dataclass
+class Scene:
+    n_infers: int
+    occ: np.ndarray                      # completed occupancy, canonical frame
+    in_feats: List[torch.Tensor]         # per subnet [P_i, C_in]
+    in_coords: List[torch.Tensor]        # per subnet [P_i, 3] int64 (already transformed)
+    Ts: List[torch.Tensor]
+    min_Cs: List[torch.Tensor]
+    max_Cs: List[torch.Tensor]
+    global_min_Cs: torch.Tensor
+    global_max_Cs: torch.Tensor
+    keep_sets: Dict[int, List[torch.Tensor]] = field(default_factory=dict)  # scale -> per subnet coords [N,3]
+
+    def to(self, device):
+        mv = lambda t: t.to(device)
+        return Scene(self.n_infers, self.occ, [mv(t) for t in self.in_feats], [mv(t) for t in self.in_coords],
+                     self.Ts, [mv(t) for t in self.min_Cs], [mv(t) for t in self.max_Cs],
+                     mv(self.global_min_Cs), mv(self.global_max_Cs),
+                     {s: [mv(t) for t in v] for s, v in self.keep_sets.items()})
+
+
+def make_scene(seed: int = 0, n_infers: int = 3, in_channels: int = 283, grid=GRID, occupancy: float = 0.10,
+               input_fraction: float = 0.30, complete_scale: int = 8) -> Scene:
+    rng = np.random.default_rng(seed + 1000)
+    occ = make_occupancy(seed, grid, occupancy)
+    g1 = np.argwhere(occ)                                    # [N1,3] lexicographic
+    sel = rng.random(g1.shape[0]) < input_fraction
+    i1 = g1[sel]
+    # points: 1 + Poisson(1) per input voxel
+    reps = 1 + rng.poisson(1.0, size=i1.shape[0])
+    pts_vox = np.repeat(i1, reps, axis=0)
+    in_feats, in_coords, Ts, min_Cs, max_Cs = [], [], [], [], []
+    keep_sets: Dict[int, List[torch.Tensor]] = {1: [], 2: [], 4: []}
+    for i in range(n_infers):
+        t = np.array([((i % 3) - 1) * 0.2, (((i // 3) % 3) - 1) * 0.2, 0.0])
+        T = generate_transformation(THETAS_DEG[i % len(THETAS_DEG)], t)
+        g1_t = transform_coords(g1, T)
+        mn = np.floor(g1_t.min(axis=0) / complete_scale).astype(np.int64) * complete_scale
+        mx = g1_t.max(axis=0)
+        c_t = transform_coords(pts_vox, T)
+        f = torch.from_numpy(rng.standard_normal((c_t.shape[0], in_channels)).astype(np.float32))
+        in_feats.append(f)
+        in_coords.append(torch.from_numpy(c_t))
+        Ts.append(torch.from_numpy(T).float())
+        min_Cs.append(torch.from_numpy(mn))
+        max_Cs.append(torch.from_numpy(mx))
+        for s in (1, 2, 4):
+            cs = np.unique(np.floor_divide(g1_t, s) * s, axis=0)
+            keep_sets[s].append(torch.from_numpy(cs))
+    gmin = torch.stack(min_Cs).min(dim=0)[0]
+    gmax = torch.stack(max_Cs).max(dim=0)[0]
+    # extent rounded up to a multiple of complete_scale (reference collate.py:76-81)
+    ext = torch.ceil((gmax - gmin + 1).double() / complete_scale).long() * complete_scale
+    gmax = gmin + ext - 1
+    return Scene(n_infers, occ, in_feats, in_coords, Ts, min_Cs, max_Cs, gmin, gmax, keep_sets)

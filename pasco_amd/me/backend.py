@@ -1,0 +1,383 @@
+"""ctypes binding of the flat C ABI declared in include/pasco_hip.h.
+
+The product backend is libpascohip.so (hand-written HIP for gfx950).  There is NO CPU fallback in
+this package: asking for a backend for a CPU tensor raises unless a test harness has explicitly
+registered a checker library (tests register oracle/libpasco_oracle.so, which exports the same ABI
+under the `pho_` prefix).  On a machine with a GPU a missing/unloadable libpascohip.so is a hard
+error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpascohip.so")
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+MAX_KVOL = 64
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int32
+
+
+class ConvDesc(C.Structure):
+    """Mirror of `ph_conv_desc` (include/pasco_hip.h)."""
+
+    _fields_ = [
+        ("in_", _vp), ("weight", _vp), ("nbr", _vp), ("out", _vp),
+        ("n_in", _i64), ("n_out", _i64),
+        ("cin", _i32), ("cout", _i32), ("kvol", _i32), ("pro_act", _i32),
+        ("pro_scale", _vp), ("pro_shift", _vp), ("bias", _vp),
+        ("epi_scale", _vp), ("epi_shift", _vp),
+        ("epi_act", _i32), ("epi_slope", C.c_float),
+        ("residual", _vp), ("res_act", _i32), ("reserved", _i32),
+    ]
+
+
+# name -> argtypes (everything returns int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "abi_version": [],
+    "last_error": [],
+    "workspace_bytes": [_i64],
+    "map_insert": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
+    "map_find": [_vp, _i64, _vp, _vp, _i64, _vp, _vp],
+    "coords_floor": [_vp, _i64, _i32, _vp, _vp],
+    "coords_expand": [_vp, _i64, _i32, _vp, _vp],
+    "nbr_build": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _vp],
+    "kmap_compact": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
+    "conv_fwd": [C.POINTER(ConvDesc), _vp],
+    "maxpool_fwd": [_vp, _i32, _vp, _i32, _i64, _vp, _vp],
+    "mask_compact": [_vp, _i64, _vp, _vp, _vp, _i64, _vp],
+    "gather_rows": [_vp, _i32, _vp, _i64, _vp, _vp],
+    "scatter_add_rows": [_vp, _i32, _vp, _i64, _vp, _vp],
+    "to_dense": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp],
+    "to_sparse_coords": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
+    "dense_gather": [_vp, _i32, _vp, _vp, _i64, _vp, _vp],
+}
+_RESTYPES = {"last_error": C.c_char_p, "workspace_bytes": _i64}
+# optional entry points (present in the HIP library only)
+_OPTIONAL = {
+    "attn_cross_fwd": [_vp] * 3 + [_vp] * 3 + [_i64, _i32, _i32, _i32, C.c_float, _vp, _vp],
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+class CBackend:
+    """Thin typed wrapper over one shared library exporting the pasco_hip.h ABI."""
+
+    def __init__(self, path: str, prefix: str, device_type: str):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} not found - build it first (python -m pasco_amd.build); "
+                "pasco_amd has no CPU fallback")
+        self.path = path
+        self.prefix = prefix
+        self.device_type = device_type
+        self.lib = C.CDLL(path)
+        self.fn: Dict[str, object] = {}
+        for name, argtypes in _SIGNATURES.items():
+            f = getattr(self.lib, prefix + name)
+            f.argtypes = argtypes
+            f.restype = _RESTYPES.get(name, C.c_int)
+            self.fn[name] = f
+        for name, argtypes in _OPTIONAL.items():
+            f = getattr(self.lib, prefix + name, None)
+            if f is not None:
+                f.argtypes = argtypes
+                f.restype = C.c_int
+                self.fn[name] = f
+        v = self.fn["abi_version"]()
+        if v != 1:
+            raise RuntimeError(f"{path}: ABI version {v}, expected 1")
+        self._ws: Dict[torch.device, torch.Tensor] = {}
+
+    # -- helpers -----------------------------------------------------------------------------------
+    def has(self, name: str) -> bool:
+        return name in self.fn
+
+    def _check(self, rc: int, name: str):
+        if rc != 0:
+            msg = self.fn["last_error"]()
+            raise RuntimeError(f"{self.prefix}{name} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def stream(self, device: torch.device) -> Optional[int]:
+        if device.type == "cuda":
+            return torch.cuda.current_stream(device).cuda_stream
+        return None
+
+    def workspace(self, n: int, device: torch.device) -> torch.Tensor:
+        need = int(self.fn["workspace_bytes"](int(n)))
+        ws = self._ws.get(device)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+            self._ws[device] = ws
+        return ws
+
+    def _chk(self, t: torch.Tensor, dtype, name: str):
+        if t.dtype != dtype:
+            raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+        if not t.is_contiguous():
+            raise ValueError(f"{name}: tensor must be contiguous")
+        if t.device.type != self.device_type:
+            raise ValueError(f"{name}: tensor on {t.device}, backend serves {self.device_type}")
+
+    # -- coordinate maps ---------------------------------------------------------------------------
+    @staticmethod
+    def table_capacity(n: int) -> int:
+        cap = 16
+        while cap < 2 * n:
+            cap <<= 1
+        return cap
+
+    def map_insert(self, coords: torch.Tensor, dedup: bool = True):
+        """coords int32 [N,4] -> (tkeys, tvals, row2uniq|None, uniq_rows|None, n_uniq)."""
+        self._chk(coords, torch.int32, "coords")
+        n = coords.shape[0]
+        dev = coords.device
+        cap = self.table_capacity(n)
+        tkeys = torch.empty(cap, dtype=torch.int64, device=dev)
+        tvals = torch.empty(cap, dtype=torch.int32, device=dev)
+        ws = self.workspace(n, dev)
+        if dedup:
+            row2uniq = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+            uniq_rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+            n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
+            rc = self.fn["map_insert"](_ptr(coords), n, _ptr(tkeys), _ptr(tvals), cap, _ptr(row2uniq),
+                                       _ptr(uniq_rows), _ptr(n_uniq), _ptr(ws), ws.numel(),
+                                       self.stream(dev))
+            self._check(rc, "map_insert")
+            nu = int(n_uniq.item())
+            return tkeys, tvals, row2uniq[:n], uniq_rows[:nu], nu
+        rc = self.fn["map_insert"](_ptr(coords), n, _ptr(tkeys), _ptr(tvals), cap, None, None, None,
+                                   _ptr(ws), ws.numel(), self.stream(dev))
+        self._check(rc, "map_insert")
+        return tkeys, tvals, None, None, n
+
+    def map_find(self, query: torch.Tensor, tkeys: torch.Tensor, tvals: torch.Tensor) -> torch.Tensor:
+        self._chk(query, torch.int32, "query")
+        n = query.shape[0]
+        out = torch.empty(n, dtype=torch.int32, device=query.device)
+        rc = self.fn["map_find"](_ptr(query), n, _ptr(tkeys), _ptr(tvals), tkeys.numel(), _ptr(out),
+                                 self.stream(query.device))
+        self._check(rc, "map_find")
+        return out
+
+    def coords_floor(self, coords: torch.Tensor, ts: int) -> torch.Tensor:
+        self._chk(coords, torch.int32, "coords")
+        out = torch.empty_like(coords)
+        rc = self.fn["coords_floor"](_ptr(coords), coords.shape[0], int(ts), _ptr(out),
+                                     self.stream(coords.device))
+        self._check(rc, "coords_floor")
+        return out
+
+    def coords_expand(self, coords: torch.Tensor, ts_out: int) -> torch.Tensor:
+        self._chk(coords, torch.int32, "coords")
+        n = coords.shape[0]
+        out = torch.empty((n * 8, 4), dtype=torch.int32, device=coords.device)
+        rc = self.fn["coords_expand"](_ptr(coords), n, int(ts_out), _ptr(out), self.stream(coords.device))
+        self._check(rc, "coords_expand")
+        return out
+
+    def nbr_build(self, out_coords: torch.Tensor, tkeys: torch.Tensor, tvals: torch.Tensor,
+                  offsets) -> torch.Tensor:
+        """offsets: list of (dx,dy,dz) already scaled by the tensor stride."""
+        self._chk(out_coords, torch.int32, "out_coords")
+        kvol = len(offsets)
+        if not 1 <= kvol <= MAX_KVOL:
+            raise ValueError(f"kernel volume {kvol} not supported (max {MAX_KVOL})")
+        n_out = out_coords.shape[0]
+        flat = (_i32 * (3 * kvol))(*[int(v) for o in offsets for v in o])
+        nbr = torch.empty((kvol, n_out), dtype=torch.int32, device=out_coords.device)
+        rc = self.fn["nbr_build"](_ptr(out_coords), n_out, _ptr(tkeys), _ptr(tvals), tkeys.numel(),
+                                  C.cast(flat, _vp), kvol, _ptr(nbr), self.stream(out_coords.device))
+        self._check(rc, "nbr_build")
+        return nbr
+
+    def kmap_compact(self, nbr: torch.Tensor):
+        """-> (pairs_in [K,N], pairs_out [K,N], counts [K]) ; segment k valid up to counts[k]."""
+        self._chk(nbr, torch.int32, "nbr")
+        kvol, n_out = nbr.shape
+        dev = nbr.device
+        pin = torch.empty_like(nbr)
+        pout = torch.empty_like(nbr)
+        counts = torch.zeros(kvol, dtype=torch.int32, device=dev)
+        ws = self.workspace(n_out, dev)
+        rc = self.fn["kmap_compact"](_ptr(nbr), kvol, n_out, _ptr(pin), _ptr(pout), _ptr(counts),
+                                     _ptr(ws), ws.numel(), self.stream(dev))
+        self._check(rc, "kmap_compact")
+        return pin, pout, counts
+
+    # -- convolution -------------------------------------------------------------------------------
+    def conv_fwd(self, x: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tensor], n_out: int,
+                 *, bias=None, pro_scale=None, pro_shift=None, pro_act=ACT_NONE, epi_scale=None,
+                 epi_shift=None, epi_act=ACT_NONE, slope=0.01, residual=None, res_act=ACT_NONE,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._chk(x, torch.float32, "in")
+        self._chk(weight, torch.float32, "weight")
+        if weight.dim() == 2:
+            kvol, (cin, cout) = 1, weight.shape
+        else:
+            kvol, cin, cout = weight.shape
+        if x.shape[1] != cin:
+            raise ValueError(f"conv: input has {x.shape[1]} channels, kernel expects {cin}")
+        if nbr is not None:
+            self._chk(nbr, torch.int32, "nbr")
+            if tuple(nbr.shape) != (kvol, n_out):
+                raise ValueError(f"conv: nbr shape {tuple(nbr.shape)} != {(kvol, n_out)}")
+        if out is None:
+            out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+        d = ConvDesc()
+        d.in_, d.weight, d.nbr, d.out = _ptr(x), _ptr(weight), _ptr(nbr), _ptr(out)
+        d.n_in, d.n_out, d.cin, d.cout, d.kvol = x.shape[0], n_out, cin, cout, kvol
+        d.pro_act, d.epi_act, d.res_act, d.epi_slope = pro_act, epi_act, res_act, float(slope)
+        for name, t, c in (("pro_scale", pro_scale, cin), ("pro_shift", pro_shift, cin),
+                           ("bias", bias, cout), ("epi_scale", epi_scale, cout),
+                           ("epi_shift", epi_shift, cout)):
+            if t is not None:
+                self._chk(t, torch.float32, name)
+                if t.numel() != c:
+                    raise ValueError(f"conv: {name} has {t.numel()} entries, expected {c}")
+            setattr(d, name, _ptr(t))
+        if residual is not None:
+            self._chk(residual, torch.float32, "residual")
+            if tuple(residual.shape) != (n_out, cout):
+                raise ValueError("conv: residual shape mismatch")
+        d.residual = _ptr(residual)
+        rc = self.fn["conv_fwd"](C.byref(d), self.stream(x.device))
+        self._check(rc, "conv_fwd")
+        return out
+
+    def maxpool_fwd(self, x: torch.Tensor, nbr: torch.Tensor) -> torch.Tensor:
+        self._chk(x, torch.float32, "in")
+        self._chk(nbr, torch.int32, "nbr")
+        kvol, n_out = nbr.shape
+        out = torch.empty((n_out, x.shape[1]), dtype=torch.float32, device=x.device)
+        rc = self.fn["maxpool_fwd"](_ptr(x), x.shape[1], _ptr(nbr), kvol, n_out, _ptr(out),
+                                    self.stream(x.device))
+        self._check(rc, "maxpool_fwd")
+        return out
+
+    # -- rows --------------------------------------------------------------------------------------
+    def mask_compact(self, mask: torch.Tensor) -> torch.Tensor:
+        """bool/uint8 mask [N] -> int32 rows kept (order preserved)."""
+        if mask.dtype == torch.bool:
+            mask = mask.view(torch.uint8)
+        self._chk(mask, torch.uint8, "mask")
+        n = mask.shape[0]
+        dev = mask.device
+        keep = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = self.workspace(n, dev)
+        rc = self.fn["mask_compact"](_ptr(mask), n, _ptr(keep), _ptr(cnt), _ptr(ws), ws.numel(),
+                                     self.stream(dev))
+        self._check(rc, "mask_compact")
+        return keep[: int(cnt.item())]
+
+    def gather_rows(self, src: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+        """src [N,C] (4-byte dtype), rows int32 [M] -> [M,C]; rows == -1 give zeros."""
+        if src.element_size() != 4:
+            raise TypeError("gather_rows serves 4-byte element types")
+        if not src.is_contiguous():
+            raise ValueError("gather_rows: src must be contiguous")
+        self._chk(rows, torch.int32, "rows")
+        c = src.shape[1]
+        out = torch.empty((rows.shape[0], c), dtype=src.dtype, device=src.device)
+        rc = self.fn["gather_rows"](_ptr(src), c, _ptr(rows), rows.shape[0], _ptr(out),
+                                    self.stream(src.device))
+        self._check(rc, "gather_rows")
+        return out
+
+    def scatter_add_rows(self, src: torch.Tensor, rows: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+        self._chk(src, torch.float32, "src")
+        self._chk(dst, torch.float32, "dst")
+        self._chk(rows, torch.int32, "rows")
+        rc = self.fn["scatter_add_rows"](_ptr(src), src.shape[1], _ptr(rows), src.shape[0], _ptr(dst),
+                                         self.stream(src.device))
+        self._check(rc, "scatter_add_rows")
+        return dst
+
+    # -- dense <-> sparse --------------------------------------------------------------------------
+    def to_dense(self, feats, coords, min3, ts: int, dims4) -> torch.Tensor:
+        self._chk(feats, torch.float32, "feats")
+        self._chk(coords, torch.int32, "coords")
+        c = feats.shape[1]
+        b, x, y, z = [int(v) for v in dims4]
+        dense = torch.zeros((b, c, x, y, z), dtype=torch.float32, device=feats.device)
+        hmin = (_i32 * 3)(*[int(v) for v in min3])
+        hdim = (_i32 * 4)(b, x, y, z)
+        rc = self.fn["to_dense"](_ptr(feats), _ptr(coords), feats.shape[0], c, C.cast(hmin, _vp), int(ts),
+                                 C.cast(hdim, _vp), _ptr(dense), self.stream(feats.device))
+        self._check(rc, "to_dense")
+        return dense
+
+    def to_sparse(self, dense: torch.Tensor):
+        """dense [B,C,X,Y,Z] -> (coords int32 [N,4] in site units, feats [N,C])."""
+        self._chk(dense, torch.float32, "dense")
+        b, c, x, y, z = dense.shape
+        dev = dense.device
+        nsites = b * x * y * z
+        coords = torch.empty((max(nsites, 1), 4), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = self.workspace(nsites, dev)
+        hdim = (_i32 * 4)(b, x, y, z)
+        rc = self.fn["to_sparse_coords"](_ptr(dense), c, C.cast(hdim, _vp), _ptr(coords), _ptr(cnt),
+                                         _ptr(ws), ws.numel(), self.stream(dev))
+        self._check(rc, "to_sparse_coords")
+        n = int(cnt.item())
+        coords = coords[:n].contiguous()
+        feats = self.dense_gather(dense, coords)
+        return coords, feats
+
+    def dense_gather(self, dense: torch.Tensor, site_coords: torch.Tensor) -> torch.Tensor:
+        self._chk(dense, torch.float32, "dense")
+        self._chk(site_coords, torch.int32, "site_coords")
+        b, c, x, y, z = dense.shape
+        n = site_coords.shape[0]
+        feats = torch.empty((n, c), dtype=torch.float32, device=dense.device)
+        hdim = (_i32 * 4)(b, x, y, z)
+        rc = self.fn["dense_gather"](_ptr(dense), c, C.cast(hdim, _vp), _ptr(site_coords), n, _ptr(feats),
+                                     self.stream(dense.device))
+        self._check(rc, "dense_gather")
+        return feats
+
+
+# ---- registry -----------------------------------------------------------------------------------
+_hip_backend: Optional[CBackend] = None
+_checker_backend: Optional[CBackend] = None
+
+
+def hip_backend() -> CBackend:
+    """The product backend. Raises if libpascohip.so is missing or cannot be loaded."""
+    global _hip_backend
+    if _hip_backend is None:
+        _hip_backend = CBackend(HIP_LIB_PATH, "ph_", "cuda")
+    return _hip_backend
+
+
+def register_checker_backend(backend: Optional[CBackend]) -> None:
+    """Test hook: serve CPU tensors from a checker library (the oracle). Never called by pasco_amd."""
+    global _checker_backend
+    _checker_backend = backend
+
+
+def backend_for(device: torch.device) -> CBackend:
+    device = torch.device(device)
+    if device.type == "cuda":
+        return hip_backend()
+    if _checker_backend is not None and device.type == _checker_backend.device_type:
+        return _checker_backend
+    raise RuntimeError(
+        f"pasco_amd serves ROCm GPU tensors only (got device '{device}'); there is no CPU path. "
+        "Move tensors to cuda:N (MI355X) - tests may register a checker backend explicitly.")

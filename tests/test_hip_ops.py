@@ -1,0 +1,226 @@
+"""GPU parity: every C-ABI entry point of libpascohip.so against the CPU oracle on the same seeded
+inputs.  Integer / index results (unique rows, neighbour tables, COO kernel maps, pruned rows,
+to_sparse coordinates) must be bit-exact; fp32 features within 1e-3 relative (north_star).
+"""
+import numpy as np
+import pytest
+import torch
+
+from pasco_amd.me.core import kernel_offsets
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-3, 1e-4
+
+
+def scene_coords(seed, n, extent=(40, 36, 12), lo=(-8, -16, 0), batch=1, dup=0.0, step=1):
+    g = torch.Generator().manual_seed(seed)
+    cs = []
+    for b in range(batch):
+        c = torch.stack([torch.randint(0, e, (n,), generator=g) for e in extent], dim=1) * step + torch.tensor(lo)
+        cs.append(torch.cat([torch.full((n, 1), b), c], dim=1))
+    c = torch.cat(cs).int()
+    if dup > 0:
+        k = int(c.shape[0] * dup)
+        idx = torch.randint(0, c.shape[0], (k,), generator=g)
+        c = torch.cat([c, c[idx]])[torch.randperm(c.shape[0] + k, generator=g)]
+    return c.contiguous()
+
+
+def unique_map(be, coords):
+    tk, tv, r2u, uq, nu = be.map_insert(coords)
+    c = be.gather_rows(coords, uq) if nu != coords.shape[0] else coords
+    return tk, tv, c, r2u, uq
+
+
+@pytest.mark.parametrize("n,dup", [(0, 0.0), (1, 0.0), (777, 0.3), (50000, 0.1), (300000, 0.0)])
+def test_map_insert_exact(hip, oracle, n, dup):
+    coords = scene_coords(1, n, extent=(200, 200, 30), dup=dup) if n else torch.zeros((0, 4), dtype=torch.int32)
+    _, _, r2u_o, uq_o, nu_o = oracle.map_insert(coords)
+    tk, tv, r2u_h, uq_h, nu_h = hip.map_insert(coords.cuda())
+    assert nu_h == nu_o
+    assert torch.equal(uq_h.cpu(), uq_o)
+    assert torch.equal(r2u_h.cpu(), r2u_o)
+    if n:
+        # find every coordinate again + some misses
+        q = torch.cat([coords, coords + torch.tensor([0, 1000, 0, 0], dtype=torch.int32)]).cuda()
+        rows = hip.map_find(q, tk, tv).cpu()
+        assert torch.equal(rows[: coords.shape[0]], r2u_o)
+        assert bool((rows[coords.shape[0]:] == -1).all())
+
+
+@pytest.mark.parametrize("ts", [2, 4, 8])
+def test_coords_floor_expand_exact(hip, oracle, ts):
+    coords = scene_coords(2, 5000, lo=(-33, -17, -5))
+    assert torch.equal(hip.coords_floor(coords.cuda(), ts).cpu(), oracle.coords_floor(coords, ts))
+    assert torch.equal(hip.coords_expand(coords.cuda(), ts).cpu(), oracle.coords_expand(coords, ts))
+
+
+@pytest.mark.parametrize("ks,n", [(3, 20000), (2, 20000), (4, 3000), (3, 1), (3, 130)])
+def test_nbr_and_coo_exact(hip, oracle, ks, n):
+    coords = scene_coords(3, n)
+    tk_o, tv_o, c_o, _, _ = unique_map(oracle, coords)
+    tk_h, tv_h, c_h, _, _ = unique_map(hip, coords.cuda())
+    assert torch.equal(c_h.cpu(), c_o)
+    offs = kernel_offsets(ks, 1)
+    nbr_o = oracle.nbr_build(c_o, tk_o, tv_o, offs)
+    nbr_h = hip.nbr_build(c_h, tk_h, tv_h, offs)
+    assert torch.equal(nbr_h.cpu(), nbr_o)
+    pi_o, po_o, cnt_o = oracle.kmap_compact(nbr_o)
+    pi_h, po_h, cnt_h = hip.kmap_compact(nbr_h)
+    assert torch.equal(cnt_h.cpu(), cnt_o)
+    for k, c in enumerate(cnt_o.tolist()):
+        assert torch.equal(pi_h[k, :c].cpu(), pi_o[k, :c])
+        assert torch.equal(po_h[k, :c].cpu(), po_o[k, :c])
+
+
+CONV_SHAPES = [  # (kernel, cin, cout, n)
+    (3, 64, 64, 30000), (3, 128, 128, 9000), (3, 256, 256, 3000), (3, 16, 20, 500), (3, 8, 8, 1),
+    (3, 67, 33, 1000), (3, 64, 100, 2000), (3, 32, 160, 2000),
+]
+
+
+@pytest.mark.parametrize("ks,cin,cout,n", CONV_SHAPES)
+def test_conv3_parity(hip, oracle, ks, cin, cout, n):
+    coords = scene_coords(4, n)
+    tk_o, tv_o, c_o, _, _ = unique_map(oracle, coords)
+    tk_h, tv_h, c_h, _, _ = unique_map(hip, coords.cuda())
+    offs = kernel_offsets(ks, 1)
+    nbr_o = oracle.nbr_build(c_o, tk_o, tv_o, offs)
+    nbr_h = hip.nbr_build(c_h, tk_h, tv_h, offs)
+    g = torch.Generator().manual_seed(5)
+    m = c_o.shape[0]
+    x = torch.randn(m, cin, generator=g)
+    w = torch.randn(len(offs), cin, cout, generator=g) / np.sqrt(cin * 8)
+    exp = oracle.conv_fwd(x, w, nbr_o, m)
+    got = hip.conv_fwd(x.cuda(), w.cuda(), nbr_h, m).cpu()
+    assert torch.allclose(got, exp, rtol=RTOL, atol=ATOL), float((got - exp).abs().max())
+
+
+def test_conv_asymmetric_identity_weight(hip, oracle):
+    """A = identity-like check with an asymmetric kernel: catches transposed C/D layouts."""
+    coords = scene_coords(6, 4000)
+    tk_h, tv_h, c_h, _, _ = unique_map(hip, coords.cuda())
+    m = c_h.shape[0]
+    cin = cout = 64
+    x = torch.arange(m * cin, dtype=torch.float32).reshape(m, cin) % 97
+    w = torch.zeros(27, cin, cout)
+    w[13] = torch.diag(torch.arange(1, cin + 1, dtype=torch.float32))  # centre offset only
+    w[13, 0, 5] = 3.0  # asymmetric entry
+    nbr = hip.nbr_build(c_h, tk_h, tv_h, kernel_offsets(3, 1))
+    got = hip.conv_fwd(x.cuda(), w.cuda(), nbr, m).cpu()
+    exp = x @ w[13]
+    assert torch.allclose(got, exp, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 128), (259, 256), (64, 20), (192, 64), (131, 128)])
+def test_conv1_and_strided_parity(hip, oracle, cin, cout):
+    g = torch.Generator().manual_seed(7)
+    n = 5000
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(cin, cout, generator=g) / np.sqrt(cin)
+    b = torch.randn(cout, generator=g)
+    exp = oracle.conv_fwd(x, w, None, n, bias=b)
+    got = hip.conv_fwd(x.cuda(), w.cuda(), None, n, bias=b.cuda()).cpu()
+    assert torch.allclose(got, exp, rtol=RTOL, atol=ATOL)
+    assert torch.allclose(got, x @ w + b, rtol=RTOL, atol=ATOL)
+
+
+def test_strided_and_transposed_parity(hip, oracle):
+    coords = scene_coords(8, 20000)
+    g = torch.Generator().manual_seed(9)
+    res = {}
+    for name, be, dev in (("o", oracle, "cpu"), ("h", hip, "cuda")):
+        tk, tv, c, _, _ = unique_map(be, coords.to(dev))
+        fl = be.coords_floor(c, 2)
+        tk2, tv2, c2, r2u, _ = unique_map(be, fl)
+        nbr_dn = be.nbr_build(c2, tk, tv, kernel_offsets(2, 1))
+        kids = be.coords_expand(c2, 1)
+        tk3, tv3, c3, _, _ = unique_map(be, kids)
+        nbr_up = be.nbr_build(c3, tk2, tv2, kernel_offsets(2, 1, transposed=True))
+        res[name] = (c, c2, nbr_dn, c3, nbr_up)
+    for a, b in zip(res["o"], res["h"]):
+        assert torch.equal(a, b.cpu())
+    c, c2, nbr_dn, c3, nbr_up = res["o"]
+    x = torch.randn(c.shape[0], 64, generator=g)
+    wd = torch.randn(8, 64, 128, generator=g) / 16
+    wu = torch.randn(8, 128, 64, generator=g) / 16
+    dn_o = oracle.conv_fwd(x, wd, nbr_dn, c2.shape[0])
+    dn_h = hip.conv_fwd(x.cuda(), wd.cuda(), res["h"][2], c2.shape[0])
+    assert torch.allclose(dn_h.cpu(), dn_o, rtol=RTOL, atol=ATOL)
+    up_o = oracle.conv_fwd(dn_o, wu, nbr_up, c3.shape[0])
+    up_h = hip.conv_fwd(dn_h, wu.cuda(), res["h"][4], c3.shape[0])
+    assert torch.allclose(up_h.cpu(), up_o, rtol=RTOL, atol=ATOL)
+
+
+def test_fused_prologue_epilogue_parity(hip, oracle):
+    coords = scene_coords(10, 12000)
+    tk_o, tv_o, c_o, _, _ = unique_map(oracle, coords)
+    tk_h, tv_h, c_h, _, _ = unique_map(hip, coords.cuda())
+    offs = kernel_offsets(3, 1)
+    nbr_o = oracle.nbr_build(c_o, tk_o, tv_o, offs)
+    nbr_h = hip.nbr_build(c_h, tk_h, tv_h, offs)
+    g = torch.Generator().manual_seed(11)
+    m, cin, cout = c_o.shape[0], 64, 64
+    x = torch.randn(m, cin, generator=g)
+    w = torch.randn(27, cin, cout, generator=g) / 40
+    ps, pb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.2
+    es, eb = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    bias, res = torch.randn(cout, generator=g), torch.randn(m, cout, generator=g)
+    for pro_act, epi_act, res_act in ((1, 1, 1), (0, 2, 0), (1, 0, 1), (2, 2, 2)):
+        kw = dict(bias=bias, pro_scale=ps, pro_shift=pb, pro_act=pro_act, epi_scale=es, epi_shift=eb,
+                  epi_act=epi_act, slope=0.01, residual=res, res_act=res_act)
+        exp = oracle.conv_fwd(x, w, nbr_o, m, **kw)
+        kw_h = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+        got = hip.conv_fwd(x.cuda(), w.cuda(), nbr_h, m, **kw_h).cpu()
+        assert torch.allclose(got, exp, rtol=RTOL, atol=ATOL), (pro_act, epi_act, res_act)
+
+
+@pytest.mark.parametrize("s,c", [(2, 100), (4, 100), (2, 7)])
+def test_maxpool_parity(hip, oracle, s, c):
+    coords = scene_coords(12, 30000)
+    outs = []
+    for be, dev in ((oracle, "cpu"), (hip, "cuda")):
+        tk, tv, cc, _, _ = unique_map(be, coords.to(dev))
+        _, _, c2, _, _ = unique_map(be, be.coords_floor(cc, s))
+        nbr = be.nbr_build(c2, tk, tv, kernel_offsets(s, 1))
+        x = torch.randn(cc.shape[0], c, generator=torch.Generator().manual_seed(13)).to(dev)
+        outs.append((c2.cpu(), be.maxpool_fwd(x, nbr).cpu()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_rows_and_dense_exact(hip, oracle):
+    g = torch.Generator().manual_seed(14)
+    n, c = 40000, 64
+    x = torch.randn(n, c, generator=g)
+    mask = torch.rand(n, generator=g) > 0.6
+    keep_o = oracle.mask_compact(mask)
+    keep_h = hip.mask_compact(mask.cuda())
+    assert torch.equal(keep_h.cpu(), keep_o)
+    assert torch.equal(hip.gather_rows(x.cuda(), keep_h).cpu(), x[mask])
+    for cc in (3, 4, 20):
+        y = torch.randn(n, cc, generator=g)
+        assert torch.equal(hip.gather_rows(y.cuda(), keep_h).cpu(), y[mask])
+    # empty / full masks
+    assert hip.mask_compact(torch.zeros(n, dtype=torch.bool).cuda()).numel() == 0
+    assert hip.mask_compact(torch.ones(5, dtype=torch.bool).cuda()).tolist() == [0, 1, 2, 3, 4]
+    # scatter-add with unique targets
+    rows = torch.randperm(n, generator=g)[: n // 2].int()
+    dst = torch.randn(n, c, generator=g)
+    exp = oracle.scatter_add_rows(x[: n // 2].contiguous(), rows, dst.clone())
+    got = hip.scatter_add_rows(x[: n // 2].contiguous().cuda(), rows.cuda(), dst.clone().cuda()).cpu()
+    assert torch.equal(got, exp)
+    # dense round trip
+    coords = scene_coords(15, 20000, extent=(64, 48, 16), lo=(-16, -8, 0), batch=2)
+    _, _, cu, _, _ = unique_map(oracle, coords)
+    f = torch.randn(cu.shape[0], 24, generator=g)
+    f[::5] = 0
+    dims = (2, 64, 48, 16)
+    d_o = oracle.to_dense(f, cu, (-16, -8, 0), 1, dims)
+    d_h = hip.to_dense(f.cuda(), cu.cuda(), (-16, -8, 0), 1, dims)
+    assert torch.equal(d_h.cpu(), d_o)
+    co, fo = oracle.to_sparse(d_o)
+    ch, fh = hip.to_sparse(d_h)
+    assert torch.equal(ch.cpu(), co) and torch.equal(fh.cpu(), fo)
+    assert co.shape[0] == int((f != 0).any(dim=1).sum())

@@ -1,0 +1,209 @@
+"""Pin the CPU oracle against an independent dense formulation.
+
+MinkowskiEngine itself cannot run here, so the oracle's operator semantics are checked against
+torch's dense conv3d / conv_transpose3d / max_pool3d on zero-filled grids: on the active sites the
+sums are identical term by term.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import pasco_amd.me as ME
+from pasco_amd.me.core import kernel_offsets
+
+
+def random_scene(seed, n=300, extent=(12, 10, 8), batch=1, lo=(0, 0, 0), step=1):
+    g = torch.Generator().manual_seed(seed)
+    cs = []
+    for b in range(batch):
+        c = torch.stack([torch.randint(0, e, (n,), generator=g) for e in extent], dim=1) * step
+        c = c + torch.tensor(lo)
+        cs.append(torch.cat([torch.full((n, 1), b), c], dim=1))
+    return torch.cat(cs).int()
+
+
+def dense_of(x: ME.SparseTensor, lo, dims, fill=0.0):
+    """[B,C,X,Y,Z] grid in units of the tensor stride, origin `lo`."""
+    ts = x.tensor_stride[0]
+    c = x.C.long()
+    b = int(c[:, 0].max()) + 1
+    d = torch.full((b, x.F.shape[1], *dims), fill, dtype=torch.float32)
+    idx = (c[:, 1:] - torch.tensor(lo)) // ts
+    d[c[:, 0], :, idx[:, 0], idx[:, 1], idx[:, 2]] = x.F
+    return d
+
+
+def sample(d, coords, lo, ts):
+    c = coords.long()
+    idx = (c[:, 1:] - torch.tensor(lo)) // ts
+    return d[c[:, 0], :, idx[:, 0], idx[:, 1], idx[:, 2]]
+
+
+def test_offsets_enumeration():
+    o = kernel_offsets(3, 1)
+    assert len(o) == 27 and o[0] == (-1, -1, -1) and o[1] == (0, -1, -1) and o[13] == (0, 0, 0) and o[26] == (1, 1, 1)
+    o2 = kernel_offsets(2, 4)
+    assert o2 == [(0, 0, 0), (4, 0, 0), (0, 4, 0), (4, 4, 0), (0, 0, 4), (4, 0, 4), (0, 4, 4), (4, 4, 4)]
+    ot = kernel_offsets(2, 2, transposed=True)
+    assert ot[1] == (-2, 0, 0) and ot[7] == (-2, -2, -2)
+
+
+@pytest.mark.parametrize("lo", [(0, 0, 0), (-7, -3, -5)])
+@pytest.mark.parametrize("cin,cout", [(5, 7), (16, 32)])
+def test_conv3_matches_dense(oracle_registered, lo, cin, cout):
+    coords = random_scene(1, n=400, lo=lo, batch=2)
+    torch.manual_seed(2)
+    x = ME.SparseTensor(torch.randn(coords.shape[0], cin), coords)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=3, bias=True, dimension=3)
+    y = conv(x)
+    assert y.coordinate_map_key == x.coordinate_map_key
+    dims = (12, 10, 8)
+    d = dense_of(x, lo, dims)
+    w = conv.kernel.detach().reshape(3, 3, 3, cin, cout).permute(4, 3, 2, 1, 0).contiguous()  # [co,ci,x,y,z]
+    ref = F.conv3d(d, w, bias=conv.bias.detach().reshape(-1), padding=1)
+    got = y.F
+    exp = sample(ref, y.C, lo, 1)
+    assert torch.allclose(got, exp, rtol=1e-4, atol=1e-5), (got - exp).abs().max()
+
+
+@pytest.mark.parametrize("lo", [(0, 0, 0), (-8, -4, -6)])
+def test_strided_conv_matches_dense(oracle_registered, lo):
+    cin, cout = 6, 9
+    coords = random_scene(3, n=350, lo=lo)
+    torch.manual_seed(4)
+    x = ME.SparseTensor(torch.randn(coords.shape[0], cin), coords)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=2, stride=2, dimension=3)
+    y = conv(x)
+    assert y.tensor_stride == [2, 2, 2]
+    # coarse coordinates = floor(c/2)*2, unique, first-occurrence order
+    exp_c = torch.div(x.C[:, 1:], 2, rounding_mode="floor") * 2
+    seen, order = set(), []
+    for r in exp_c.tolist():
+        if tuple(r) not in seen:
+            seen.add(tuple(r))
+            order.append(r)
+    assert y.C[:, 1:].tolist() == order
+    d = dense_of(x, lo, (12, 10, 8))
+    w = conv.kernel.detach().reshape(2, 2, 2, cin, cout).permute(4, 3, 2, 1, 0).contiguous()
+    ref = F.conv3d(d, w, stride=2)
+    exp = sample(ref, y.C, lo, 2)
+    assert torch.allclose(y.F, exp, rtol=1e-4, atol=1e-5)
+
+
+def test_generative_transpose_matches_dense(oracle_registered):
+    cin, cout = 7, 5
+    lo = (-8, 0, -4)
+    coords = random_scene(5, n=60, extent=(6, 5, 4), lo=lo, step=2)
+    torch.manual_seed(6)
+    x = ME.SparseTensor(torch.randn(coords.shape[0], cin), coords, tensor_stride=2)
+    up = ME.MinkowskiConvolutionTranspose(cin, cout, kernel_size=2, stride=2, dimension=3,
+                                          expand_coordinates=True)
+    y = up(x)
+    assert y.tensor_stride == [1, 1, 1]
+    assert y.F.shape[0] == 8 * x.F.shape[0]
+    # children of parent i are rows 8i..8i+7, x fastest
+    par = x.C.long()
+    kid = y.C.long().reshape(-1, 8, 4)
+    assert torch.equal(kid[:, 0], par)
+    assert torch.equal(kid[:, 1], par + torch.tensor([0, 1, 0, 0]))
+    assert torch.equal(kid[:, 6], par + torch.tensor([0, 0, 1, 1]))
+    d = dense_of(x, lo, (6, 5, 4))
+    w = up.kernel.detach().reshape(2, 2, 2, cin, cout).permute(3, 4, 2, 1, 0).contiguous()  # [ci,co,x,y,z]
+    ref = F.conv_transpose3d(d, w, stride=2)
+    exp = sample(ref, y.C, lo, 1)
+    assert torch.allclose(y.F, exp, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("s", [2, 4])
+def test_maxpool_matches_dense(oracle_registered, s):
+    lo = (-8, -4, 0)
+    coords = random_scene(7, n=500, extent=(16, 12, 8), lo=lo)
+    torch.manual_seed(8)
+    x = ME.SparseTensor(torch.randn(coords.shape[0], 11), coords)
+    y = ME.MinkowskiMaxPooling(kernel_size=s, stride=s, dimension=3)(x)
+    d = dense_of(x, lo, (16, 12, 8), fill=float("-inf"))
+    ref = F.max_pool3d(d, s, s)
+    exp = sample(ref, y.C, lo, s)
+    assert torch.equal(y.F, exp)
+
+
+def test_conv1_is_plain_gemm(oracle_registered):
+    coords = random_scene(9, n=100)
+    torch.manual_seed(10)
+    x = ME.SparseTensor(torch.randn(coords.shape[0], 13), coords)
+    conv = ME.MinkowskiConvolution(13, 20, kernel_size=1, bias=True, dimension=3)
+    assert conv.kernel.shape == (13, 20) and conv.bias.shape == (1, 20)
+    y = conv(x)
+    assert torch.allclose(y.F, x.F @ conv.kernel + conv.bias, rtol=1e-5, atol=1e-5)
+
+
+def test_duplicates_keep_first(oracle_registered):
+    c = torch.tensor([[0, 1, 1, 1], [0, 2, 2, 2], [0, 1, 1, 1], [0, 3, 3, 3], [0, 2, 2, 2]]).int()
+    f = torch.arange(5.0).reshape(5, 1)
+    x = ME.SparseTensor(f, c)
+    assert x.C.tolist() == [[0, 1, 1, 1], [0, 2, 2, 2], [0, 3, 3, 3]]
+    assert x.F.reshape(-1).tolist() == [0.0, 1.0, 3.0]
+    assert x.inverse_mapping.tolist() == [0, 1, 0, 2, 1]
+
+
+def test_prune_union_dense_roundtrip(oracle_registered):
+    coords = random_scene(11, n=200)
+    torch.manual_seed(12)
+    x = ME.SparseTensor(torch.randn(coords.shape[0], 4), coords)
+    keep = x.F[:, 0] > 0
+    p = ME.MinkowskiPruning()(x, keep)
+    assert torch.equal(p.C, x.C[keep]) and torch.equal(p.F, x.F[keep])
+    # union: lhs rows first, then unseen rhs rows in order
+    q = ME.MinkowskiPruning()(x, x.F[:, 1] > 0)
+    u = p + q
+    only_q = [r for r in q.C.tolist() if r not in p.C.tolist()]
+    assert u.C.tolist() == p.C.tolist() + only_q
+    dx = dense_of(p, (0, 0, 0), (12, 10, 8)) + dense_of(q, (0, 0, 0), (12, 10, 8))
+    assert torch.allclose(u.F, sample(dx, u.C, (0, 0, 0), 1))
+    # dense -> to_sparse: lexicographic order, all-zero rows dropped
+    z = x.F.clone()
+    z[::7] = 0
+    xz = ME.SparseTensor(z, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
+    d, mn, ts = xz.dense(shape=torch.Size([1, 4, 12, 10, 8]), min_coordinate=torch.IntTensor([0, 0, 0]))
+    t = ME.to_sparse(d)
+    nz = (z != 0).any(dim=1)
+    exp_c = sorted(x.C[nz].tolist())
+    assert t.C.tolist() == exp_c
+    assert t.coordinate_manager is not x.coordinate_manager
+    assert torch.equal(t.F, sample(d, t.C, (0, 0, 0), 1))
+
+
+def test_fused_prologue_epilogue(oracle):
+    """conv_fwd's fused BN/ReLU prologue + bias/BN/act/residual epilogue == unfused composition."""
+    torch.manual_seed(13)
+    coords = random_scene(14, n=300)
+    tk, tv, r2u, uq, nu = oracle.map_insert(coords.contiguous())
+    c = coords[uq.long()].contiguous()
+    n, cin, cout = c.shape[0], 12, 12
+    x = torch.randn(n, cin)
+    w = torch.randn(27, cin, cout) * 0.1
+    nbr = oracle.nbr_build(c, tk, tv, kernel_offsets(3, 1))
+    ps, pb, es, eb, bias = (torch.rand(cin) + 0.5, torch.randn(cin) * 0.1, torch.rand(cout) + 0.5,
+                            torch.randn(cout) * 0.1, torch.randn(cout))
+    res = torch.randn(n, cout)
+    got = oracle.conv_fwd(x, w, nbr, n, bias=bias, pro_scale=ps, pro_shift=pb, pro_act=1, epi_scale=es,
+                          epi_shift=eb, epi_act=2, slope=0.01, residual=res, res_act=1)
+    xin = torch.relu(x * ps + pb)
+    y = oracle.conv_fwd(xin, w, nbr, n) + bias
+    y = F.leaky_relu(y * es + eb, 0.01)
+    exp = torch.relu(y + res)
+    assert torch.allclose(got, exp, rtol=1e-5, atol=1e-5)
+
+
+def test_kmap_coo_matches_bruteforce(oracle_registered):
+    coords = random_scene(15, n=150, extent=(6, 6, 6))
+    x = ME.SparseTensor(torch.zeros(coords.shape[0], 1), coords)
+    mgr = x.coordinate_manager
+    coo = mgr.kernel_map_coo(x.coordinate_map_key, x.coordinate_map_key, 3)
+    lut = {tuple(r): i for i, r in enumerate(x.C.tolist())}
+    for k, (dx, dy, dz) in enumerate(kernel_offsets(3, 1)):
+        exp = [(lut[(b, a + dx, y + dy, z + dz)], o) for o, (b, a, y, z) in enumerate(x.C.tolist())
+               if (b, a + dx, y + dy, z + dz) in lut]
+        got = list(zip(coo[k][0].tolist(), coo[k][1].tolist()))
+        assert got == exp
