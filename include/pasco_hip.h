@@ -109,10 +109,12 @@ int PH_FN(kmap_compact)(const int32_t *nbr, int32_t kvol, int64_t n_out, int32_t
  *
  *   out[o,:] = epi( sum_k [nbr[k][o] >= 0] * pro(in[nbr[k][o], :]) @ W[k] + bias )
  *   pro(x)  = act_pro(x * pro_scale + pro_shift)          (per input channel; BN-eval + ReLU)
- *   epi(y)  = act_res( act_epi(y * epi_scale + epi_shift) + residual[o,:] )
+ *   epi(y)  = act_res( act_epi(y * epi_scale + epi_shift) * epi2_scale + epi2_shift + residual[o,:] )
+ *             (second affine = the extra BatchNorm that follows a down-conv block,
+ *              encoder_v2.py:124-126; with residual == NULL act_res is its activation)
  *
  * nbr == NULL means the identity map (kernel volume 1, n_out == n_in).  Any of pro_scale /
- * pro_shift / bias / epi_scale / epi_shift / residual may be NULL.  W is [kvol, cin, cout].
+ * pro_shift / bias / epi_scale / epi_shift / epi2_scale / epi2_shift / residual may be NULL.  W is [kvol, cin, cout].
  * ------------------------------------------------------------------------------------------- */
 typedef struct ph_conv_desc {
   const float *in;       /* [n_in, cin] */
@@ -133,8 +135,10 @@ typedef struct ph_conv_desc {
   int32_t epi_act;
   float epi_slope;        /* negative slope for PH_ACT_LEAKY (pro and epi) */
   const float *residual;  /* [n_out, cout] added after epi_act */
-  int32_t res_act;        /* activation after the residual add */
+  int32_t res_act;        /* activation after the second affine / residual add */
   int32_t reserved;
+  const float *epi2_scale; /* [cout] second per-channel affine, applied after epi_act */
+  const float *epi2_shift; /* [cout] */
 } ph_conv_desc;
 
 int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);

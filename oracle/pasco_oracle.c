@@ -205,6 +205,7 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   (void)stream;
   if (!d) return fail("conv_fwd: null desc");
   if (d->cin <= 0 || d->cout <= 0 || d->kvol < 1 || d->kvol > PH_MAX_KVOL) return fail("conv_fwd: bad shape");
+  if (d->n_out == 0) return 0;
   if (!d->nbr && !(d->kvol == 1 && d->n_in == d->n_out)) return fail("conv_fwd: identity map needs kvol == 1");
   const int cin = d->cin, cout = d->cout;
   const int64_t n_out = d->n_out;
@@ -249,7 +250,11 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
           float v = acc[(int64_t)r * cout + n] + (d->bias ? d->bias[n] : 0.f);
           v = v * (d->epi_scale ? d->epi_scale[n] : 1.f) + (d->epi_shift ? d->epi_shift[n] : 0.f);
           v = act_apply(v, d->epi_act, d->epi_slope);
-          if (d->residual) v = act_apply(v + d->residual[o * cout + n], d->res_act, d->epi_slope);
+          if (d->residual || d->epi2_scale || d->epi2_shift || d->res_act != PH_ACT_NONE) {
+            v = v * (d->epi2_scale ? d->epi2_scale[n] : 1.f) + (d->epi2_shift ? d->epi2_shift[n] : 0.f);
+            if (d->residual) v += d->residual[o * cout + n];
+            v = act_apply(v, d->res_act, d->epi_slope);
+          }
           d->out[o * cout + n] = v;
         }
       }

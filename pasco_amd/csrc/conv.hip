@@ -1,6 +1,6 @@
 // Sparse convolution forward for gfx950: output-stationary gather -> LDS tile -> fp32 MFMA.
 //
-//   out[o,:] = epi( sum_k [nbr[k][o] >= 0] * pro(in[nbr[k][o],:]) @ W[k] + bias )
+//   out[o,:] = epi( sum_k [nbr[k][o] >= 0] * pro(in[nbr[k][o],:]) @ W[k] + bias )   (pasco_hip.h)
 //
 // One workgroup (256 threads = 4 wave64) owns BM = 128 output rows x BN output channels and walks
 // the (kernel offset, input-channel chunk) stages.  Per stage the 128 neighbour rows are gathered
@@ -37,7 +37,7 @@ struct ConvArgs {
   int64_t n_in, n_out;
   int cin, cout, kvol;
   int pro_act;
-  const float *pro_scale, *pro_shift, *bias, *epi_scale, *epi_shift, *residual;
+  const float *pro_scale, *pro_shift, *bias, *epi_scale, *epi_shift, *epi2_scale, *epi2_shift, *residual;
   int epi_act, res_act;
   float slope;
   int n_row_tiles, n_col_tiles;
@@ -236,6 +236,9 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
     const float bias = a.bias ? a.bias[col] : 0.f;
     const float es = a.epi_scale ? a.epi_scale[col] : 1.f;
     const float eb = a.epi_shift ? a.epi_shift[col] : 0.f;
+    const float es2 = a.epi2_scale ? a.epi2_scale[col] : 1.f;
+    const float eb2 = a.epi2_shift ? a.epi2_shift[col] : 0.f;
+    const bool tail = a.residual || a.epi2_scale || a.epi2_shift || a.res_act != PH_ACT_NONE;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -244,7 +247,11 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
         if (row >= a.n_out) continue;
         float v = acc[i][j][r] + bias;
         v = act_apply(v * es + eb, a.epi_act, a.slope);
-        if (a.residual) v = act_apply(v + a.residual[row * cout + col], a.res_act, a.slope);
+        if (tail) {
+          v = v * es2 + eb2;
+          if (a.residual) v += a.residual[row * cout + col];
+          v = act_apply(v, a.res_act, a.slope);
+        }
         a.out[row * cout + col] = v;
       }
     }
@@ -278,6 +285,7 @@ extern "C" int ph_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   PH_REQUIRE(d->cin > 0 && d->cout > 0 && d->kvol >= 1 && d->kvol <= PH_MAX_KVOL,
              "conv_fwd: bad shape cin=%d cout=%d kvol=%d", d->cin, d->cout, d->kvol);
   PH_REQUIRE(d->n_out >= 0 && d->n_out < 0x7FFFFF00, "conv_fwd: bad n_out");
+  if (d->n_out == 0) return 0;
   PH_REQUIRE(d->nbr != nullptr || (d->kvol == 1 && d->n_in == d->n_out),
              "conv_fwd: identity map needs kvol == 1 and n_in == n_out");
   PH_REQUIRE(d->in && d->weight && d->out, "conv_fwd: null tensor");
@@ -298,6 +306,8 @@ extern "C" int ph_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   a.bias = d->bias;
   a.epi_scale = d->epi_scale;
   a.epi_shift = d->epi_shift;
+  a.epi2_scale = d->epi2_scale;
+  a.epi2_shift = d->epi2_shift;
   a.residual = d->residual;
   a.epi_act = d->epi_act;
   a.res_act = d->res_act;

@@ -1,0 +1,110 @@
+"""Sparse building blocks of PaSCo's U-Net, restated on fused HIP launches.
+
+Module trees (and therefore state-dict keys) follow the reference so its checkpoints load:
+  ResidualBlock                      pasco/maskpls/mink.py:618-658
+  BasicConvolutionBlock              pasco/maskpls/mink.py:505-518
+  BasicGenerativeDeconvolutionBlock  pasco/maskpls/mink.py:520-534
+  MinkowskiSpatialDropout            pasco/models/dropout.py:43-60 (identity at inference)
+Each block's eval forward is a fixed sequence of conv launches with BN/activation folded in.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import me as ME
+from . import fused
+from .fused import ACT_LEAKY, ACT_NONE, ACT_RELU
+
+
+class SpatialDropout(ME.MinkowskiModuleBase):
+    """Channel dropout on sparse features; identity in eval mode (the only mode served)."""
+
+    def __init__(self, p: float = 0.5, *a, **kw):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        assert not self.training, "inference only"
+        return x
+
+
+class ResidualBlock(nn.Module):
+    """Pre-activation block: BN-ReLU-conv3-BN-ReLU-conv3, out = ReLU(skip + y); no BN on the skip.
+
+    Fused schedule (2 launches): conv_a gathers ReLU(BN0(x)) (prologue) and stores ReLU(BN1(.))
+    (epilogue); conv_b adds the skip and applies the final ReLU in its epilogue."""
+
+    def __init__(self, inc, outc, ks=3, stride=1, dilation=1, D=3, drop_path=0.0, use_se=False):
+        super().__init__()
+        assert drop_path == 0.0 and not use_se, "drop-path / SE are not on the served path"
+        self.net = nn.Sequential(
+            ME.MinkowskiBatchNorm(inc),
+            ME.MinkowskiReLU(inplace=True),
+            ME.MinkowskiConvolution(inc, outc, kernel_size=ks, dilation=dilation, stride=stride, dimension=D),
+            ME.MinkowskiBatchNorm(outc),
+            ME.MinkowskiReLU(inplace=True),
+            ME.MinkowskiConvolution(outc, outc, kernel_size=ks, dilation=dilation, stride=1, dimension=D),
+        )
+        self.downsample = nn.Sequential() if (inc == outc and stride == 1) else nn.Sequential(
+            ME.MinkowskiConvolution(inc, outc, kernel_size=1, dilation=1, stride=stride, dimension=D))
+        self.relu = ME.MinkowskiReLU(inplace=True)
+
+    def forward(self, x: ME.SparseTensor) -> ME.SparseTensor:
+        skip = x if len(self.downsample) == 0 else fused.conv(x, self.downsample[0])
+        y = fused.conv(x, self.net[2], pro_bn=self.net[0], pro_act=ACT_RELU, epi_bn=self.net[3], epi_act=ACT_RELU)
+        return fused.conv(y, self.net[5], residual=skip.F, res_act=ACT_RELU)
+
+
+class BasicConvolutionBlock(nn.Module):
+    """conv -> BN -> LeakyReLU(0.01); `post_bn` (optional) is the extra BN+ReLU the encoder appends
+    (encoder_v2.py:124-126), folded into the same epilogue."""
+
+    def __init__(self, inc, outc, ks=3, stride=1, dilation=1, D=3):
+        super().__init__()
+        self.net = nn.Sequential(
+            ME.MinkowskiConvolution(inc, outc, kernel_size=ks, dilation=dilation, stride=stride, dimension=D),
+            ME.MinkowskiBatchNorm(outc),
+            ME.MinkowskiLeakyReLU(inplace=True),
+        )
+
+    def forward(self, x, post_bn=None, post_act=ACT_NONE):
+        return fused.conv(x, self.net[0], epi_bn=self.net[1], epi_act=ACT_LEAKY,
+                          slope=self.net[2].module.negative_slope, epi2_bn=post_bn, res_act=post_act)
+
+
+class BasicGenerativeDeconvolutionBlock(nn.Module):
+    """generative transposed conv (k2, s2, expand_coordinates) -> BN -> LeakyReLU."""
+
+    def __init__(self, inc, outc, ks=3, stride=1, D=3):
+        super().__init__()
+        self.net = nn.Sequential(
+            ME.MinkowskiConvolutionTranspose(inc, outc, kernel_size=ks, stride=stride, dimension=D,
+                                             expand_coordinates=True),
+            ME.MinkowskiBatchNorm(outc),
+            ME.MinkowskiLeakyReLU(inplace=True),
+        )
+
+    def forward(self, x, out_key=None, nbr=None):
+        return fused.conv(x, self.net[0], epi_bn=self.net[1], epi_act=ACT_LEAKY,
+                          slope=self.net[2].module.negative_slope, out_key=out_key, nbr=nbr)
+
+
+def run_sequential(seq: nn.Sequential, x):
+    """Run a reference-shaped nn.Sequential, folding `BasicConvolutionBlock, BN, ReLU` triples and
+    skipping identities / dropouts."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, BasicConvolutionBlock) and i + 2 < len(mods) and \
+                isinstance(mods[i + 1], ME.MinkowskiBatchNorm) and isinstance(mods[i + 2], ME.MinkowskiReLU):
+            x = m(x, post_bn=mods[i + 1], post_act=ACT_RELU)
+            i += 3
+            continue
+        if isinstance(m, (nn.Identity, SpatialDropout)):
+            i += 1
+            continue
+        x = m(x)
+        i += 1
+    return x

@@ -1,0 +1,177 @@
+"""Generative sparse decoder (reference: pasco/models/decoder_v3.py:77-172 `DecoderBlock`,
+:175-511 `DecoderGenerativeSepConvV2`).
+
+Per level (tensor stride 4, 2, 1): generative up-sampling, pruning to the global bounds, coordinate
+channels + BN + conv k1 ("resize"), union-add with the encoder skip, residual blocks, one
+completion head per MIMO subnet; then the occupied voxels are kept (OR over subnets of
+argmax != 0, decoder_v3.py:337-339,380-381) and the per-subnet panoptic branch feeds the mask
+transformer.
+
+Launch-level differences to the reference, results unchanged:
+  * the bounds prune is applied to the generated coordinates BEFORE the up-convolution's features
+    are computed (children outside the bounds are never materialised);
+  * prune-by-class and prune-by-bounds in predict_panop are one compaction (mask AND);
+  * BN / activations ride in conv prologues / epilogues.
+`keep_override` (benchmark only, SURVEY.md 8(d) "teacher-forced keep") replaces the argmax-derived
+masks by membership tests against given voxel sets.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import me as ME
+from . import fused
+from .blocks import BasicGenerativeDeconvolutionBlock, ResidualBlock, SpatialDropout, run_sequential
+from .fused import ACT_NONE, ACT_RELU
+
+
+def inside_bounds(coords: torch.Tensor, lo, hi) -> torch.Tensor:
+    """Inclusive box test on int32 [N,4] coordinates (decoder_v3.py:151-158, misc.py:16-27)."""
+    lo = torch.as_tensor(lo, device=coords.device).to(coords.dtype).reshape(1, 3)
+    hi = torch.as_tensor(hi, device=coords.device).to(coords.dtype).reshape(1, 3)
+    xyz = coords[:, 1:]
+    return ((xyz >= lo) & (xyz <= hi)).all(dim=1)
+
+
+def batch_sparse_tensor(tensors: List[ME.SparseTensor]):
+    """Zero-pad per-subnet tensors to [M, Nmax, C] / [M, Nmax, 4] (reference: pasco/models/utils.py:659-670)."""
+    n_max = max(t.F.shape[0] for t in tensors)
+    f0, c0 = tensors[0].F, tensors[0].C
+    bf = f0.new_zeros((len(tensors), n_max, f0.shape[1]))
+    bc = c0.new_zeros((len(tensors), n_max, c0.shape[1]))
+    for i, t in enumerate(tensors):
+        bf[i, : t.F.shape[0]] = t.F
+        bc[i, : t.F.shape[0]] = t.C
+    return bf, bc
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, n_heads, compl_head_dim, heavy_decoder=True, dropout=0.0):
+        super().__init__()
+        self.upsample = BasicGenerativeDeconvolutionBlock(in_channels, out_channels, ks=2, stride=2)
+        self.resize = nn.Sequential(
+            ME.MinkowskiBatchNorm(out_channels + 3),
+            ME.MinkowskiConvolution(out_channels + 3, out_channels, kernel_size=1, bias=True, dimension=3),
+        )
+        n_res = 7 if heavy_decoder else 3
+        layers = [ResidualBlock(out_channels, out_channels) for _ in range(n_res)]
+        if heavy_decoder:
+            layers.append(SpatialDropout(p=dropout))
+        self.process = nn.Sequential(*layers)
+        self.n_heads = n_heads
+        self.completion_heads = nn.ModuleDict({
+            str(i): nn.Sequential(ME.MinkowskiConvolution(out_channels, compl_head_dim, kernel_size=1, bias=True,
+                                                          dimension=3))
+            for i in range(n_heads)})
+
+    def forward(self, x: ME.SparseTensor, shortcut: ME.SparseTensor, global_min, global_max):
+        mgr = x.coordinate_manager
+        up = self.upsample.net[0]
+        # children -> bounds prune -> features only for surviving children
+        kids_key = mgr.expand(x.coordinate_map_key, up.stride)
+        keep = inside_bounds(mgr.get_coordinates(kids_key), global_min, global_max)
+        out_key, _ = mgr.prune(kids_key, keep)
+        nbr = mgr.kernel_map(x.coordinate_map_key, out_key, up.kernel_size, up.dilation, transposed=True)
+        dec = self.upsample(x, out_key=out_key, nbr=nbr)
+        # coordinate channels (absolute coords / tensor stride) + BN + conv k1 with bias
+        ts = dec.tensor_stride[0]
+        feats = torch.cat([dec.F, dec.C[:, 1:].float() / ts], dim=1)
+        dec = ME.SparseTensor(feats, coordinate_map_key=out_key, coordinate_manager=mgr)
+        dec = fused.conv(dec, self.resize[1], pro_bn=self.resize[0], pro_act=ACT_NONE)
+        y = run_sequential(self.process, dec + shortcut)
+        logits = [fused.conv(y, self.completion_heads[str(i)][0]) for i in range(self.n_heads)]
+        return y, logits
+
+
+class DecoderGenerativeSepConvV2(nn.Module):
+    def __init__(self, f, n_classes, transformer_predictor, n_infers, heavy_decoder=True, dropouts=(0.0, 0.0, 0.0)):
+        super().__init__()
+        dec_ch = list(f[::-1])
+        self.n_infers = n_infers
+        self.n_classes = n_classes
+        self.transformer_predictor = transformer_predictor
+        self.dec_blocks = nn.ModuleList()
+        self.voxel_feats = nn.ModuleDict()
+        for i in range(len(dec_ch) - 1):
+            scale = 2 ** (len(dec_ch) - 2 - i)
+            self.dec_blocks.append(DecoderBlock(dec_ch[i], dec_ch[i + 1], n_heads=n_infers, compl_head_dim=n_classes,
+                                                heavy_decoder=heavy_decoder, dropout=dropouts[i]))
+            c = dec_ch[i + 1]
+            for j in range(n_infers):
+                self.voxel_feats[f"scale{scale}_infer{j}"] = nn.Sequential(
+                    ME.MinkowskiConvolution(c, c, kernel_size=3, bias=False, dimension=3),
+                    ME.MinkowskiBatchNorm(c),
+                    ME.MinkowskiReLU(),
+                    ME.MinkowskiConvolution(c, c, kernel_size=3, bias=True, dimension=3),
+                )
+        self.pruning = ME.MinkowskiPruning()
+
+    # -- keep masks ---------------------------------------------------------------------------------
+    @staticmethod
+    def _occupied(logits: ME.SparseTensor) -> torch.Tensor:
+        # argmax(softmax(l)) != 0  <=>  argmax(l) != 0   (decoder_v3.py:337-339, :411-414)
+        return logits.F.argmax(dim=-1) != 0
+
+    def _keep_completion(self, x, scale, sem_logits, keep_override):
+        if keep_override is not None:
+            keeps = [keep_override.member(scale, i, x.C) for i in range(self.n_infers)]
+        else:
+            keeps = [self._occupied(l) for l in sem_logits]
+        keep = keeps[0]
+        for k in keeps[1:]:
+            keep = keep | k
+        return keep
+
+    # -- panoptic branch ----------------------------------------------------------------------------
+    def predict_panop(self, xs, sem_logits_at_scales, min_Cs, max_Cs, keep_override=None):
+        xs_infers = defaultdict(list)
+        sem_logits_pruneds = []
+        for i in range(self.n_infers):
+            for scale, x in xs.items():
+                logits = sem_logits_at_scales[scale][i]
+                keep = keep_override.member(scale, i, x.C) if keep_override is not None else self._occupied(logits)
+                if int(keep.sum()) == 0:  # reference fallback (decoder_v3.py:415-418)
+                    keep = torch.zeros_like(keep)
+                    keep[:1000] = True
+                keep = keep & inside_bounds(x.C, min_Cs[i], max_Cs[i])
+                if scale == 1:
+                    sem_logits_pruneds.append(self.pruning(logits, keep))
+                xi = self.pruning(x, keep)
+                vf = self.voxel_feats[f"scale{scale}_infer{i}"]
+                h = fused.conv(xi, vf[0], epi_bn=vf[1], epi_act=ACT_RELU)
+                xs_infers[scale].append(fused.conv(h, vf[3]))
+        batched = {s: batch_sparse_tensor(v) for s, v in xs_infers.items()}
+        sem_F, sem_C = batch_sparse_tensor(sem_logits_pruneds)
+        keep_pad = ((sem_F != 0).sum(-1) + (sem_C != 0).sum(-1)) != 0
+        panop = self.transformer_predictor(batched, (sem_F, sem_C), min_Cs, max_Cs, keep_pad)
+        return panop, sem_logits_pruneds
+
+    def forward(self, x, features, global_min_coords, global_max_coords, min_Cs, max_Cs,
+                is_predict_panop=True, keep_override=None):
+        """features = [enc_s1, enc_s2, enc_s4]; x = bottleneck output at tensor stride 8."""
+        assert not self.training, "inference only"
+        skips = features[::-1]
+        sem_logits_at_scales: Dict[int, list] = {}
+        xs: Dict[int, ME.SparseTensor] = {}
+        for i, block in enumerate(self.dec_blocks):
+            scale = 2 ** (len(self.dec_blocks) - 1 - i)
+            x, sem_logits = block(x, skips[i], global_min_coords, global_max_coords)
+            keep = self._keep_completion(x, scale, sem_logits, keep_override)
+            mgr = x.coordinate_manager
+            out_key, rows = mgr.prune(x.coordinate_map_key, keep)
+            be = mgr.backend()
+            x = ME.SparseTensor(be.gather_rows(x.F, rows), coordinate_map_key=out_key, coordinate_manager=mgr)
+            sem_logits = [ME.SparseTensor(be.gather_rows(l.F, rows), coordinate_map_key=out_key,
+                                          coordinate_manager=mgr) for l in sem_logits]
+            xs[scale] = x
+            sem_logits_at_scales[scale] = sem_logits
+        ret = {"sem_logits_at_scales": sem_logits_at_scales}
+        if is_predict_panop:
+            panop, pruned = self.predict_panop(xs, sem_logits_at_scales, min_Cs, max_Cs, keep_override)
+            ret["panop_predictions"] = panop
+            ret["sem_logits_pruneds"] = pruned
+        return ret

@@ -1,0 +1,61 @@
+"""Fused launch helpers: eval-mode BatchNorm folded to per-channel (scale, shift) and handed to the
+conv kernel as gather prologue / store epilogue, so the sparse blocks of PaSCo need no separate
+elementwise passes."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ..me import SparseTensor
+from ..me.backend import ACT_LEAKY, ACT_NONE, ACT_RELU
+from ..me.modules import MinkowskiBatchNorm, _ConvBase
+
+def fold_bn(bn) -> Tuple[torch.Tensor, torch.Tensor]:
+    """BatchNorm (eval) -> (scale, shift) with y = x * scale + shift. Cached per module version."""
+    m = bn.bn if isinstance(bn, MinkowskiBatchNorm) else bn
+    assert isinstance(m, nn.modules.batchnorm._BatchNorm)
+    assert not m.training, "fused graph serves inference (module.eval()) only"
+    ver = (m.running_mean._version, m.running_var._version,
+           m.weight._version if m.weight is not None else -1,
+           m.bias._version if m.bias is not None else -1, m.running_mean.device)
+    hit = getattr(m, "_ph_folded", None)
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        inv = torch.rsqrt(m.running_var.float() + m.eps)
+        scale = inv * (m.weight.float() if m.weight is not None else 1.0)
+        shift = (m.bias.float() if m.bias is not None else 0.0) - m.running_mean.float() * scale
+        scale, shift = scale.contiguous(), shift.contiguous()
+    m._ph_folded = (ver, scale, shift)
+    return scale, shift
+
+
+def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NONE, epi_bn=None,
+         epi_act: int = ACT_NONE, epi2_bn=None, residual: Optional[torch.Tensor] = None,
+         res_act: int = ACT_NONE, slope: float = 0.01, out_key=None, nbr=None) -> SparseTensor:
+    """One fused launch of a Minkowski-style convolution module on `x`.
+
+    out = act_res( act_epi(BN_epi(conv(act_pro(BN_pro(x))) + bias)) -> BN_epi2 -> (+ residual) )
+    """
+    mgr = x.coordinate_manager
+    if out_key is None:
+        out_key, nbr = mod._maps(x)
+    n_out = mgr.size(out_key)
+    ps = pb = es = eb = e2s = e2b = None
+    if pro_bn is not None:
+        ps, pb = fold_bn(pro_bn)
+    if epi_bn is not None:
+        es, eb = fold_bn(epi_bn)
+    if epi2_bn is not None:
+        e2s, e2b = fold_bn(epi2_bn)
+    bias = mod.bias.detach().reshape(-1) if mod.bias is not None else None
+    out = mgr.backend().conv_fwd(
+        x.F if x.F.is_contiguous() else x.F.contiguous(), mod.kernel.detach(), nbr, n_out, bias=bias,
+        pro_scale=ps, pro_shift=pb, pro_act=pro_act, epi_scale=es, epi_shift=eb, epi_act=epi_act,
+        epi2_scale=e2s, epi2_shift=e2b, residual=residual, res_act=res_act, slope=slope)
+    return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
+
+
+__all__ = ["fold_bn", "conv", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]

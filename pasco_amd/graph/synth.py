@@ -127,3 +127,29 @@ def make_scene(seed: int = 0, n_infers: int = 3, in_channels: int = 283, grid=GR
     ext = torch.ceil((gmax - gmin + 1).double() / complete_scale).long() * complete_scale
     gmax = gmin + ext - 1
     return Scene(n_infers, occ, in_feats, in_coords, Ts, min_Cs, max_Cs, gmin, gmax, keep_sets)
+
+
+class TeacherKeep:
+    """Benchmark-only keep masks (SURVEY.md 8(d) "teacher-forced keep"): with random weights
+    `argmax != 0` is arbitrary, so a voxel is kept at scale s for subnet i iff it lies in
+    transform(G_s, T_i).  Membership is a hash lookup on the device; the tables are scene
+    preparation, built outside the timed region."""
+
+    def __init__(self, scene: Scene, device):
+        from ..me.backend import backend_for
+        self.be = backend_for(device)
+        self.tables = {}
+        for s, sets in scene.keep_sets.items():
+            for i, cs in enumerate(sets):
+                c4 = torch.cat([torch.zeros((cs.shape[0], 1), dtype=torch.int64), cs.cpu()], dim=1)
+                c4 = c4.to(torch.int32).to(device).contiguous()
+                tk, tv, _, _, _ = self.be.map_insert(c4, dedup=False)
+                self.tables[(s, i)] = (tk, tv)
+
+    def member(self, scale: int, i: int, coords: torch.Tensor) -> torch.Tensor:
+        tk, tv = self.tables[(scale, i)]
+        q = coords.to(torch.int32).contiguous()
+        if q.shape[0] and int(q[0, 0]) != 0:
+            q = q.clone()
+            q[:, 0] = 0
+        return self.be.map_find(q, tk, tv) >= 0

@@ -1,0 +1,255 @@
+"""Mask-transformer decoder over sparse voxels (reference:
+pasco/models/transformer/transformer_predictor_v2.py:11-303, blocks.py:9-138,
+position_encoding.py:71-135).
+
+Three decoder layers over the voxel sets at tensor stride 4, 2, 1: masked cross-attention
+(queries -> voxels), self-attention, FFN; class / mask heads before the first and after every layer.
+State-dict keys follow the reference.  Quirks reproduced on purpose:
+  * the sine position encoding normalises x / (x + 1e-6) * 2*pi, i.e. ~2*pi for any non-zero
+    coordinate and 0 for 0 (position_encoding.py:100-104);
+  * zero-padded voxel rows take part as attention keys (padding_mask=None,
+    transformer_predictor_v2.py:175-177) and are looked up with wrap-around indices;
+  * a query masked everywhere attends everywhere (:163-164);
+  * cross-attention / FFN add their residual to the *normed* tensor (blocks.py:82,91,118-120).
+The attention-mask construction avoids the reference's dense [1,100,X,Y,Z] detour: the pooled
+keep-mask stays sparse and level voxels look their parent block up in its hash map.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import me as ME
+
+
+def sine_position_encoding(coords: torch.Tensor, num_pos_feats: int, temperature: float = 10000.0,
+                           scale: float = 2 * math.pi) -> torch.Tensor:
+    """coords [N,3] -> [N, 3*num_pos_feats]; interleaved sin/cos per axis, axes concatenated."""
+    c = coords.float()
+    c = c / (c + 1e-6) * scale
+    i = torch.arange(num_pos_feats, dtype=torch.float32, device=coords.device)
+    dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / num_pos_feats)
+    ang = c[:, :, None] / dim_t                                   # [N,3,F]
+    enc = torch.stack((ang[:, :, 0::2].sin(), ang[:, :, 1::2].cos()), dim=2)   # [N,3,2,F/2]
+    return enc.flatten(2).flatten(1)
+
+
+class PositionEmbeddingSineSparse(nn.Module):
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        super().__init__()
+        assert normalize, "the served configuration uses normalize=True"
+        self.num_pos_feats = num_pos_feats
+        self.temperature = temperature
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def forward(self, coords):
+        return sine_position_encoding(coords, self.num_pos_feats, self.temperature, self.scale)
+
+
+def _xavier(module):
+    for p in module.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+
+
+class SelfAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=True)
+        self.norm = nn.LayerNorm(d_model)
+        _xavier(self)
+
+    def forward(self, x, query_pos=None):
+        qk = x if query_pos is None else x + query_pos
+        y = self.self_attn(qk, qk, value=x, need_weights=False)[0]
+        return self.norm(x + y)
+
+
+class CrossAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0):
+        super().__init__()
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=True)
+        self.norm = nn.LayerNorm(d_model)
+        self.nhead = nhead
+        _xavier(self)
+
+    def forward(self, q_embed, feats, attn_mask=None, pos=None, query_pos=None):
+        """q_embed [B,Q,D]; feats [B,N,D]; attn_mask bool [B,Q,N] (True = masked), shared by heads."""
+        q = self.norm(q_embed)
+        kv = feats if pos is None else feats + pos
+        mha = self.multihead_attn
+        B, Q, D = q.shape
+        H = self.nhead
+        w, b = mha.in_proj_weight, mha.in_proj_bias
+        qq = F.linear(q if query_pos is None else q + query_pos, w[:D], b[:D])
+        kk = F.linear(kv, w[D:2 * D], b[D:2 * D])
+        vv = F.linear(kv, w[2 * D:], b[2 * D:])
+        qq = qq.view(B, Q, H, D // H).transpose(1, 2)
+        kk = kk.view(B, -1, H, D // H).transpose(1, 2)
+        vv = vv.view(B, -1, H, D // H).transpose(1, 2)
+        bias = None
+        if attn_mask is not None:
+            bias = torch.zeros(attn_mask.shape, dtype=q.dtype, device=q.device)
+            bias.masked_fill_(attn_mask, float("-inf"))
+            bias = bias[:, None]
+        o = F.scaled_dot_product_attention(qq, kk, vv, attn_mask=bias)
+        o = o.transpose(1, 2).reshape(B, Q, D)
+        return q + mha.out_proj(o)
+
+
+class FFNLayer(nn.Module):
+    def __init__(self, d_model, dim_feedforward=2048, dropout=0.0):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = nn.LayerNorm(d_model)
+        _xavier(self)
+
+    def forward(self, x):
+        x = self.norm(x)
+        return x + self.linear2(F.relu(self.linear1(x)))
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.num_layers = num_layers
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i < self.num_layers - 1:
+                x = F.relu(x)
+        return x
+
+
+class TransformerPredictorV2(nn.Module):
+    def __init__(self, in_channels, num_classes=20, hidden_dim=384, num_queries=100, nheads=8,
+                 dim_feedforward=2048, mask_dim=256, n_infers=2, **_ignored):
+        super().__init__()
+        self.nheads = nheads
+        self.n_infers = n_infers
+        self.hidden_dim = hidden_dim
+        self.query_dim = hidden_dim
+        self.num_queries = num_queries
+        self.decoder_norm = nn.LayerNorm(hidden_dim)
+        self.pe_layer = PositionEmbeddingSineSparse(hidden_dim // 3, normalize=True)
+        self.src_scales = [4, 2, 1]
+        self.num_layers = len(self.src_scales)
+        self.transformer_self_attention_layers = nn.ModuleList(
+            SelfAttentionLayer(hidden_dim, nheads) for _ in range(self.num_layers))
+        self.transformer_cross_attention_layers = nn.ModuleList(
+            CrossAttentionLayer(hidden_dim, nheads) for _ in range(self.num_layers))
+        self.transformer_ffn_layers = nn.ModuleList(
+            FFNLayer(hidden_dim, dim_feedforward) for _ in range(self.num_layers))
+        self.query_feat = nn.Embedding(num_queries * n_infers, hidden_dim)
+        self.query_embed = nn.Embedding(num_queries * n_infers, hidden_dim)
+        self.input_projs = nn.ModuleList(nn.Linear(in_channels[i], hidden_dim) for i in range(self.num_layers))
+        self.max_pools = nn.ModuleDict({
+            str(s): ME.MinkowskiMaxPooling(kernel_size=s, stride=s, dimension=3) for s in self.src_scales})
+        self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
+        self.mask_embed = MLP(hidden_dim, hidden_dim, hidden_dim, 3)
+        self.mask_feat_proj = nn.Linear(mask_dim, hidden_dim)
+
+    # -- heads --------------------------------------------------------------------------------------
+    def pred_heads(self, output, mask_features):
+        d = self.decoder_norm(output)
+        outputs_class = self.class_embed(d)
+        mask_embed = self.mask_embed(d)                                   # [B,Q,D]
+        outputs_mask = torch.matmul(mask_features, mask_embed.transpose(1, 2))   # [B,P,Q]
+        return outputs_class, outputs_mask
+
+    # -- attention mask -----------------------------------------------------------------------------
+    def compute_attn_mask(self, outputs_mask, voxel_coord, src_C, src_scale, min_Cs, max_Cs):
+        """bool [B,Q,N_level], True = query may NOT attend that voxel.
+
+        Query q may attend level voxel p iff some scale-1 voxel v of the same subnet inside p's
+        s^3 block has mask_logit[v,q] > 0 (sigmoid > 0.5) (transformer_predictor_v2.py:220-289)."""
+        B, P, Q = outputs_mask.shape
+        keep_F = (outputs_mask > 0).float().reshape(B * P, Q)
+        bcol = torch.arange(B, device=keep_F.device, dtype=torch.int32).repeat_interleave(P).reshape(-1, 1)
+        keep_C = torch.cat([bcol, voxel_coord.reshape(B * P, 4)[:, 1:].to(torch.int32)], dim=1)
+        keep = ME.SparseTensor(keep_F, keep_C)       # duplicated (padded) rows keep their first occurrence
+        pooled = self.max_pools[str(src_scale)](keep) if src_scale != 1 else keep
+        N = src_C.shape[1]
+        dev = src_C.device
+        mn = torch.stack([torch.as_tensor(m) for m in min_Cs]).to(dev).to(torch.int64)   # [B,3]
+        mx = torch.stack([torch.as_tensor(m) for m in max_Cs]).to(dev).to(torch.int64)
+        size = torch.div(mx - mn, src_scale, rounding_mode="floor") + 1                   # dense extent per subnet
+
+        def sites(coords4, b_index):
+            """dense-grid site of each coordinate, with python-style wrap of negative indices (the
+            reference indexes a dense tensor: SparseTensor.dense + advanced indexing)."""
+            idx = torch.div(coords4[:, 1:].to(torch.int64) - mn[b_index], src_scale, rounding_mode="floor")
+            idx = torch.where(idx < 0, idx + size[b_index], idx)
+            return torch.cat([b_index.reshape(-1, 1), idx], dim=1).to(torch.int32)
+
+        # table over the dense sites the pooled voxels land on
+        pc = pooled.C
+        site_mgr = ME.CoordinateManager(D=3, device=dev)
+        site_key, (_, uniq) = site_mgr.insert_and_map(sites(pc, pc[:, 0].to(torch.int64)), 1)
+        bq = torch.arange(B, device=dev, dtype=torch.int64).repeat_interleave(N)
+        rows = site_mgr.find(site_key, sites(src_C.reshape(B * N, 4), bq))
+        if uniq is not None:   # two pooled voxels wrapped onto one site: keep the first
+            rows = torch.where(rows >= 0, uniq[rows.clamp(min=0).long()], rows)
+        vals = site_mgr.backend().gather_rows(pooled.F.contiguous(), rows.contiguous())   # -1 -> zeros
+        attn_mask = ~(vals.reshape(B, N, Q) != 0)
+        return attn_mask.permute(0, 2, 1)
+
+    # -- forward ------------------------------------------------------------------------------------
+    def forward(self, xs, sem_logits, min_Cs, max_Cs, keep_pad):
+        """xs[scale] = (feats [B,N,C], coords [B,N,4]); returns one dict per subnet."""
+        sem_F, sem_C = sem_logits
+        B = sem_F.shape[0]
+        assert B == self.n_infers, "batch size should be equal to number of inference"
+        D = self.hidden_dim
+        output = self.query_feat.weight.reshape(B, -1, D)
+        query_embed = self.query_embed.weight.reshape(B, -1, D)
+        srcs, src_Cs, pos = [], [], []
+        for s in self.src_scales:
+            f, c = xs[s]
+            srcs.append(f)
+            src_Cs.append(c)
+            pos.append(self.pe_layer(c.reshape(-1, 4)[:, 1:]).reshape(B, -1, D))
+        voxel_coord = xs[1][1]
+        voxel_feat = self.mask_feat_proj(xs[1][0]) + pos[-1]
+        predictions_class, predictions_mask = [], []
+        oc, om = self.pred_heads(output, voxel_feat)
+        predictions_class.append(oc)
+        predictions_mask.append(om)
+        for i in range(self.num_layers):
+            src_F = self.input_projs[i](srcs[i])
+            attn_mask = self.compute_attn_mask(om, voxel_coord, src_Cs[i], self.src_scales[i], min_Cs, max_Cs)
+            all_masked = attn_mask.all(dim=-1, keepdim=True)
+            attn_mask = attn_mask & ~all_masked
+            output = self.transformer_cross_attention_layers[i](output, src_F, attn_mask=attn_mask, pos=pos[i],
+                                                                query_pos=query_embed)
+            output = self.transformer_self_attention_layers[i](output, query_pos=query_embed)
+            output = self.transformer_ffn_layers[i](output)
+            oc, om = self.pred_heads(output, voxel_feat)
+            predictions_class.append(oc)
+            predictions_mask.append(om)
+        panop_predictions = []
+        for b in range(B):
+            keep = keep_pad[b]
+            first = ME.SparseTensor(predictions_mask[0][b][keep].contiguous(), voxel_coord[b][keep])
+            key, mgr = first.coordinate_map_key, first.coordinate_manager
+            idx = first.unique_index        # None unless coordinates repeat
+            masks = [first]
+            for m in predictions_mask[1:]:
+                f = m[b][keep]
+                f = f[idx.long()] if idx is not None else f
+                masks.append(ME.SparseTensor(f.contiguous(), coordinate_map_key=key, coordinate_manager=mgr))
+            classes = [c[b].unsqueeze(0) for c in predictions_class]
+            panop_predictions.append({
+                "query_logits": classes[-1],
+                "voxel_logits": masks[-1],
+                "aux_outputs": [{"query_logits": a, "voxel_logits": m} for a, m in zip(classes[:-1], masks[:-1])],
+            })
+        return panop_predictions

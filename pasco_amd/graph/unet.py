@@ -1,0 +1,145 @@
+"""PaSCo network graph: point-feature stage, MIMO input merge, sparse U-Net + mask transformer.
+
+Reference: pasco/models/unet3d_sparse_v2.py:15-86 (`CylinderFeat`), :89-256 (`UNet3DV2`);
+pasco/models/augmenter.py:13-27 (`Augmenter.merge`); pasco/models/net_panoptic_sparse.py:40-312,
+539-576 (`Net.__init__/forward/step_inference`).  Inference only.  Parameter names follow the
+reference state dict (`feat.*`, `unet3d.encoder.*`, `unet3d.dense3d.*`,
+`unet3d.decoder_generative.*`, `transformer_predictor.*`).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import me as ME
+from .bottleneck import SPCDense3Dv2
+from .decoder import DecoderGenerativeSepConvV2
+from .encoder import Encoder3DSepV2
+from .transformer import TransformerPredictorV2
+
+
+def compute_scene_size(min_coords, max_coords, scale=1):
+    """ceil((max - min + 1) / scale) * scale (reference: pasco/models/misc.py:30-32)."""
+    return (torch.ceil((max_coords - min_coords + 1) / scale) * scale).int()
+
+
+class CylinderFeat(nn.Module):
+    """Per-point MLP + max over the points of a voxel (reference unet3d_sparse_v2.py:15-86).
+
+    The reference shuffles the points before a *sorted* unique + scatter-max, which is
+    result-neutral, so the shuffle is omitted."""
+
+    def __init__(self, fea_dim=3, out_pt_fea_dim=64):
+        super().__init__()
+        self.PPmodel = nn.Sequential(
+            nn.BatchNorm1d(fea_dim), nn.Linear(fea_dim, 64), nn.BatchNorm1d(64), nn.ReLU(),
+            nn.Linear(64, 128), nn.BatchNorm1d(128), nn.ReLU(),
+            nn.Linear(128, 256), nn.BatchNorm1d(256), nn.ReLU(),
+            nn.Linear(256, out_pt_fea_dim))
+
+    def forward(self, pt_fea: List[torch.Tensor], xy_ind: List[torch.Tensor]):
+        ind = torch.cat([F.pad(c, (1, 0), value=i) for i, c in enumerate(xy_ind)], dim=0)
+        fea = torch.cat(pt_fea, dim=0)
+        unq, inv = torch.unique(ind, return_inverse=True, dim=0)
+        h = self.PPmodel(fea)
+        pooled = torch.full((unq.shape[0], h.shape[1]), float("-inf"), dtype=h.dtype, device=h.device)
+        pooled.scatter_reduce_(0, inv[:, None].expand_as(h), h, reduce="amax", include_self=True)
+        return unq.to(torch.int64), pooled
+
+
+def merge_subnet_inputs(in_feat: ME.SparseTensor, n_infers: int) -> ME.SparseTensor:
+    """MIMO multiplexing: voxel-wise channel concat of the subnets' inputs on the union of their
+    coordinates (batch index i -> channel block i), all-zero rows dropped, batch index 0,
+    rows in lexicographic (x,y,z) order.  Same result as the reference's dense round trip
+    (augmenter.py:13-27: .dense -> cat channels -> ME.to_sparse) without the [M,64,X,Y,Z] tensor."""
+    C = in_feat.C
+    Fi = in_feat.F
+    c = Fi.shape[1]
+    xyz = C[:, 1:]
+    uniq, inv = torch.unique(xyz, return_inverse=True, dim=0)      # sorted rows = lexicographic order
+    out = Fi.new_zeros((uniq.shape[0], n_infers * c))
+    col = C[:, 0].to(torch.int64) * c
+    idx = (inv[:, None] * (n_infers * c) + col[:, None] + torch.arange(c, device=Fi.device)[None, :])
+    out.view(-1).index_copy_(0, idx.reshape(-1), Fi.reshape(-1))
+    nz = (out != 0).any(dim=1)
+    if not bool(nz.all()):
+        out, uniq = out[nz], uniq[nz]
+    coords = torch.cat([torch.zeros((uniq.shape[0], 1), dtype=torch.int32, device=uniq.device),
+                        uniq.to(torch.int32)], dim=1)
+    return ME.SparseTensor(out.contiguous(), coords)
+
+
+class UNet3DV2(nn.Module):
+    def __init__(self, in_channels, n_classes, transformer_predictor, n_infers, f_maps, heavy_decoder=True,
+                 dense3d_dropout=0.0, decoder_dropouts=(0.0, 0.0, 0.0), encoder_dropouts=(0.0, 0.0, 0.0)):
+        super().__init__()
+        self.n_infers = n_infers
+        self.transformer_predictor = transformer_predictor
+        self.encoder = Encoder3DSepV2(in_channels, f_maps, heavy_decoder=heavy_decoder, dropouts=encoder_dropouts)
+        self.dense3d = nn.Sequential(SPCDense3Dv2(init_size=f_maps[-1]), nn.Dropout3d(dense3d_dropout))
+        self.decoder_generative = DecoderGenerativeSepConvV2(
+            f_maps, n_classes=n_classes, transformer_predictor=transformer_predictor, n_infers=n_infers,
+            heavy_decoder=heavy_decoder, dropouts=decoder_dropouts)
+        self.encoder = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(self.encoder)
+        self.decoder_generative = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(self.decoder_generative)
+
+    def dense_bottleneck(self, deepest: ME.SparseTensor, bs, global_min_coords, global_max_coords):
+        """stride-8 features -> dense grid -> SPCDense3Dv2 -> back to a sparse tensor that shares the
+        encoder's coordinate manager (unet3d_sparse_v2.py:182-214)."""
+        scale = deepest.tensor_stride[0]
+        gmin = global_min_coords.to(deepest.device)
+        max_c = deepest.C[:, 1:].max(dim=0)[0].to(torch.int32)
+        gmax = torch.max(global_max_coords.to(deepest.device).to(torch.int32), max_c)
+        size = (compute_scene_size(gmin, gmax, scale) // scale).tolist()
+        shape = torch.Size((bs, deepest.shape[1], *size))
+        dense = deepest.dense(shape, min_coordinate=torch.IntTensor(gmin.tolist()))[0]
+        dense = self.dense3d(dense)
+        t = ME.to_sparse(dense)
+        coords = t.C.clone()
+        coords[:, 1:] = coords[:, 1:] * scale + gmin.reshape(1, -1).to(coords.dtype)
+        return ME.SparseTensor(features=t.F, coordinates=coords, tensor_stride=scale,
+                               coordinate_manager=deepest.coordinate_manager)
+
+    def forward(self, in_feat, bs, global_min_coords, global_max_coords, min_Cs, max_Cs,
+                is_predict_panop=True, keep_override=None):
+        assert not self.training, "inference only"
+        feats = self.encoder(in_feat)
+        deepest = self.dense_bottleneck(feats[-1], bs, global_min_coords, global_max_coords)
+        return self.decoder_generative(deepest, feats[:-1], global_min_coords, global_max_coords, min_Cs, max_Cs,
+                                       is_predict_panop=is_predict_panop, keep_override=keep_override)
+
+
+class PascoNet(nn.Module):
+    """Inference graph of the reference `Net` (net_panoptic_sparse.py:40-312): `feat` (point MLP),
+    MIMO merge, `unet3d` (+ `transformer_predictor`).  Ensembling / panoptic post-processing are the
+    next rows of SURVEY.md 8(f)."""
+
+    def __init__(self, n_classes=20, n_infers=1, in_channels=27 + 256, f=64, num_queries=100, heavy_decoder=True,
+                 encoder_dropouts=(0.0, 0.0, 0.0), decoder_dropouts=(0.0, 0.0, 0.0), dense3d_dropout=0.0):
+        super().__init__()
+        self.n_infers = n_infers
+        self.n_classes = n_classes
+        self.transformer_predictor = TransformerPredictorV2(
+            in_channels=[f * 4, f * 2, f], num_classes=n_classes, hidden_dim=384, num_queries=num_queries, nheads=8,
+            dim_feedforward=1024, mask_dim=f, n_infers=n_infers)
+        self.unet3d = UNet3DV2(in_channels=f * n_infers, n_classes=n_classes,
+                               transformer_predictor=self.transformer_predictor, n_infers=n_infers,
+                               f_maps=[f, f * 2, f * 4, f * 4], heavy_decoder=heavy_decoder,
+                               dense3d_dropout=dense3d_dropout, decoder_dropouts=decoder_dropouts,
+                               encoder_dropouts=encoder_dropouts)
+        self.feat = CylinderFeat(fea_dim=in_channels, out_pt_fea_dim=f)
+
+    def prepare_input(self, in_feats: List[torch.Tensor], in_coords: List[torch.Tensor]) -> ME.SparseTensor:
+        """`self.feat` + `ME.SparseTensor` + `Augmenter.merge` (net_panoptic_sparse.py:548-550)."""
+        coords, feats = self.feat(in_feats, in_coords)
+        x = ME.SparseTensor(feats, coords.int())
+        return merge_subnet_inputs(x, self.n_infers)
+
+    def forward(self, in_feat: ME.SparseTensor, global_min_coords, global_max_coords, min_Cs, max_Cs,
+                is_predict_panop=True, keep_override=None):
+        """The reference's timed window: `self.unet3d(...)` (net_panoptic_sparse.py:228-250)."""
+        return self.unet3d(in_feat, 1, global_min_coords, global_max_coords, min_Cs, max_Cs,
+                           is_predict_panop=is_predict_panop, keep_override=keep_override)

@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("epi_scale", _vp), ("epi_shift", _vp),
         ("epi_act", _i32), ("epi_slope", C.c_float),
         ("residual", _vp), ("res_act", _i32), ("reserved", _i32),
+        ("epi2_scale", _vp), ("epi2_shift", _vp),
     ]
 
 
@@ -223,6 +224,7 @@ class CBackend:
     def conv_fwd(self, x: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tensor], n_out: int,
                  *, bias=None, pro_scale=None, pro_shift=None, pro_act=ACT_NONE, epi_scale=None,
                  epi_shift=None, epi_act=ACT_NONE, slope=0.01, residual=None, res_act=ACT_NONE,
+                 epi2_scale=None, epi2_shift=None,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._chk(x, torch.float32, "in")
         self._chk(weight, torch.float32, "weight")
@@ -238,13 +240,16 @@ class CBackend:
                 raise ValueError(f"conv: nbr shape {tuple(nbr.shape)} != {(kvol, n_out)}")
         if out is None:
             out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+        if n_out == 0:
+            return out
         d = ConvDesc()
         d.in_, d.weight, d.nbr, d.out = _ptr(x), _ptr(weight), _ptr(nbr), _ptr(out)
         d.n_in, d.n_out, d.cin, d.cout, d.kvol = x.shape[0], n_out, cin, cout, kvol
         d.pro_act, d.epi_act, d.res_act, d.epi_slope = pro_act, epi_act, res_act, float(slope)
         for name, t, c in (("pro_scale", pro_scale, cin), ("pro_shift", pro_shift, cin),
                            ("bias", bias, cout), ("epi_scale", epi_scale, cout),
-                           ("epi_shift", epi_shift, cout)):
+                           ("epi_shift", epi_shift, cout), ("epi2_scale", epi2_scale, cout),
+                           ("epi2_shift", epi2_shift, cout)):
             if t is not None:
                 self._chk(t, torch.float32, name)
                 if t.numel() != c:
