@@ -187,6 +187,25 @@ int PH_FN(to_sparse_coords)(const float *dense, int32_t c, const int32_t *h_dims
 int PH_FN(dense_gather)(const float *dense, int32_t c, const int32_t *h_dims4,
                         const int32_t *site_coords, int64_t n, float *feats, ph_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Masked cross-attention of <= 128 queries over N voxel keys (CrossAttentionLayer of the mask
+ * transformer: pasco/models/transformer/blocks.py:73-92, called at
+ * transformer_predictor_v2.py:167-173 with the mask of :220-289).
+ *   q [B, H, Qn, Dh] (pre-scaled by 1/sqrt(Dh)), k / v [B, N, H*Dh], out [B, Qn, H*Dh]
+ *   bits [B, N, 4]: bit q of the 128-bit word = query q may attend that key (NULL = no mask)
+ *   any  [B, 4]   : OR of bits over the keys; a query with no allowed key attends everywhere
+ *                   (transformer_predictor_v2.py:163-164)
+ * attn_mask_pack builds bits / any from allow flags vals [B*N, Qn] (non-zero = allowed).
+ * ------------------------------------------------------------------------------------------- */
+int64_t PH_FN(attn_workspace_bytes)(int64_t n, int32_t b, int32_t h, int32_t qn, int32_t dh);
+
+int PH_FN(attn_mask_pack)(const float *vals, int64_t n, int32_t b, int32_t qn, uint32_t *bits,
+                          uint32_t *any, ph_stream_t stream);
+
+int PH_FN(attn_cross_fwd)(const float *q, const float *k, const float *v, const uint32_t *bits,
+                          const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h,
+                          int32_t qn, int32_t dh, void *ws, int64_t ws_bytes, ph_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -377,3 +377,71 @@ int pho_dense_gather(const float *dense, int32_t c, const int32_t *h_dims4, cons
   }
   return 0;
 }
+
+/* ---- masked cross-attention (transformer/blocks.py:73-92; mask transformer_predictor_v2.py:220-289,
+ * all-masked rule :163-164): plain two-pass softmax per (b, h, q) in double accumulation-free fp32. */
+int64_t pho_attn_workspace_bytes(int64_t n, int32_t b, int32_t h, int32_t qn, int32_t dh) {
+  (void)n; (void)b; (void)h; (void)qn; (void)dh;
+  return 256;
+}
+
+int pho_attn_mask_pack(const float *vals, int64_t n, int32_t b, int32_t qn, uint32_t *bits, uint32_t *any,
+                       ph_stream_t stream) {
+  (void)stream;
+  if (qn < 1 || qn > 128) return fail("attn_mask_pack: bad qn");
+  if (any) memset(any, 0, sizeof(uint32_t) * 4 * (size_t)b);
+  for (int64_t row = 0; row < (int64_t)b * n; ++row) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int q = 0; q < qn; ++q)
+      if (vals[row * qn + q] != 0.f) w[q >> 5] |= 1u << (q & 31);
+    for (int i = 0; i < 4; ++i) {
+      bits[row * 4 + i] = w[i];
+      if (any) any[(row / n) * 4 + i] |= w[i];
+    }
+  }
+  return 0;
+}
+
+int pho_attn_cross_fwd(const float *q, const float *k, const float *v, const uint32_t *bits, const uint32_t *any,
+                       float *out, int64_t n, int32_t b, int32_t h, int32_t qn, int32_t dh, void *ws,
+                       int64_t ws_bytes, ph_stream_t stream) {
+  (void)ws; (void)ws_bytes; (void)stream;
+  if (qn < 1 || qn > 128 || dh < 1) return fail("attn_cross_fwd: bad shape");
+  const int D = h * dh;
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int bi = 0; bi < b; ++bi)
+    for (int task = 0; task < h * qn; ++task) {
+      const int hi = task / qn, qi = task % qn;
+      const float *qv = q + (((int64_t)bi * h + hi) * qn + qi) * dh;
+      int force = bits == NULL;
+      if (bits && any) force = !((any[bi * 4 + (qi >> 5)] >> (qi & 31)) & 1u);
+      float *sc = (float *)malloc(sizeof(float) * (size_t)n);
+      float mx = -INFINITY;
+      for (int64_t j = 0; j < n; ++j) {
+        int ok = force || ((bits[((int64_t)bi * n + j) * 4 + (qi >> 5)] >> (qi & 31)) & 1u);
+        float s = -INFINITY;
+        if (ok) {
+          const float *kv = k + ((int64_t)bi * n + j) * D + hi * dh;
+          s = 0.f;
+          for (int d = 0; d < dh; ++d) s += qv[d] * kv[d];
+        }
+        sc[j] = s;
+        if (s > mx) mx = s;
+      }
+      float *o = out + ((int64_t)bi * qn + qi) * D + hi * dh;
+      for (int d = 0; d < dh; ++d) o[d] = 0.f;
+      float l = 0.f;
+      if (mx > -INFINITY) {
+        for (int64_t j = 0; j < n; ++j) {
+          if (sc[j] == -INFINITY) continue;
+          float p = expf(sc[j] - mx);
+          l += p;
+          const float *vv = v + ((int64_t)bi * n + j) * D + hi * dh;
+          for (int d = 0; d < dh; ++d) o[d] += p * vv[d];
+        }
+        for (int d = 0; d < dh; ++d) o[d] /= l;
+      }
+      free(sc);
+    }
+  return 0;
+}

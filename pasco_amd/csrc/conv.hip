@@ -2,9 +2,9 @@
 //
 //   out[o,:] = epi( sum_k [nbr[k][o] >= 0] * pro(in[nbr[k][o],:]) @ W[k] + bias )   (pasco_hip.h)
 //
-// One workgroup (256 threads = 4 wave64) owns BM = 128 output rows x BN output channels and walks
-// the (kernel offset, input-channel chunk) stages.  Per stage the 128 neighbour rows are gathered
-// with 16-byte coalesced loads (a 32-float chunk of a row = 8 lanes x float4) into an LDS A tile,
+// One workgroup (256 threads = 4 wave64) owns BM (128/64/32) output rows x BN output channels and walks
+// the (kernel offset, input-channel chunk) stages.  Per stage the BM neighbour rows are gathered
+// with 16-byte coalesced loads (a 32/64-float chunk of a row = 8/16 lanes x float4) into an LDS A tile,
 // the matching W[k] slab goes into an LDS B tile, and the waves run v_mfma_f32_32x32x2_f32
 // (exact fp32, SURVEY.md 8(d): C >= 128 layers are FLOP-bound in fp32, C = 64 sits at the ridge).
 // The output tile lives in accumulator registers for the whole kernel-offset loop and is written
@@ -15,19 +15,18 @@
 //
 // LDS layouts (bank maths in MI355X_MICROARCH.md "LDS"):
 //   As[BM][BKC + 4]  row-major; a lane reads its 4 k-values with one ds_read_b128; row stride of
-//                    36 dwords makes any 16 rows with distinct (row mod 16) hit distinct 16-byte
+//                    36 / 68 dwords makes any 16 rows with distinct (row mod 16) hit distinct 16-byte
 //                    slots -> conflict free for the b128 lane groups.
 //   Bs[BKC][BN + 4]  k-major; lanes 0..31 read 32 consecutive dwords (ds_read_b32).
 // The contraction index inside an 8-wide step is permuted (hardware k-half h <-> k = 4h + s) so
 // that A needs one wide read per 4 MFMAs; A and B use the same permutation.
+#include <stdlib.h>
+
 #include "ph_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int CV_THREADS = 256;
-constexpr int BM = 128;
-constexpr int BKC = 32;
-constexpr int A_LD = BKC + 4;
 
 struct ConvArgs {
   const float *in;
@@ -49,14 +48,19 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
   return v;
 }
 
-// WM x WN waves, each TM x TN tiles of 32x32.  WM*TM*32 == BM.
-template <int WM, int WN, int TM, int TN, bool VEC_A, bool VEC_B>
+// Tile = BM output rows x BN output channels, BKC input channels per LDS stage.
+// WM x WN waves (4 in total), each TM x TN MFMA tiles of 32x32:  BM = WM*TM*32, BN = WN*TN*32.
+template <int BM, int BKC, int WM, int WN, int TM, int TN, bool VEC_A, bool VEC_B>
 __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
   constexpr int BN = WN * TN * 32;
+  constexpr int A_LD = BKC + 4;
   constexpr int B_LD = BN + 4;
-  constexpr int A_PASSES = BM * (BKC / 4) / CV_THREADS;  // float4 slots per thread (4)
-  constexpr int B_SLOTS = BKC * (BN / 4) / CV_THREADS;   // float4 slots per thread
+  constexpr int A_TPR = BKC / 4;                 // threads (float4 slots) per gathered row chunk
+  constexpr int A_RPP = CV_THREADS / A_TPR;      // rows per pass
+  constexpr int A_PASSES = BM / A_RPP;           // float4 slots per thread
+  constexpr int B_SLOTS = BKC * (BN / 4) / CV_THREADS;
   static_assert(WM * WN == 4 && WM * TM * 32 == BM, "tile shape");
+  static_assert(A_PASSES >= 1 && B_SLOTS >= 1, "loader shape");
 
   __shared__ __attribute__((aligned(16))) float As[BM * A_LD];
   __shared__ __attribute__((aligned(16))) float Bs[BKC * B_LD];
@@ -85,9 +89,8 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
   const int nchunks = (cin + BKC - 1) / BKC;
   const int nstages = a.kvol * nchunks;
 
-  // A loader mapping: 8 float4 per row chunk, 32 rows per pass
-  const int a_c4 = tid & 7;
-  const int a_r0 = tid >> 3;
+  const int a_c4 = tid % A_TPR;
+  const int a_r0 = tid / A_TPR;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -99,23 +102,29 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
 
   float4 ra[A_PASSES];
   float4 rb[B_SLOTS];
-  unsigned a_valid = 0;
+  int idx_cur[A_PASSES], idx_nxt[A_PASSES];
   int cur_c0 = 0;
 
-  auto load_stage = [&](int s) {
-    const int k = s / nchunks;
-    const int c0 = (s - k * nchunks) * BKC;
+  // neighbour rows of this thread's A slots for kernel offset k (prefetched one offset ahead so
+  // that the dependent row loads never wait for an index load)
+  auto load_idx = [&](int k, int *dst) {
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      const int64_t row = m0 + a_r0 + p * A_RPP;
+      int idx = -1;
+      if (row < a.n_out) idx = a.nbr ? a.nbr[(int64_t)k * a.n_out + row] : (int)row;
+      dst[p] = idx;
+    }
+  };
+
+  auto load_stage = [&](int k, int c0) {
     cur_c0 = c0;
-    a_valid = 0;
     const int cbase = c0 + a_c4 * 4;
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
-      const int64_t row = m0 + a_r0 + p * 32;
-      int idx = -1;
-      if (row < a.n_out) idx = a.nbr ? a.nbr[(int64_t)k * a.n_out + row] : (int)row;
+      const int idx = idx_cur[p];
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx >= 0) {
-        a_valid |= (1u << p);
         const float *src = a.in + (int64_t)idx * cin + cbase;
         if (VEC_A) {
           if (cbase < cin) v = *reinterpret_cast<const float4 *>(src);
@@ -152,10 +161,13 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
     }
   };
 
-  auto store_stage = [&]() {
+  const bool has_pro = (a.pro_scale != nullptr) || (a.pro_shift != nullptr) || a.pro_act != PH_ACT_NONE;
+
+  // registers -> LDS, applying the gather prologue (BN affine + activation) to valid rows only.
+  // `valid` holds one bit per pass for the stage whose data sits in ra[].
+  auto store_stage = [&](unsigned valid) {
     const int cbase = cur_c0 + a_c4 * 4;
     float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pb = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool has_pro = (a.pro_scale != nullptr) || (a.pro_shift != nullptr) || a.pro_act != PH_ACT_NONE;
     if (has_pro) {
       float s4[4] = {1.f, 1.f, 1.f, 1.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -171,18 +183,17 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
       float4 v = ra[p];
-      if (has_pro && ((a_valid >> p) & 1u)) {
+      if (has_pro && ((valid >> p) & 1u)) {
         v.x = act_apply(v.x * ps.x + pb.x, a.pro_act, a.slope);
         v.y = act_apply(v.y * ps.y + pb.y, a.pro_act, a.slope);
         v.z = act_apply(v.z * ps.z + pb.z, a.pro_act, a.slope);
         v.w = act_apply(v.w * ps.w + pb.w, a.pro_act, a.slope);
-        // channels beyond cin must stay zero
-        if (cbase + 0 >= cin) v.x = 0.f;
+        if (cbase + 0 >= cin) v.x = 0.f;  // channels beyond cin must stay zero
         if (cbase + 1 >= cin) v.y = 0.f;
         if (cbase + 2 >= cin) v.z = 0.f;
         if (cbase + 3 >= cin) v.w = 0.f;
       }
-      *reinterpret_cast<float4 *>(&As[(a_r0 + p * 32) * A_LD + a_c4 * 4]) = v;
+      *reinterpret_cast<float4 *>(&As[(a_r0 + p * A_RPP) * A_LD + a_c4 * 4]) = v;
     }
 #pragma unroll
     for (int q = 0; q < B_SLOTS; ++q) {
@@ -219,11 +230,32 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
     }
   };
 
-  load_stage(0);
+  auto valid_bits = [&]() {
+    unsigned v = 0;
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) v |= (idx_cur[p] >= 0 ? 1u : 0u) << p;
+    return v;
+  };
+
+  load_idx(0, idx_cur);
+  if (a.kvol > 1) load_idx(1, idx_nxt);
+  load_stage(0, 0);
+  unsigned valid = valid_bits();
+  int k = 0, chunk = 0;
   for (int s = 0; s < nstages; ++s) {
-    store_stage();
+    store_stage(valid);
     __syncthreads();
-    if (s + 1 < nstages) load_stage(s + 1);
+    if (s + 1 < nstages) {
+      if (++chunk == nchunks) {
+        chunk = 0;
+        ++k;
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) idx_cur[p] = idx_nxt[p];
+        if (k + 1 < a.kvol) load_idx(k + 1, idx_nxt);
+      }
+      load_stage(k, chunk * BKC);
+      valid = valid_bits();
+    }
     compute_stage();
     __syncthreads();
   }
@@ -258,7 +290,7 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
   }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int BM, int BKC, int WM, int WN, int TM, int TN>
 static int launch_conv(const ConvArgs &a, hipStream_t st) {
   constexpr int BN = WN * TN * 32;
   ConvArgs args = a;
@@ -269,20 +301,37 @@ static int launch_conv(const ConvArgs &a, hipStream_t st) {
   const bool va = (a.cin % 4 == 0) && (((uintptr_t)a.in & 15) == 0);
   const bool vb = (a.cout % 4 == 0) && (((uintptr_t)a.w & 15) == 0);
   if (va && vb)
-    hipLaunchKernelGGL((k_conv_mfma<WM, WN, TM, TN, true, true>), dim3(grid), dim3(CV_THREADS), 0, st, args);
+    hipLaunchKernelGGL((k_conv_mfma<BM, BKC, WM, WN, TM, TN, true, true>), dim3(grid), dim3(CV_THREADS), 0, st, args);
   else if (va)
-    hipLaunchKernelGGL((k_conv_mfma<WM, WN, TM, TN, true, false>), dim3(grid), dim3(CV_THREADS), 0, st, args);
+    hipLaunchKernelGGL((k_conv_mfma<BM, BKC, WM, WN, TM, TN, true, false>), dim3(grid), dim3(CV_THREADS), 0, st, args);
   else if (vb)
-    hipLaunchKernelGGL((k_conv_mfma<WM, WN, TM, TN, false, true>), dim3(grid), dim3(CV_THREADS), 0, st, args);
+    hipLaunchKernelGGL((k_conv_mfma<BM, BKC, WM, WN, TM, TN, false, true>), dim3(grid), dim3(CV_THREADS), 0, st, args);
   else
-    hipLaunchKernelGGL((k_conv_mfma<WM, WN, TM, TN, false, false>), dim3(grid), dim3(CV_THREADS), 0, st, args);
+    hipLaunchKernelGGL((k_conv_mfma<BM, BKC, WM, WN, TM, TN, false, false>), dim3(grid), dim3(CV_THREADS), 0, st, args);
   PH_LAUNCH_CHECK();
   return 0;
 }
 
+// Tile selection (measured on MI355X, profiles/r1b_op_bench.json): 64-row tiles beat 128-row tiles
+// at every PaSCo layer shape (more workgroups in flight hide the gather latency better); layers
+// whose 64-row tiling cannot cover the 256 CUs twice drop to 32 rows.  PASCO_CONV_CFG="bm" overrides.
+static int pick_cfg(const ConvArgs &a, int *bm) {
+  const int bn = a.cout <= 32 ? 32 : (a.cout <= 64 ? 64 : 128);
+  const int64_t ncol = (a.cout + bn - 1) / bn;
+  int m = bn == 32 ? 128 : 64;
+  if (bn == 128 && ((a.n_out + 63) / 64) * ncol < 2 * 256) m = 32;
+  const char *env = getenv("PASCO_CONV_CFG");
+  if (env) {
+    const int em = atoi(env);
+    if (em == 128 || (em == 64 && bn >= 64) || (em == 32 && bn == 128)) m = em;
+  }
+  *bm = m;
+  return bn;
+}
+
 extern "C" int ph_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   PH_REQUIRE(d != nullptr, "conv_fwd: null desc");
-  PH_REQUIRE(d->cin > 0 && d->cout > 0 && d->kvol >= 1 && d->kvol <= PH_MAX_KVOL,
+  PH_REQUIRE(d->cin > 0 && d->cout > 0 && d->kvol >= 1 && d->kvol <= 4096,
              "conv_fwd: bad shape cin=%d cout=%d kvol=%d", d->cin, d->cout, d->kvol);
   PH_REQUIRE(d->n_out >= 0 && d->n_out < 0x7FFFFF00, "conv_fwd: bad n_out");
   if (d->n_out == 0) return 0;
@@ -314,7 +363,21 @@ extern "C" int ph_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   a.slope = d->epi_slope;
   a.n_row_tiles = a.n_col_tiles = 0;
   hipStream_t st = ph_stream(stream);
-  if (d->cout <= 32) return launch_conv<4, 1, 1, 1>(a, st);
-  if (d->cout <= 64) return launch_conv<4, 1, 1, 2>(a, st);
-  return launch_conv<2, 2, 2, 2>(a, st);
+  int bm = 128;
+  const int bn = pick_cfg(a, &bm);
+#define PH_CONV_CASE(BM_, WM_, WN_, TM_, TN_) \
+  if (bm == BM_) return launch_conv<BM_, 32, WM_, WN_, TM_, TN_>(a, st)
+  if (bn == 32) {
+    PH_CONV_CASE(128, 4, 1, 1, 1);
+  } else if (bn == 64) {
+    PH_CONV_CASE(128, 4, 1, 1, 2);
+    PH_CONV_CASE(64, 2, 2, 1, 1);
+  } else {
+    PH_CONV_CASE(128, 2, 2, 2, 2);
+    PH_CONV_CASE(64, 2, 2, 1, 2);
+    PH_CONV_CASE(32, 1, 4, 1, 1);
+  }
+#undef PH_CONV_CASE
+  ph_set_error("conv_fwd: no kernel for bm=%d bn=%d", bm, bn);
+  return 1;
 }

@@ -24,6 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import me as ME
+from ..me.backend import backend_for
 
 
 def sine_position_encoding(coords: torch.Tensor, num_pos_feats: int, temperature: float = 10000.0,
@@ -77,8 +78,10 @@ class CrossAttentionLayer(nn.Module):
         self.nhead = nhead
         _xavier(self)
 
-    def forward(self, q_embed, feats, attn_mask=None, pos=None, query_pos=None):
-        """q_embed [B,Q,D]; feats [B,N,D]; attn_mask bool [B,Q,N] (True = masked), shared by heads."""
+    def forward(self, q_embed, feats, attn_mask=None, pos=None, query_pos=None, mask_bits=None):
+        """q_embed [B,Q,D]; feats [B,N,D].  Mask either as `attn_mask` bool [B,Q,N] (True = masked,
+        shared by the heads; torch path) or as `mask_bits` = (bits [B,N,4], any [B,4]) for the fused
+        HIP kernel (ph_attn_cross_fwd), which also applies the all-masked -> unmasked rule."""
         q = self.norm(q_embed)
         kv = feats if pos is None else feats + pos
         mha = self.multihead_attn
@@ -89,6 +92,11 @@ class CrossAttentionLayer(nn.Module):
         kk = F.linear(kv, w[D:2 * D], b[D:2 * D])
         vv = F.linear(kv, w[2 * D:], b[2 * D:])
         qq = qq.view(B, Q, H, D // H).transpose(1, 2)
+        if mask_bits is not None:
+            be = backend_for(q.device)
+            q4 = (qq * (float(D // H) ** -0.5)).contiguous()
+            o = be.attn_cross_fwd(q4, kk.contiguous(), vv.contiguous(), mask_bits[0], mask_bits[1])
+            return q + mha.out_proj(o)
         kk = kk.view(B, -1, H, D // H).transpose(1, 2)
         vv = vv.view(B, -1, H, D // H).transpose(1, 2)
         bias = None
@@ -166,8 +174,8 @@ class TransformerPredictorV2(nn.Module):
         return outputs_class, outputs_mask
 
     # -- attention mask -----------------------------------------------------------------------------
-    def compute_attn_mask(self, outputs_mask, voxel_coord, src_C, src_scale, min_Cs, max_Cs):
-        """bool [B,Q,N_level], True = query may NOT attend that voxel.
+    def compute_allow(self, outputs_mask, voxel_coord, src_C, src_scale, min_Cs, max_Cs):
+        """fp32 [B*N_level, Q] allow flags (non-zero = query may attend that voxel).
 
         Query q may attend level voxel p iff some scale-1 voxel v of the same subnet inside p's
         s^3 block has mask_logit[v,q] > 0 (sigmoid > 0.5) (transformer_predictor_v2.py:220-289)."""
@@ -198,9 +206,7 @@ class TransformerPredictorV2(nn.Module):
         rows = site_mgr.find(site_key, sites(src_C.reshape(B * N, 4), bq))
         if uniq is not None:   # two pooled voxels wrapped onto one site: keep the first
             rows = torch.where(rows >= 0, uniq[rows.clamp(min=0).long()], rows)
-        vals = site_mgr.backend().gather_rows(pooled.F.contiguous(), rows.contiguous())   # -1 -> zeros
-        attn_mask = ~(vals.reshape(B, N, Q) != 0)
-        return attn_mask.permute(0, 2, 1)
+        return site_mgr.backend().gather_rows(pooled.F.contiguous(), rows.contiguous())   # -1 -> zeros
 
     # -- forward ------------------------------------------------------------------------------------
     def forward(self, xs, sem_logits, min_Cs, max_Cs, keep_pad):
@@ -225,11 +231,18 @@ class TransformerPredictorV2(nn.Module):
         predictions_mask.append(om)
         for i in range(self.num_layers):
             src_F = self.input_projs[i](srcs[i])
-            attn_mask = self.compute_attn_mask(om, voxel_coord, src_Cs[i], self.src_scales[i], min_Cs, max_Cs)
-            all_masked = attn_mask.all(dim=-1, keepdim=True)
-            attn_mask = attn_mask & ~all_masked
-            output = self.transformer_cross_attention_layers[i](output, src_F, attn_mask=attn_mask, pos=pos[i],
-                                                                query_pos=query_embed)
+            allow = self.compute_allow(om, voxel_coord, src_Cs[i], self.src_scales[i], min_Cs, max_Cs)
+            N_i, Qn = src_F.shape[1], om.shape[2]
+            be = backend_for(src_F.device)
+            if be.attn_supported(Qn, D // self.nheads):
+                bits = be.attn_mask_pack(allow, B, N_i)
+                output = self.transformer_cross_attention_layers[i](output, src_F, pos=pos[i], query_pos=query_embed,
+                                                                    mask_bits=bits)
+            else:   # shapes outside the fused kernel: torch attention with the materialised mask
+                attn_mask = ~(allow.reshape(B, N_i, Qn) != 0).permute(0, 2, 1)
+                attn_mask = attn_mask & ~attn_mask.all(dim=-1, keepdim=True)   # all-masked -> unmasked
+                output = self.transformer_cross_attention_layers[i](output, src_F, attn_mask=attn_mask,
+                                                                    pos=pos[i], query_pos=query_embed)
             output = self.transformer_self_attention_layers[i](output, query_pos=query_embed)
             output = self.transformer_ffn_layers[i](output)
             oc, om = self.pred_heads(output, voxel_feat)

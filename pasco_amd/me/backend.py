@@ -59,12 +59,12 @@ _SIGNATURES = {
     "to_dense": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp],
     "to_sparse_coords": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "dense_gather": [_vp, _i32, _vp, _vp, _i64, _vp, _vp],
+    "attn_workspace_bytes": [_i64, _i32, _i32, _i32, _i32],
+    "attn_mask_pack": [_vp, _i64, _i32, _i32, _vp, _vp, _vp],
+    "attn_cross_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
 }
-_RESTYPES = {"last_error": C.c_char_p, "workspace_bytes": _i64}
-# optional entry points (present in the HIP library only)
-_OPTIONAL = {
-    "attn_cross_fwd": [_vp] * 3 + [_vp] * 3 + [_i64, _i32, _i32, _i32, C.c_float, _vp, _vp],
-}
+_RESTYPES = {"last_error": C.c_char_p, "workspace_bytes": _i64, "attn_workspace_bytes": _i64}
+_OPTIONAL = {}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
 
@@ -356,6 +356,41 @@ class CBackend:
                                      self.stream(dense.device))
         self._check(rc, "dense_gather")
         return feats
+
+
+    # -- attention -----------------------------------------------------------------------------------
+    def attn_mask_pack(self, vals: torch.Tensor, b: int, n: int):
+        """allow flags [B*N, Qn] fp32 -> (bits int32 [B, N, 4], any int32 [B, 4])."""
+        self._chk(vals, torch.float32, "vals")
+        qn = vals.shape[1]
+        assert vals.shape[0] == b * n
+        bits = torch.empty((b, n, 4), dtype=torch.int32, device=vals.device)
+        any_ = torch.empty((b, 4), dtype=torch.int32, device=vals.device)
+        rc = self.fn["attn_mask_pack"](_ptr(vals), n, b, qn, _ptr(bits), _ptr(any_), self.stream(vals.device))
+        self._check(rc, "attn_mask_pack")
+        return bits, any_
+
+    def attn_supported(self, qn: int, dh: int) -> bool:
+        return qn <= 128 and (dh == 48 or self.device_type == "cpu")
+
+    def attn_cross_fwd(self, q, k, v, bits=None, any_=None) -> torch.Tensor:
+        """q [B,H,Qn,Dh] (pre-scaled), k/v [B,N,H*Dh] -> out [B,Qn,H*Dh]."""
+        for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+            self._chk(t, torch.float32, nm)
+        b, h, qn, dh = q.shape
+        n = k.shape[1]
+        assert k.shape == (b, n, h * dh) and v.shape == k.shape
+        out = torch.empty((b, qn, h * dh), dtype=torch.float32, device=q.device)
+        need = int(self.fn["attn_workspace_bytes"](n, b, h, qn, dh))
+        key = ("attn", q.device)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+            self._ws[key] = ws
+        rc = self.fn["attn_cross_fwd"](_ptr(q), _ptr(k), _ptr(v), _ptr(bits), _ptr(any_), _ptr(out), n, b, h, qn, dh,
+                                       _ptr(ws), ws.numel(), self.stream(q.device))
+        self._check(rc, "attn_cross_fwd")
+        return out
 
 
 # ---- registry -----------------------------------------------------------------------------------

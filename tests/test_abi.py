@@ -1,0 +1,65 @@
+"""C-ABI surface: both shared libraries export every entry point include/pasco_hip.h declares, the
+ctypes mirror of `ph_conv_desc` has the C layout, and the product has no CPU path.  No compute."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pasco_hip.h")
+
+
+def declared():
+    src = open(HEADER).read()
+    return sorted(set(re.findall(r"PH_FN\((\w+)\)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    names = declared()
+    for must in ("map_insert", "nbr_build", "kmap_compact", "conv_fwd", "maxpool_fwd", "mask_compact",
+                 "to_dense", "to_sparse_coords", "attn_cross_fwd"):
+        assert must in names
+
+
+def test_hip_library_exports_every_symbol():
+    from pasco_amd.build import build_hip
+    lib = ctypes.CDLL(build_hip(verbose=False))
+    for n in declared():
+        assert hasattr(lib, "ph_" + n), f"libpascohip.so lacks ph_{n}"
+    lib.ph_abi_version.restype = ctypes.c_int
+    assert lib.ph_abi_version() == 1
+
+
+def test_oracle_exports_every_symbol(oracle):
+    for n in declared():
+        assert hasattr(oracle.lib, "pho_" + n), f"oracle lacks pho_{n}"
+
+
+def test_conv_desc_layout_matches_c():
+    from pasco_amd.me.backend import ConvDesc
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "pasco_hip.h"\nint main(){printf("%zu %zu %zu %zu", ' \
+           'sizeof(ph_conv_desc), offsetof(ph_conv_desc, cin), offsetof(ph_conv_desc, residual), ' \
+           'offsetof(ph_conv_desc, epi2_scale)); return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        size, o_cin, o_res, o_e2 = [int(v) for v in subprocess.check_output([exe]).split()]
+    assert ctypes.sizeof(ConvDesc) == size
+    assert ConvDesc.cin.offset == o_cin and ConvDesc.residual.offset == o_res and ConvDesc.epi2_scale.offset == o_e2
+
+
+def test_no_cpu_path_in_product():
+    from pasco_amd.me import backend
+    backend.register_checker_backend(None)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        backend.backend_for(torch.device("cpu"))
+    import pasco_amd.me as ME
+    with pytest.raises(RuntimeError):
+        ME.SparseTensor(torch.zeros(2, 3), torch.zeros(2, 4, dtype=torch.int32))

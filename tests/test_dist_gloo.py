@@ -1,0 +1,59 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise scene sharding, the max-over-ranks timing
+contract of bench.py and the variable-size all-gather of per-voxel logits (config C4)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pasco_amd.graph.dist import allgather_voxel_logits, shard_indices, timed_steps
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        n = 50 + 37 * rank                       # subnets keep different numbers of voxels
+        feats = torch.randn(n, 20, generator=g)
+        coords = torch.randint(0, 256, (n, 4), generator=g).int()
+        fs, cs = allgather_voxel_logits(feats, coords)
+        ok = len(fs) == world
+        for r in range(world):
+            gr = torch.Generator().manual_seed(100 + r)
+            ef = torch.randn(50 + 37 * r, 20, generator=gr)
+            ec = torch.randint(0, 256, (50 + 37 * r, 4), generator=gr).int()
+            ok = ok and torch.equal(fs[r], ef) and torch.equal(cs[r], ec)
+        # timing contract: the slow rank sets the time for everybody
+        import time
+        elapsed = timed_steps(lambda: time.sleep(0.01 * (1 + 3 * rank)), steps=3, warmup=1)
+        mine = shard_indices(7, rank, world)
+        q.put((rank, ok, elapsed, mine))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), "all-gather of voxel logits"
+    e0, e1 = res[0][2], res[1][2]
+    assert abs(e0 - e1) < 1e-9 and e0 >= 3 * 0.04 * 0.9, "max over ranks"
+    assert res[0][3] == [0, 2, 4, 6] and res[1][3] == [1, 3, 5]

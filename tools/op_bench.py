@@ -38,7 +38,7 @@ def main():
     g1 = np.argwhere(occ)
     res = []
     levels = {}
-    for s, c in ((1, 64), (2, 128), (4, 256)):
+    for s, c in ((1, 64), (2, 128), (4, 256), (8, 256)):
         cs = np.unique(np.floor_divide(g1, s) * s, axis=0)
         coords = torch.from_numpy(np.concatenate([np.zeros((cs.shape[0], 1), np.int64), cs], 1)).int().cuda()
         levels[s] = (coords, c)
@@ -48,6 +48,17 @@ def main():
     for name, (coords, c) in levels.items():
         n = coords.shape[0]
         ts = 4 if name == "U4" else name
+        cfg_times = {}
+        if len(sys.argv) > 2 and sys.argv[2] == "cfgs":
+            tk0, tv0, _, _, _ = be.map_insert(coords, dedup=False)
+            nbr0 = be.nbr_build(coords, tk0, tv0, kernel_offsets(3, ts))
+            x0 = torch.randn(n, c, device="cuda")
+            w0 = torch.randn(27, c, c, device="cuda") / np.sqrt(27 * c)
+            o0 = torch.empty(n, c, device="cuda")
+            for cfg in ("128,32", "128,64", "64,32", "64,64", "32,32", "32,64"):
+                os.environ["PASCO_CONV_CFG"] = cfg
+                cfg_times[cfg] = round(timeit(lambda: be.conv_fwd(x0, w0, nbr0, n, out=o0), iters=10) * 1e6, 1)
+            os.environ.pop("PASCO_CONV_CFG", None)
         t_ins = timeit(lambda: be.map_insert(coords, dedup=False))
         t_ins_d = timeit(lambda: be.map_insert(coords, dedup=True))
         tk, tv, _, _, _ = be.map_insert(coords, dedup=False)
@@ -68,7 +79,7 @@ def main():
         b_min = 4.0 * n * c + 4.0 * n * c + 8.0 * P + 4.0 * 27 * c * c
         w1 = torch.randn(c, c, device="cuda")
         t_k1 = timeit(lambda: be.conv_fwd(x, w1, None, n, out=out))
-        r = dict(level=str(name), n=n, c=c, pairs=P, pairs_per_voxel=P / n,
+        r = dict(level=str(name), n=n, c=c, cfg_us=cfg_times, pairs=P, pairs_per_voxel=P / n,
                  t_insert_us=t_ins * 1e6, t_insert_dedup_us=t_ins_d * 1e6, t_nbr_us=t_nbr * 1e6,
                  nbr_GBs=(16.0 * 2 * n + 8.0 * P) / t_nbr / 1e9,
                  t_conv3_us=t_conv * 1e6, t_conv3_fused_us=t_conv_f * 1e6,

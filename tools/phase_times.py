@@ -1,0 +1,46 @@
+"""Wall-clock breakdown of one bench step by phase (synchronising; diagnostic only)."""
+import os, sys, time, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from pasco_amd.graph.synth import make_scene, TeacherKeep
+from pasco_amd.graph import decoder as D, unet as U, transformer as T
+
+dev = torch.device("cuda", 0)
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+net = bench.build_net(M, 283, dev)
+scene = make_scene(0, n_infers=M).to(dev)
+tk = TeacherKeep(scene, dev)
+times = {}
+
+def timed(name, fn):
+    def w(*a, **k):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        r = fn(*a, **k)
+        torch.cuda.synchronize(); times[name] = times.get(name, 0.0) + time.perf_counter() - t
+        return r
+    return w
+
+u = net.unet3d
+net.prepare_input = timed("prepare_input(pointMLP+merge)", net.prepare_input)
+u.encoder.forward = timed("encoder", u.encoder.forward)
+u.dense_bottleneck = timed("bottleneck", u.dense_bottleneck)
+for i, b in enumerate(u.decoder_generative.dec_blocks):
+    b.forward = timed(f"dec_block{i}", b.forward)
+u.decoder_generative.predict_panop = timed("predict_panop(total)", u.decoder_generative.predict_panop)
+net.transformer_predictor.forward = timed("  transformer", net.transformer_predictor.forward)
+tp = net.transformer_predictor
+tp.compute_allow = timed("    attn_mask", tp.compute_allow)
+for i, l in enumerate(tp.transformer_cross_attention_layers):
+    l.forward = timed(f"    xattn{i}", l.forward)
+tp.pred_heads = timed("    pred_heads", tp.pred_heads)
+with torch.no_grad():
+    for _ in range(2):
+        bench.run_scene(net, scene, tk)
+    times.clear()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3):
+        bench.run_scene(net, scene, tk)
+    torch.cuda.synchronize(); tot = (time.perf_counter() - t0) / 3
+print(json.dumps({k: round(v / 3 * 1e3, 2) for k, v in times.items()}, indent=1))
+print("total ms/step (with sync overhead):", round(tot * 1e3, 2))
