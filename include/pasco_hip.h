@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define PH_ABI_VERSION 1
-#define PH_MAX_KVOL 64 /* largest kernel volume served (4x4x4 max-pool window) */
+#define PH_MAX_KVOL 64 /* largest kernel volume of one nbr_build / pooling call (4x4x4 window); conv_fwd takes tables of up to 4096 offsets (dense bottleneck: 7x7x5 = 245) */
 
 /* activation codes for fused prologue / epilogue */
 #define PH_ACT_NONE 0

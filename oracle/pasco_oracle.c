@@ -204,7 +204,7 @@ static float act_apply(float v, int act, float slope) {
 int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   (void)stream;
   if (!d) return fail("conv_fwd: null desc");
-  if (d->cin <= 0 || d->cout <= 0 || d->kvol < 1 || d->kvol > PH_MAX_KVOL) return fail("conv_fwd: bad shape");
+  if (d->cin <= 0 || d->cout <= 0 || d->kvol < 1 || d->kvol > 4096) return fail("conv_fwd: bad shape");
   if (d->n_out == 0) return 0;
   if (!d->nbr && !(d->kvol == 1 && d->n_in == d->n_out)) return fail("conv_fwd: identity map needs kvol == 1");
   const int cin = d->cin, cout = d->cout;

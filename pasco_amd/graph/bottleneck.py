@@ -3,13 +3,21 @@ pasco/models/unet3d_sparse_v2.py:182-214).
 
 Eleven dense 3-D convolutions (256 -> 256, kernels (3,3,1) (5,5,3) (7,7,5) and 1x1x1) on the
 stride-8 grid (32 x 32 x 4 for a 256 x 256 x 32 scene), each followed by BatchNorm3d + ReLU.  This is
-genuinely dense GEMM work; round 1 runs it through torch.nn.Conv3d (MIOpen) - see DESIGN.md.
+genuinely dense GEMM work.  `forward` is the plain torch formulation (reference semantics, used by
+the golden tests); `forward_rows` runs the same eleven convolutions as implicit GEMMs on the
+hand-written MFMA convolution kernel: the grid is a sparse tensor whose every site is active, the
+(7,7,5) / (5,5,3) / (3,3,1) kernels are neighbour tables of 245 / 75 / 9 offsets (cached per grid
+shape), BN + ReLU ride in the epilogue, features stay channels-last [sites, 256].
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from ..me.backend import ACT_RELU, MAX_KVOL, backend_for
+from ..me.core import kernel_offsets
+from .fused import fold_bn
 
 
 def _conv(c, k):
@@ -49,4 +57,70 @@ class SPCDense3Dv2(nn.Module):
         y1 = self._cbr(self.res_1, self.bn_res_1, x)
         y2 = self._cbr(self.res_2, self.bn_res_2, x)
         y3 = self._cbr(self.res_3, self.bn_res_3, x)
+        return x1 + y0 + y1 + y2 + y3
+
+
+    # ---- implicit-GEMM path on the sparse-conv kernel ---------------------------------------------------
+    _KERNELS = {"a_conv1": (3, 3, 1), "a_conv2": (3, 3, 1), "a_conv3": (5, 5, 3), "a_conv4": (7, 7, 5),
+                "a_conv5": (3, 3, 1), "a_conv6": (5, 5, 3), "a_conv7": (7, 7, 5), "ch_conv1": (1, 1, 1),
+                "res_1": (3, 3, 1), "res_2": (5, 5, 3), "res_3": (7, 7, 5)}
+    _BNS = {"a_conv1": "bn_1", "a_conv2": "bn_2", "a_conv3": "bn_3", "a_conv4": "bn_4", "a_conv5": "bn_5",
+            "a_conv6": "bn_6", "a_conv7": "bn_7", "ch_conv1": "bn_ch_conv1", "res_1": "bn_res_1",
+            "res_2": "bn_res_2", "res_3": "bn_res_3"}
+
+    def _row_weight(self, name):
+        """Conv3d weight [Cout, Cin, kx, ky, kz] -> [K, Cin, Cout] with K enumerated x fastest."""
+        w = getattr(self, name)[0].weight
+        hit = getattr(self, "_roww_" + name, None)
+        ver = (w._version, w.device)
+        if hit is None or hit[0] != ver:
+            k = w.shape[2] * w.shape[3] * w.shape[4]
+            rw = w.detach().permute(4, 3, 2, 1, 0).reshape(k, w.shape[1], w.shape[0]).contiguous()
+            if k == 1:
+                rw = rw.reshape(w.shape[1], w.shape[0])
+            hit = (ver, rw)
+            object.__setattr__(self, "_roww_" + name, hit)
+        return hit[1]
+
+    def _grid_tables(self, dims, device):
+        """site coordinates [B*X*Y*Z, 4] (lexicographic) + neighbour tables per kernel shape, cached."""
+        cache = self.__dict__.setdefault("_grid_cache", {})
+        key = (tuple(int(d) for d in dims), str(device))
+        if key in cache:
+            return cache[key]
+        b, x, y, z = key[0]
+        be = backend_for(device)
+        ax = [torch.arange(n, dtype=torch.int32, device=device) for n in (b, x, y, z)]
+        coords = torch.stack(torch.meshgrid(*ax, indexing="ij"), dim=-1).reshape(-1, 4).contiguous()
+        tk, tv, _, _, _ = be.map_insert(coords, dedup=False)
+        tables = {}
+        for ks in {(3, 3, 1), (5, 5, 3), (7, 7, 5)}:
+            offs = kernel_offsets(ks, 1)
+            parts = [be.nbr_build(coords, tk, tv, offs[i:i + MAX_KVOL]) for i in range(0, len(offs), MAX_KVOL)]
+            tables[ks] = torch.cat(parts, dim=0).contiguous()
+        cache[key] = (coords, tables)
+        return cache[key]
+
+    def forward_rows(self, rows: torch.Tensor, dims) -> torch.Tensor:
+        """rows [B*X*Y*Z, C] channels-last features of the dense grid (zeros at empty sites), sites in
+        lexicographic (b,x,y,z) order -> same layout after the block.  dims = (B, X, Y, Z)."""
+        assert not self.training, "inference only"
+        be = backend_for(rows.device)
+        _, tables = self._grid_tables(dims, rows.device)
+        n = rows.shape[0]
+
+        def cbr(name, x):
+            ks = self._KERNELS[name]
+            scale, shift = fold_bn(getattr(self, self._BNS[name]))
+            return be.conv_fwd(x, self._row_weight(name), tables.get(ks), n, epi_scale=scale, epi_shift=shift,
+                               epi_act=ACT_RELU)
+
+        x = rows.contiguous()
+        x1 = cbr("a_conv1", x)
+        x2, x3, x4 = cbr("a_conv2", x1), cbr("a_conv3", x1), cbr("a_conv4", x1)
+        t1 = x2 + x3 + x4
+        x5, x6, x7 = cbr("a_conv5", t1), cbr("a_conv6", t1), cbr("a_conv7", t1)
+        s = x1 + t1 + x5 + x6 + x7
+        y0 = cbr("ch_conv1", s)
+        y1, y2, y3 = cbr("res_1", x), cbr("res_2", x), cbr("res_3", x)
         return x1 + y0 + y1 + y2 + y3

@@ -94,13 +94,28 @@ class UNet3DV2(nn.Module):
         max_c = deepest.C[:, 1:].max(dim=0)[0].to(torch.int32)
         gmax = torch.max(global_max_coords.to(deepest.device).to(torch.int32), max_c)
         size = (compute_scene_size(gmin, gmax, scale) // scale).tolist()
-        shape = torch.Size((bs, deepest.shape[1], *size))
-        dense = deepest.dense(shape, min_coordinate=torch.IntTensor(gmin.tolist()))[0]
-        dense = self.dense3d(dense)
-        t = ME.to_sparse(dense)
-        coords = t.C.clone()
+        # channels-last rows of the dense grid (sites in lexicographic order = ME.to_sparse order);
+        # the reference goes sparse -> dense [1,C,X,Y,Z] -> Conv3d stack -> ME.to_sparse, this is the
+        # same computation without leaving the row layout.
+        dims = (bs, *[int(v) for v in size])
+        nsites = dims[0] * dims[1] * dims[2] * dims[3]
+        c = deepest.F.shape[1]
+        site = torch.div(deepest.C[:, 1:].to(torch.int64) - gmin.to(torch.int64).reshape(1, 3), scale,
+                         rounding_mode="floor")
+        inside = ((site >= 0) & (site < torch.tensor(dims[1:], device=site.device))).all(dim=1)
+        lin = ((deepest.C[:, 0].to(torch.int64) * dims[1] + site[:, 0]) * dims[2] + site[:, 1]) * dims[3] + site[:, 2]
+        rows = deepest.F.new_zeros((nsites, c))
+        rows[lin[inside]] = deepest.F[inside]
+        dense3d, dropout = self.dense3d[0], self.dense3d[1]
+        assert not dropout.training
+        out = dense3d.forward_rows(rows, dims)
+        site_coords, _ = dense3d._grid_tables(dims, out.device)
+        nz = (out != 0).any(dim=1)                     # ME.to_sparse drops all-zero sites
+        if not bool(nz.all()):
+            out, site_coords = out[nz].contiguous(), site_coords[nz]
+        coords = site_coords.clone()
         coords[:, 1:] = coords[:, 1:] * scale + gmin.reshape(1, -1).to(coords.dtype)
-        return ME.SparseTensor(features=t.F, coordinates=coords, tensor_stride=scale,
+        return ME.SparseTensor(features=out, coordinates=coords, tensor_stride=scale,
                                coordinate_manager=deepest.coordinate_manager)
 
     def forward(self, in_feat, bs, global_min_coords, global_max_coords, min_Cs, max_Cs,
