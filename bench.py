@@ -31,6 +31,19 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (matrix) = vecto
 HBM_PEAK_GBS = 8000.0
 
 
+def pmc_traffic():
+    """HBM bytes per k_conv_mfma launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r1_pmc_conv.json, produced by tools/pmc_summary.py; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md).  PMC counters cannot be collected from inside the process, so this is a
+    recorded measurement, or null when none is committed."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_conv.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def build_net(n_infers, in_channels, device, heavy=False):
     from pasco_amd.graph import PascoNet
     torch.manual_seed(1234)
@@ -161,21 +174,23 @@ def main():
                        "pruning": "teacher-forced", "parallelism": f"scene-parallel x{world}, no collective"},
         }
         if not args.no_profile:
-            s = prof.summary(27)
+            s = prof.summary()
             if s["launches"]:
                 avg = s["time_s"] / s["launches"]
                 tf = s["flops"] / s["time_s"] / 1e12
                 res["roofline"] = {
-                    "kernel": "k_conv_mfma (k=3 sparse conv, fp32 MFMA 32x32x2)", "bound": "mfma",
-                    "achieved": round(tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "k_conv_mfma (sparse conv / implicit GEMM, fp32 MFMA 32x32x2; every launch of the step)",
+                    "bound": "mfma", "achieved": round(tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
                     "launches_per_step": s["launches"] / args.steps, "avg_launch_us": round(avg * 1e6, 2),
                     "flops_per_launch": s["flops"] / s["launches"],
                     "alg_bytes_per_launch": s["bytes_alg"] / s["launches"],
                     "alg_GBps": round(s["bytes_alg"] / s["time_s"] / 1e9, 1),
                     "alg_frac_of_hbm_peak": round(s["bytes_alg"] / s["time_s"] / 1e9 / HBM_PEAK_GBS, 4),
-                    "k3_conv_ms_per_step": round(s["time_s"] / args.steps * 1e3, 3),
-                    "all_conv_ms_per_step": round(s["all_conv_time_s"] / args.steps * 1e3, 3),
+                    "conv_ms_per_step": round(s["time_s"] / args.steps * 1e3, 3),
+                    "k3_only": {"launches_per_step": s["k3_launches"] / args.steps,
+                                "TFLOPs": round(s["k3_flops"] / max(s["k3_time_s"], 1e-12) / 1e12, 3),
+                                "ms_per_step": round(s["k3_time_s"] / args.steps * 1e3, 3)},
                 }
         if not args.no_cpu_baseline and world == 1:
             try:

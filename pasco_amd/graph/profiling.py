@@ -40,29 +40,37 @@ class ConvProfiler:
         backend.conv_fwd = conv_fwd
         backend._conv_profiled = True
 
-    def summary(self, kvol_filter=27):
-        """Aggregate over the recorded launches with kernel volume `kvol_filter` (k=3 convs, the
-        dominant kernel): average duration, algorithmic flops / bytes per launch."""
+    def summary(self):
+        """Aggregate over every recorded `k_conv_mfma` launch (k=3 / k=2 strided / generative transposed /
+        k=1 convolutions and the dense bottleneck's implicit GEMMs): average duration, algorithmic
+        flops / bytes per launch (flops = 2 P Cin Cout, B_alg = 4 P Cin + 4 N_out Cout
+        + 8 P + 4 K Cin Cout, with P = pairs of the neighbour table, P = N for identity maps)."""
         torch.cuda.synchronize()
         pair_cache = {}
         t = flops = b_alg = b_min = 0.0
-        n = 0
-        t_all = 0.0
+        t_k3 = f_k3 = 0.0
+        n_k3 = 0
         for r in self.records:
             dt = r["e0"].elapsed_time(r["e1"]) * 1e-3
-            t_all += dt
-            if r["kvol"] != kvol_filter:
-                continue
             nbr = r["nbr"]
-            key = nbr.data_ptr()
-            if key not in pair_cache:
-                pair_cache[key] = int((nbr >= 0).sum().item())
-            P = pair_cache[key]
+            if nbr is None:
+                P = r["n_out"]
+                idx_bytes = 0.0
+            else:
+                key = nbr.data_ptr()
+                if key not in pair_cache:
+                    pair_cache[key] = int((nbr >= 0).sum().item())
+                P = pair_cache[key]
+                idx_bytes = 8.0 * P
             cin, cout, n_out, n_in = r["cin"], r["cout"], r["n_out"], r["n_in"]
-            flops += 2.0 * P * cin * cout
-            b_alg += 4.0 * P * cin + 4.0 * n_out * cout + 8.0 * P + 4.0 * r["kvol"] * cin * cout
-            b_min += 4.0 * n_in * cin + 4.0 * n_out * cout + 8.0 * P + 4.0 * r["kvol"] * cin * cout
+            fl = 2.0 * P * cin * cout
+            flops += fl
+            b_alg += 4.0 * P * cin + 4.0 * n_out * cout + idx_bytes + 4.0 * r["kvol"] * cin * cout
+            b_min += 4.0 * min(n_in, P) * cin + 4.0 * n_out * cout + idx_bytes + 4.0 * r["kvol"] * cin * cout
             t += dt
-            n += 1
-        return dict(launches=n, time_s=t, flops=flops, bytes_alg=b_alg, bytes_min=b_min,
-                    all_conv_launches=len(self.records), all_conv_time_s=t_all)
+            if r["kvol"] == 27:
+                t_k3 += dt
+                f_k3 += fl
+                n_k3 += 1
+        return dict(launches=len(self.records), time_s=t, flops=flops, bytes_alg=b_alg, bytes_min=b_min,
+                    k3_launches=n_k3, k3_time_s=t_k3, k3_flops=f_k3)

@@ -35,7 +35,7 @@ def test_attn_cross_matches_torch(hip, B, H, Q, N, masked):
         allow = torch.rand(B, N, Q, generator=g) > 0.7
         allow[:, :, 3] = False                                  # a query with nothing allowed
         if N > 20:
-            allow[0, : N // 2, 5] = False
+            allow[0, : N // 2, Q - 1] = False
         allow = allow.cuda()
         bits, any_ = hip.attn_mask_pack(allow.reshape(B * N, Q).float().contiguous(), B, N)
     got = hip.attn_cross_fwd(q, k, v, bits, any_)
