@@ -40,6 +40,8 @@ struct ConvArgs {
   int epi_act, res_act;
   float slope;
   int n_row_tiles, n_col_tiles;
+  const int32_t *perm;
+  const uint32_t *gmask;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
@@ -87,7 +89,32 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
 
   const int cin = a.cin, cout = a.cout;
   const int nchunks = (cin + BKC - 1) / BKC;
-  const int nstages = a.kvol * nchunks;
+
+  // offset compaction: which kernel offsets does this tile (kmask_blk) / each of this wave's
+  // 32-row MFMA tiles (mymask) have at all?  Without a schedule every offset is walked.
+  const bool sched = a.gmask != nullptr;
+  uint32_t kmask_blk = ~0u;
+  uint32_t mymask[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) mymask[i] = ~0u;
+  if (sched) {
+    kmask_blk = 0u;
+    const int64_t g0 = m0 >> 5;
+    const int64_t ngroups = (a.n_out + 31) >> 5;
+#pragma unroll
+    for (int g = 0; g < BM / 32; ++g)
+      if (g0 + g < ngroups) kmask_blk |= a.gmask[g0 + g];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int64_t gi = g0 + wm * TM + i;
+      mymask[i] = gi < ngroups ? a.gmask[gi] : 0u;
+    }
+  }
+  auto next_k = [&](int k) -> int {  // next active offset after k, or kvol
+    if (!sched) return k + 1;
+    const uint32_t rest = (k + 1 < 32) ? (kmask_blk >> (k + 1)) : 0u;
+    return rest ? k + 1 + __builtin_ctz(rest) : a.kvol;
+  };
 
   const int a_c4 = tid % A_TPR;
   const int a_r0 = tid / A_TPR;
@@ -204,7 +231,15 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
     }
   };
 
-  auto compute_stage = [&]() {
+  auto compute_stage = [&](int kcur) {
+    bool on[TM];
+    bool any_on = false;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      on[i] = !sched || ((mymask[i] >> kcur) & 1u);
+      any_on |= on[i];
+    }
+    if (!any_on) return;
 #pragma unroll
     for (int k8 = 0; k8 < BKC / 8; ++k8) {
       float4 av[TM];
@@ -221,6 +256,7 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
           bv[j] = Bs[(k8 * 8 + h * 4 + s) * B_LD + (wn * TN + j) * 32 + l31];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+          if (!on[i]) continue;
           const float aval = (s == 0) ? av[i].x : (s == 1) ? av[i].y : (s == 2) ? av[i].z : av[i].w;
 #pragma unroll
           for (int j = 0; j < TN; ++j)
@@ -237,27 +273,39 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
     return v;
   };
 
-  load_idx(0, idx_cur);
-  if (a.kvol > 1) load_idx(1, idx_nxt);
-  load_stage(0, 0);
-  unsigned valid = valid_bits();
-  int k = 0, chunk = 0;
-  for (int s = 0; s < nstages; ++s) {
-    store_stage(valid);
-    __syncthreads();
-    if (s + 1 < nstages) {
-      if (++chunk == nchunks) {
-        chunk = 0;
-        ++k;
-#pragma unroll
-        for (int p = 0; p < A_PASSES; ++p) idx_cur[p] = idx_nxt[p];
-        if (k + 1 < a.kvol) load_idx(k + 1, idx_nxt);
+  int k = sched ? (kmask_blk ? __builtin_ctz(kmask_blk) : a.kvol) : 0;
+  if (k < a.kvol) {
+    int kn = next_k(k);
+    load_idx(k, idx_cur);
+    if (kn < a.kvol) load_idx(kn, idx_nxt);
+    load_stage(k, 0);
+    unsigned valid = valid_bits();
+    int chunk = 0;
+    for (;;) {
+      store_stage(valid);
+      __syncthreads();
+      int k2 = k, c2 = chunk + 1;
+      if (c2 == nchunks) {
+        c2 = 0;
+        k2 = kn;
       }
-      load_stage(k, chunk * BKC);
-      valid = valid_bits();
+      const bool more = k2 < a.kvol;
+      if (more) {
+        if (c2 == 0) {
+#pragma unroll
+          for (int p = 0; p < A_PASSES; ++p) idx_cur[p] = idx_nxt[p];
+          kn = next_k(k2);
+          if (kn < a.kvol) load_idx(kn, idx_nxt);
+        }
+        load_stage(k2, c2 * BKC);
+        valid = valid_bits();
+      }
+      compute_stage(k);
+      __syncthreads();
+      if (!more) break;
+      k = k2;
+      chunk = c2;
     }
-    compute_stage();
-    __syncthreads();
   }
 
   // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -275,8 +323,9 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row >= a.n_out) continue;
+        const int64_t srow = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (srow >= a.n_out) continue;
+        const int64_t row = a.perm ? (int64_t)a.perm[srow] : srow;
         float v = acc[i][j][r] + bias;
         v = act_apply(v * es + eb, a.epi_act, a.slope);
         if (tail) {
@@ -362,6 +411,10 @@ extern "C" int ph_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   a.res_act = d->res_act;
   a.slope = d->epi_slope;
   a.n_row_tiles = a.n_col_tiles = 0;
+  a.perm = d->perm;
+  a.gmask = d->gmask;
+  PH_REQUIRE((d->perm == nullptr) == (d->gmask == nullptr), "conv_fwd: perm and gmask come together");
+  PH_REQUIRE(d->gmask == nullptr || (d->kvol <= 32 && d->nbr != nullptr), "conv_fwd: schedule needs kvol <= 32");
   hipStream_t st = ph_stream(stream);
   int bm = 128;
   const int bn = pick_cfg(a, &bm);
