@@ -213,7 +213,7 @@ class CoordinateManager:
             self._kmap_cache[ck] = nbr
         return nbr
 
-    SCHED_MIN_ROWS = 8192
+    SCHED_MIN_ROWS = int(__import__('os').environ.get('PASCO_SCHED_MIN_ROWS', str(1 << 40)))   # off by default: no net gain on PaSCo's maps (profiles/README.md)
 
     def schedule(self, nbr: Optional[torch.Tensor]):
         """Offset-compaction schedule (perm, nbr_s, gmask) of a cached neighbour table, or None when
