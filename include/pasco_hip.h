@@ -102,14 +102,6 @@ int PH_FN(kmap_compact)(const int32_t *nbr, int32_t kvol, int64_t n_out, int32_t
                         int32_t *pairs_out, int32_t *counts, void *ws, int64_t ws_bytes,
                         ph_stream_t stream);
 
-/* Offset compaction for kernel volumes <= 32 (the k=3 maps of mink.py:625-638): a walk order `perm`
- * (rows sorted by their offset mask inside chunks of 4096 rows), the neighbour table in that order
- * (nbr_s[k][j] = nbr[k][perm[j]]) and per-32-row-group offset masks, so that conv_fwd only issues
- * the offsets a group actually has.  Results of conv_fwd are unchanged.  ws: 4*n_out bytes. */
-int PH_FN(kmap_schedule)(const int32_t *nbr, int32_t kvol, int64_t n_out, int32_t *perm,
-                         int32_t *nbr_s, uint32_t *gmask, void *ws, int64_t ws_bytes,
-                         ph_stream_t stream);
-
 /* ---------------------------------------------------------------------------------------------
  * Sparse convolution forward (MinkowskiConvolution k=3 mink.py:625-638, decoder_v3.py:267-282;
  * k=2,s=2 mink.py:509-511; transposed k=2,s=2 mink.py:524-527; k=1 encoder_v2.py:109-111,
@@ -147,10 +139,6 @@ typedef struct ph_conv_desc {
   int32_t reserved;
   const float *epi2_scale; /* [cout] second per-channel affine, applied after epi_act */
   const float *epi2_shift; /* [cout] */
-  /* optional schedule from kmap_schedule (all three or none): `nbr` is then the SCHEDULED table,
-   * schedule row j computes output row perm[j]; gmask[j/32] = offsets used by rows 32*(j/32).. */
-  const int32_t *perm;    /* [n_out] */
-  const uint32_t *gmask;  /* [ceil(n_out/32)] */
 } ph_conv_desc;
 
 int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);

@@ -224,7 +224,7 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
       for (int k = 0; k < d->kvol; ++k) {
         const float *wk = d->weight + (int64_t)k * cin * cout;
         for (int r = 0; r < rows; ++r) {
-          const int64_t o = o0 + r;   /* schedule position when d->perm is given */
+          const int64_t o = o0 + r;
           const int idx = d->nbr ? d->nbr[(int64_t)k * n_out + o] : (int)o;
           if (idx < 0) continue;
           const float *src = d->in + (int64_t)idx * cin;
@@ -245,7 +245,7 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
         }
       }
       for (int r = 0; r < rows; ++r) {
-        const int64_t o = d->perm ? d->perm[o0 + r] : o0 + r;
+        const int64_t o = o0 + r;
         for (int n = 0; n < cout; ++n) {
           float v = acc[(int64_t)r * cout + n] + (d->bias ? d->bias[n] : 0.f);
           v = v * (d->epi_scale ? d->epi_scale[n] : 1.f) + (d->epi_shift ? d->epi_shift[n] : 0.f);
@@ -446,39 +446,3 @@ int pho_attn_cross_fwd(const float *q, const float *k, const float *v, const uin
   return 0;
 }
 
-/* Offset-compaction schedule (see include/pasco_hip.h): rows sorted by their offset mask, ties by row,
- * inside chunks of 4096 consecutive rows. */
-typedef struct { uint32_t mask; int32_t idx; } sched_key;
-static int sched_cmp(const void *a, const void *b) {
-  const sched_key *x = (const sched_key *)a, *y = (const sched_key *)b;
-  if (x->mask != y->mask) return x->mask < y->mask ? -1 : 1;
-  return x->idx < y->idx ? -1 : (x->idx > y->idx);
-}
-
-int pho_kmap_schedule(const int32_t *nbr, int32_t kvol, int64_t n_out, int32_t *perm, int32_t *nbr_s,
-                      uint32_t *gmask, void *ws, int64_t ws_bytes, ph_stream_t stream) {
-  (void)ws; (void)ws_bytes; (void)stream;
-  if (kvol < 1 || kvol > 32) return fail("kmap_schedule: kernel volume not served");
-  enum { CHUNK = 4096 };
-  sched_key *keys = (sched_key *)malloc(sizeof(sched_key) * CHUNK);
-  uint32_t *mask = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n_out ? n_out : 1));
-  for (int64_t o = 0; o < n_out; ++o) {
-    uint32_t m = 0;
-    for (int k = 0; k < kvol; ++k) m |= (nbr[(int64_t)k * n_out + o] >= 0 ? 1u : 0u) << k;
-    mask[o] = m;
-  }
-  for (int64_t base = 0; base < n_out; base += CHUNK) {
-    int cnt = (int)((n_out - base) < CHUNK ? (n_out - base) : CHUNK);
-    for (int i = 0; i < cnt; ++i) { keys[i].mask = mask[base + i]; keys[i].idx = i; }
-    qsort(keys, (size_t)cnt, sizeof(sched_key), sched_cmp);
-    for (int i = 0; i < cnt; ++i) perm[base + i] = (int32_t)(base + keys[i].idx);
-  }
-  for (int64_t j = 0; j < n_out; ++j) {
-    for (int k = 0; k < kvol; ++k) nbr_s[(int64_t)k * n_out + j] = nbr[(int64_t)k * n_out + perm[j]];
-    if ((j & 31) == 0) gmask[j >> 5] = 0;
-    gmask[j >> 5] |= mask[perm[j]];
-  }
-  free(keys);
-  free(mask);
-  return 0;
-}

@@ -371,92 +371,3 @@ extern "C" int ph_kmap_compact(const int32_t *nbr, int32_t kvol, int64_t n_out, 
                      counts, ws, ws_bytes, ph_stream(stream));
 }
 
-// ---- kernel-map schedule: offset compaction -----------------------------------------------------
-// A k=3 map touches on average only ~15 of its 27 offsets per voxel; processed in map order, a tile
-// of 32 rows nevertheless needs (almost) all 27, because neighbouring rows miss different offsets.
-// The schedule reorders the ROWS OF A TILE WALK (not the tensor): inside chunks of 4096 consecutive
-// rows (so the gathers stay L2-local) rows are sorted by their 27-bit offset mask, which makes the
-// rows of a 32-row group agree on their offsets; the conv kernel then walks only the offsets set in
-// the group masks (wave ballot of the per-row masks = `gmask`).  Measured on S10: 26.9 -> 18.9
-// offsets issued per row at 15.4 useful.
-constexpr int SCH_CHUNK = 4096;
-
-__global__ void __launch_bounds__(256)
-    k_row_masks(const int32_t *__restrict__ nbr, int kvol, int64_t n_out, uint32_t *__restrict__ mask) {
-  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= n_out) return;
-  uint32_t m = 0;
-  for (int k = 0; k < kvol; ++k) m |= (nbr[(int64_t)k * n_out + o] >= 0 ? 1u : 0u) << k;
-  mask[o] = m;
-}
-
-// one workgroup sorts one chunk: key = mask << 32 | local index (unique keys -> deterministic)
-__global__ void __launch_bounds__(256)
-    k_chunk_sort(const uint32_t *__restrict__ mask, int64_t n_out, int32_t *__restrict__ perm) {
-  __shared__ unsigned long long keys[SCH_CHUNK];
-  const int64_t base = (int64_t)blockIdx.x * SCH_CHUNK;
-  for (int i = threadIdx.x; i < SCH_CHUNK; i += 256) {
-    const int64_t o = base + i;
-    keys[i] = o < n_out ? (((unsigned long long)mask[o] << 32) | (unsigned)i) : ~0ull;
-  }
-  __syncthreads();
-  for (int size = 2; size <= SCH_CHUNK; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = threadIdx.x; t < SCH_CHUNK / 2; t += 256) {
-        const int lo = 2 * t - (t & (stride - 1));   // index with the `stride` bit cleared
-        const int hi = lo + stride;
-        const bool up = ((lo & size) == 0);
-        const unsigned long long a = keys[lo], b = keys[hi];
-        if ((a > b) == up) {
-          keys[lo] = b;
-          keys[hi] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = threadIdx.x; i < SCH_CHUNK; i += 256) {
-    const int64_t j = base + i;
-    if (j < n_out) perm[j] = (int32_t)(base + (int64_t)(keys[i] & 0xFFFFFFFFull));
-  }
-}
-
-__global__ void __launch_bounds__(256)
-    k_apply_sched(const int32_t *__restrict__ nbr, int kvol, int64_t n_out, const int32_t *__restrict__ perm,
-                  int32_t *__restrict__ nbr_s) {
-  const int k = blockIdx.y;
-  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_out) return;
-  nbr_s[(int64_t)k * n_out + j] = nbr[(int64_t)k * n_out + perm[j]];
-}
-
-// gmask[g] = OR of the masks of schedule rows 32g .. 32g+31 (one wave covers two groups)
-__global__ void __launch_bounds__(256)
-    k_group_masks(const uint32_t *__restrict__ mask, const int32_t *__restrict__ perm, int64_t n_out,
-                  uint32_t *__restrict__ gmask) {
-  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t m = j < n_out ? mask[perm[j]] : 0u;
-#pragma unroll
-  for (int d = 1; d < 32; d <<= 1) m |= __shfl_xor(m, d);
-  if ((threadIdx.x & 31) == 0 && j < n_out) gmask[j >> 5] = m;
-}
-
-extern "C" int ph_kmap_schedule(const int32_t *nbr, int32_t kvol, int64_t n_out, int32_t *perm,
-                                int32_t *nbr_s, uint32_t *gmask, void *ws, int64_t ws_bytes,
-                                ph_stream_t stream) {
-  PH_REQUIRE(kvol >= 1 && kvol <= 32, "kmap_schedule: kernel volume %d not served (<= 32)", kvol);
-  PH_REQUIRE(ws_bytes >= 4 * n_out, "kmap_schedule: workspace too small");
-  if (n_out == 0) return 0;
-  hipStream_t st = ph_stream(stream);
-  uint32_t *mask = (uint32_t *)ws;
-  hipLaunchKernelGGL(k_row_masks, dim3(nblk(n_out, 256)), dim3(256), 0, st, nbr, kvol, n_out, mask);
-  PH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_chunk_sort, dim3(nblk(n_out, SCH_CHUNK)), dim3(256), 0, st, mask, n_out, perm);
-  PH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_apply_sched, dim3(nblk(n_out, 256), (unsigned)kvol), dim3(256), 0, st, nbr, kvol, n_out,
-                     perm, nbr_s);
-  PH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_group_masks, dim3(nblk(n_out, 256)), dim3(256), 0, st, mask, perm, n_out, gmask);
-  PH_LAUNCH_CHECK();
-  return 0;
-}

@@ -54,8 +54,7 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     out = mgr.backend().conv_fwd(
         x.F if x.F.is_contiguous() else x.F.contiguous(), mod.kernel.detach(), nbr, n_out, bias=bias,
         pro_scale=ps, pro_shift=pb, pro_act=pro_act, epi_scale=es, epi_shift=eb, epi_act=epi_act,
-        epi2_scale=e2s, epi2_shift=e2b, residual=residual, res_act=res_act, slope=slope,
-        sched=mgr.schedule(nbr))
+        epi2_scale=e2s, epi2_shift=e2b, residual=residual, res_act=res_act, slope=slope)
     return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
 
 

@@ -37,7 +37,6 @@ class ConvDesc(C.Structure):
         ("epi_act", _i32), ("epi_slope", C.c_float),
         ("residual", _vp), ("res_act", _i32), ("reserved", _i32),
         ("epi2_scale", _vp), ("epi2_shift", _vp),
-        ("perm", _vp), ("gmask", _vp),
     ]
 
 
@@ -52,7 +51,6 @@ _SIGNATURES = {
     "coords_expand": [_vp, _i64, _i32, _vp, _vp],
     "nbr_build": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "kmap_compact": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
-    "kmap_schedule": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
     "conv_fwd": [C.POINTER(ConvDesc), _vp],
     "maxpool_fwd": [_vp, _i32, _vp, _i32, _i64, _vp, _vp],
     "mask_compact": [_vp, _i64, _vp, _vp, _vp, _i64, _vp],
@@ -222,25 +220,11 @@ class CBackend:
         self._check(rc, "kmap_compact")
         return pin, pout, counts
 
-    def kmap_schedule(self, nbr: torch.Tensor):
-        """-> (perm [N], nbr_s [K,N], gmask [ceil(N/32)]) : offset-compaction schedule of a kernel map."""
-        self._chk(nbr, torch.int32, "nbr")
-        kvol, n_out = nbr.shape
-        dev = nbr.device
-        perm = torch.empty(n_out, dtype=torch.int32, device=dev)
-        nbr_s = torch.empty_like(nbr)
-        gmask = torch.empty((n_out + 31) // 32, dtype=torch.int32, device=dev)
-        ws = self.workspace(n_out, dev)
-        rc = self.fn["kmap_schedule"](_ptr(nbr), kvol, n_out, _ptr(perm), _ptr(nbr_s), _ptr(gmask), _ptr(ws),
-                                      ws.numel(), self.stream(dev))
-        self._check(rc, "kmap_schedule")
-        return perm, nbr_s, gmask
-
     # -- convolution -------------------------------------------------------------------------------
     def conv_fwd(self, x: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tensor], n_out: int,
                  *, bias=None, pro_scale=None, pro_shift=None, pro_act=ACT_NONE, epi_scale=None,
                  epi_shift=None, epi_act=ACT_NONE, slope=0.01, residual=None, res_act=ACT_NONE,
-                 epi2_scale=None, epi2_shift=None, sched=None,
+                 epi2_scale=None, epi2_shift=None,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._chk(x, torch.float32, "in")
         self._chk(weight, torch.float32, "weight")
@@ -250,9 +234,6 @@ class CBackend:
             kvol, cin, cout = weight.shape
         if x.shape[1] != cin:
             raise ValueError(f"conv: input has {x.shape[1]} channels, kernel expects {cin}")
-        perm = gmask = None
-        if sched is not None:      # (perm, nbr_s, gmask) from kmap_schedule: walk the scheduled table
-            perm, nbr, gmask = sched
         if nbr is not None:
             self._chk(nbr, torch.int32, "nbr")
             if tuple(nbr.shape) != (kvol, n_out):
@@ -279,7 +260,6 @@ class CBackend:
             if tuple(residual.shape) != (n_out, cout):
                 raise ValueError("conv: residual shape mismatch")
         d.residual = _ptr(residual)
-        d.perm, d.gmask = _ptr(perm), _ptr(gmask)
         rc = self.fn["conv_fwd"](C.byref(d), self.stream(x.device))
         self._check(rc, "conv_fwd")
         return out

@@ -96,7 +96,6 @@ class CoordinateManager:
         self._maps: Dict[CoordinateMapKey, _CoordMap] = {}
         self._stride_cache: Dict[tuple, CoordinateMapKey] = {}
         self._kmap_cache: Dict[tuple, torch.Tensor] = {}
-        self._sched_cache: Dict[int, tuple] = {}
         self._origin: Dict[CoordinateMapKey, Tuple[CoordinateMapKey, torch.Tensor]] = {}
 
     # -- basics ------------------------------------------------------------------------------------
@@ -212,20 +211,6 @@ class CoordinateManager:
             nbr = self.backend().nbr_build(mo.coords, mi.tkeys, mi.tvals, offs)
             self._kmap_cache[ck] = nbr
         return nbr
-
-    SCHED_MIN_ROWS = int(__import__('os').environ.get('PASCO_SCHED_MIN_ROWS', str(1 << 40)))   # off by default: no net gain on PaSCo's maps (profiles/README.md)
-
-    def schedule(self, nbr: Optional[torch.Tensor]):
-        """Offset-compaction schedule (perm, nbr_s, gmask) of a cached neighbour table, or None when
-        it does not pay (small maps, kernel volume 1/8 where every offset is used, volumes > 32)."""
-        if nbr is None or nbr.shape[0] != 27 or nbr.shape[1] < self.SCHED_MIN_ROWS:
-            return None
-        key = id(nbr)
-        hit = self._sched_cache.get(key)
-        if hit is None or hit[0] is not nbr:
-            hit = (nbr, self.backend().kmap_schedule(nbr))
-            self._sched_cache[key] = hit
-        return hit[1]
 
     def kernel_map_coo(self, in_key, out_key, kernel_size, dilation=1, transposed=False):
         """Upstream-style COO kernel map: list over offsets of (in_rows, out_rows)."""

@@ -225,31 +225,3 @@ def test_rows_and_dense_exact(hip, oracle):
     assert torch.equal(ch.cpu(), co) and torch.equal(fh.cpu(), fo)
     assert co.shape[0] == int((f != 0).any(dim=1).sum())
 
-
-@pytest.mark.parametrize("n", [5000, 70000])
-def test_kmap_schedule_exact_and_conv_unchanged(hip, oracle, n):
-    """Offset-compaction schedule: perm / scheduled table / group masks bit-exact vs the oracle; the
-    convolution walked in schedule order (skipping absent offsets) equals the plain walk."""
-    coords = scene_coords(21, n, extent=(120, 100, 12))
-    tk_o, tv_o, c_o, _, _ = unique_map(oracle, coords)
-    tk_h, tv_h, c_h, _, _ = unique_map(hip, coords.cuda())
-    offs = kernel_offsets(3, 1)
-    nbr_o = oracle.nbr_build(c_o, tk_o, tv_o, offs)
-    nbr_h = hip.nbr_build(c_h, tk_h, tv_h, offs)
-    so, sh = oracle.kmap_schedule(nbr_o), hip.kmap_schedule(nbr_h)
-    for a, b in zip(so, sh):
-        assert torch.equal(a, b.cpu())
-    m = c_o.shape[0]
-    assert sorted(so[0].tolist()) == list(range(m))
-    g = torch.Generator().manual_seed(22)
-    for cin, cout in ((64, 64), (128, 128), (32, 20)):
-        x = torch.randn(m, cin, generator=g).cuda()
-        w = (torch.randn(27, cin, cout, generator=g) / 30).cuda()
-        res = torch.randn(m, cout, generator=g).cuda()
-        ps = (torch.rand(cin, generator=g) + 0.5).cuda()
-        kw = dict(pro_scale=ps, pro_shift=ps, pro_act=1, residual=res, res_act=1)
-        plain = hip.conv_fwd(x, w, nbr_h, m, **kw)
-        walked = hip.conv_fwd(x, w, None, m, sched=sh, **kw)
-        assert torch.allclose(plain, walked, rtol=1e-5, atol=1e-5), float((plain - walked).abs().max())
-        exp = oracle.conv_fwd(x.cpu(), w.cpu(), None, m, sched=so, **{k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
-        assert torch.allclose(walked.cpu(), exp, rtol=RTOL, atol=ATOL)

@@ -55,7 +55,7 @@ def main():
             x0 = torch.randn(n, c, device="cuda")
             w0 = torch.randn(27, c, c, device="cuda") / np.sqrt(27 * c)
             o0 = torch.empty(n, c, device="cuda")
-            for cfg in ("128,32", "128,64", "64,32", "64,64", "32,32", "32,64"):
+            for cfg in ("128", "64", "32"):
                 os.environ["PASCO_CONV_CFG"] = cfg
                 cfg_times[cfg] = round(timeit(lambda: be.conv_fwd(x0, w0, nbr0, n, out=o0), iters=10) * 1e6, 1)
             os.environ.pop("PASCO_CONV_CFG", None)
@@ -70,10 +70,6 @@ def main():
         w = torch.randn(27, c, c, device="cuda") / np.sqrt(27 * c)
         out = torch.empty(n, c, device="cuda")
         t_conv = timeit(lambda: be.conv_fwd(x, w, nbr, n, out=out), iters=10)
-        t_sched_build = timeit(lambda: be.kmap_schedule(nbr), iters=5)
-        sch = be.kmap_schedule(nbr)
-        t_conv_s = timeit(lambda: be.conv_fwd(x, w, None, n, out=out, sched=sch), iters=10)
-        issued = float(sum(bin(v & 0xFFFFFFFF).count("1") for v in sch[2].tolist())) * 32 / n
         ps = torch.rand(c, device="cuda")
         t_conv_f = timeit(lambda: be.conv_fwd(x, w, nbr, n, out=out, pro_scale=ps, pro_shift=ps, pro_act=1,
                                               epi_scale=ps, epi_shift=ps, epi_act=1, residual=x, res_act=1), iters=10)
@@ -86,8 +82,7 @@ def main():
         r = dict(level=str(name), n=n, c=c, cfg_us=cfg_times, pairs=P, pairs_per_voxel=P / n,
                  t_insert_us=t_ins * 1e6, t_insert_dedup_us=t_ins_d * 1e6, t_nbr_us=t_nbr * 1e6,
                  nbr_GBs=(16.0 * 2 * n + 8.0 * P) / t_nbr / 1e9,
-                 t_conv3_us=t_conv * 1e6, t_conv3_sched_us=t_conv_s * 1e6, t_sched_build_us=t_sched_build * 1e6,
-                 offsets_issued_per_row=issued, t_conv3_fused_us=t_conv_f * 1e6,
+                 t_conv3_us=t_conv * 1e6, t_conv3_fused_us=t_conv_f * 1e6,
                  conv3_TFLOPs=flop / t_conv / 1e12, conv3_TFLOPs_issued=flop_dense / t_conv / 1e12,
                  conv3_frac_f32_peak=flop / t_conv / F32_PEAK,
                  conv3_GBs_alg=b_alg / t_conv / 1e9, conv3_frac_hbm=b_alg / t_conv / HBM_PEAK,
