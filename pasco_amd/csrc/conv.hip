@@ -42,11 +42,11 @@ struct ConvArgs {
   int n_row_tiles, n_col_tiles;
 };
 
-__device__ __forceinline__ float act_apply(float v, int act, float slope) {
-  if (act == PH_ACT_RELU) return fmaxf(v, 0.f);
-  if (act == PH_ACT_LEAKY) return v > 0.f ? v : v * slope;
-  return v;
+// activations are evaluated branch-free as max(v,0) + neg*min(v,0): neg = 1 (none), 0 (ReLU), slope (leaky)
+__device__ __forceinline__ float act_neg_of(int act, float slope) {
+  return act == PH_ACT_RELU ? 0.f : (act == PH_ACT_LEAKY ? slope : 1.f);
 }
+__device__ __forceinline__ float act_apply(float v, float neg) { return fmaxf(v, 0.f) + neg * fminf(v, 0.f); }
 
 // Tile = BM output rows x BN output channels, BKC input channels per LDS stage.
 // WM x WN waves (4 in total), each TM x TN MFMA tiles of 32x32:  BM = WM*TM*32, BN = WN*TN*32.
@@ -86,6 +86,9 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
   const int l31 = lane & 31;
 
   const int cin = a.cin, cout = a.cout;
+  const float pro_neg = act_neg_of(a.pro_act, a.slope);
+  const float epi_neg = act_neg_of(a.epi_act, a.slope);
+  const float res_neg = act_neg_of(a.res_act, a.slope);
   const int nchunks = (cin + BKC - 1) / BKC;
   const int nstages = a.kvol * nchunks;
 
@@ -184,10 +187,10 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
     for (int p = 0; p < A_PASSES; ++p) {
       float4 v = ra[p];
       if (has_pro && ((valid >> p) & 1u)) {
-        v.x = act_apply(v.x * ps.x + pb.x, a.pro_act, a.slope);
-        v.y = act_apply(v.y * ps.y + pb.y, a.pro_act, a.slope);
-        v.z = act_apply(v.z * ps.z + pb.z, a.pro_act, a.slope);
-        v.w = act_apply(v.w * ps.w + pb.w, a.pro_act, a.slope);
+        v.x = act_apply(v.x * ps.x + pb.x, pro_neg);
+        v.y = act_apply(v.y * ps.y + pb.y, pro_neg);
+        v.z = act_apply(v.z * ps.z + pb.z, pro_neg);
+        v.w = act_apply(v.w * ps.w + pb.w, pro_neg);
         if (cbase + 0 >= cin) v.x = 0.f;  // channels beyond cin must stay zero
         if (cbase + 1 >= cin) v.y = 0.f;
         if (cbase + 2 >= cin) v.z = 0.f;
@@ -278,11 +281,11 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
         const int64_t row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row >= a.n_out) continue;
         float v = acc[i][j][r] + bias;
-        v = act_apply(v * es + eb, a.epi_act, a.slope);
+        v = act_apply(v * es + eb, epi_neg);
         if (tail) {
           v = v * es2 + eb2;
           if (a.residual) v += a.residual[row * cout + col];
-          v = act_apply(v, a.res_act, a.slope);
+          v = act_apply(v, res_neg);
         }
         a.out[row * cout + col] = v;
       }
@@ -312,7 +315,10 @@ static int launch_conv(const ConvArgs &a, hipStream_t st) {
   return 0;
 }
 
-// Tile selection (measured on MI355X, profiles/r1b_op_bench.json): 64-row tiles beat 128-row tiles
+// Tile selection (measured on MI355X, profiles/r1b_op_bench.json; two restructurings of this kernel
+// - a mask-sorted walk order with per-group offset skipping, and a double-buffered / LDS-index variant,
+// both in the git history - measured 10-20 % slower: they cost registers / LDS, hence resident
+// workgroups, and this kernel lives on thread-level parallelism; see profiles/README.md): 64-row tiles beat 128-row tiles
 // at every PaSCo layer shape (more workgroups in flight hide the gather latency better); layers
 // whose 64-row tiling cannot cover the 256 CUs twice drop to 32 rows.  PASCO_CONV_CFG="bm" overrides.
 static int pick_cfg(const ConvArgs &a, int *bm) {
