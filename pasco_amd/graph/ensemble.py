@@ -1,0 +1,172 @@
+"""Subnet ensembling on the canonical grid (reference: pasco/models/ensembler.py:20-131,159-187,
+pasco/models/transform_utils.py:60-74,95-117,160-181, pasco/models/utils.py:153-198,
+pasco/models/misc.py:46-57).
+
+The reference resamples every subnet's per-voxel outputs onto the canonical 256x256x32 grid through
+dense tensors ([20,256,256,32] per subnet for the semantic probabilities, [100,256,256,32] = 838 MB per
+subnet for the mask probabilities) and `grid_sample(nearest)`.  Restated sparsely, same results:
+
+  * the canonical voxel centres are pushed through T_i once (`project_canonical`, the reference's
+    `transform`: metres, voxel 0.2, origin (0,-25.6,-2), round) and looked up in the subnet's coordinate
+    hash map - "nearest sample with zero padding" of an integer coordinate is exactly a hash lookup;
+  * mask probabilities live on the compacted union of occupied canonical sites [U, Q] (U ~ 10 % of the
+    grid); soft-IoU matching is the same [Q,U] x [U,Q] product, the Hungarian step runs on the host
+    with scipy as in the reference (utils.py:191);
+  * `ME.to_sparse` of a dense tensor whose occupied sites are known is an order-preserving compaction.
+Dense [C,256,256,32] tensors are produced only where they are the returned format (semantic
+probabilities), as a view of channels-last rows.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+
+from .. import me as ME
+from ..me.backend import backend_for
+
+CANONICAL_SIZE = (256, 256, 32)
+RESOLUTION = 0.2
+MIN_BOUND = (0.0, -25.6, -2.0)
+
+
+def canonical_sites(size: Sequence[int], device) -> torch.Tensor:
+    """int32 [X*Y*Z, 3] voxel indices of the canonical grid, lexicographic (x, y, z)."""
+    ax = [torch.arange(n, dtype=torch.int32, device=device) for n in size]
+    return torch.stack(torch.meshgrid(*ax, indexing="ij"), dim=-1).reshape(-1, 3)
+
+
+def project_canonical(sites: torch.Tensor, T: torch.Tensor, resolution: float = RESOLUTION) -> torch.Tensor:
+    """Voxel index -> voxel centre in metres -> T -> voxel index (round half to even), fp32 like the
+    reference's `transform` (transform_utils.py:60-74).  The 4x4 product is written out with a fixed
+    operation order so that CPU and GPU give bit-identical coordinates."""
+    T = T.to(device=sites.device, dtype=torch.float32)
+    mb = torch.tensor(MIN_BOUND, dtype=torch.float32, device=sites.device)
+    # float64 until the cast, as in the reference (numpy grid is float64, min_bound float32 -> promoted)
+    p = (sites.to(torch.float64) * resolution + resolution / 2 + mb.to(torch.float64)).to(torch.float32)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    out = []
+    for r in range(3):
+        v = T[r, 0] * x + T[r, 1] * y
+        v = v + T[r, 2] * z
+        v = v + T[r, 3]
+        out.append(v)
+    q = torch.stack(out, dim=1)
+    q = (q - mb - resolution / 2) / resolution
+    return torch.round(q).to(torch.int32)
+
+
+def _lookup_rows(st: ME.SparseTensor, coords3: torch.Tensor) -> torch.Tensor:
+    """row of each (0, x, y, z) coordinate in st's coordinate map, or -1."""
+    q = torch.cat([torch.zeros((coords3.shape[0], 1), dtype=torch.int32, device=coords3.device), coords3], dim=1)
+    return st.coordinate_manager.find(st.coordinate_map_key, q.contiguous())
+
+
+class Ensembler(torch.nn.Module):
+    def __init__(self, scene_size=CANONICAL_SIZE):
+        super().__init__()
+        self.scene_size = tuple(scene_size)
+        self._sites = {}
+
+    def projected(self, T: torch.Tensor, device, cache: dict) -> torch.Tensor:
+        """canonical sites seen through T (shared by the semantic and the mask resampling of a scene)."""
+        key = id(T)
+        if key not in cache:
+            cache[key] = project_canonical(self.sites(device), T)
+        return cache[key]
+
+    def sites(self, device) -> torch.Tensor:
+        key = str(device)
+        if key not in self._sites:
+            self._sites[key] = canonical_sites(self.scene_size, device)
+        return self._sites[key]
+
+    # -- a21 -----------------------------------------------------------------------------------------
+    def ensemble_sem_compl(self, sem_logits_at_scales: Dict[int, List[ME.SparseTensor]], Ts,
+                           cache: dict = None) -> List[torch.Tensor]:
+        """-> list of [n_classes, X, Y, Z] probabilities, one per subnet + their mean (ensembler.py:159-187).
+        Sites a subnet does not cover get class-0 probability 1."""
+        logits_1 = sem_logits_at_scales[1]
+        dev = logits_1[0].device
+        cache = {} if cache is None else cache
+        X, Y, Z = self.scene_size
+        outs = []
+        for i, st in enumerate(logits_1):
+            probs = F.softmax(st.F, dim=-1)
+            rows = _lookup_rows(st, self.projected(Ts[i], dev, cache))
+            dense_rows = backend_for(dev).gather_rows(probs.contiguous(), rows)          # [XYZ, C], -1 -> 0
+            empty = dense_rows.sum(dim=1) == 0
+            dense_rows[:, 0] = torch.where(empty, torch.ones_like(dense_rows[:, 0]), dense_rows[:, 0])
+            outs.append(dense_rows)
+        outs.append(torch.stack(outs, dim=0).mean(0))
+        return [o.reshape(X, Y, Z, -1).permute(3, 0, 1, 2) for o in outs]
+
+    # -- a22 -----------------------------------------------------------------------------------------
+    @staticmethod
+    def match_queries(anchor_mask: torch.Tensor, aux_mask: torch.Tensor, iou_threshold: float):
+        """Soft-IoU Hungarian matching of query masks given as [U, Q] site rows (utils.py:153-198)."""
+        inter = anchor_mask.t() @ aux_mask                                   # [Q, Q]
+        union = anchor_mask.sum(0)[:, None] + aux_mask.sum(0)[None, :] - inter
+        iou = torch.where(union != 0, inter / union, torch.zeros_like(inter))
+        iou = iou * (iou > iou_threshold)
+        a_idx, b_idx = linear_sum_assignment((1.0 - iou).cpu().numpy())
+        a_idx = torch.as_tensor(a_idx, device=iou.device)
+        b_idx = torch.as_tensor(b_idx, device=iou.device)
+        return a_idx, b_idx, iou[a_idx, b_idx]
+
+    def ensemble_panop(self, panop_predictions, ensemble_sem_prob_denses, Ts, iou_threshold=0.2, cache: dict = None):
+        """-> one dict per subnet + the ensemble: {"sem_probs", "voxel_probs" (SparseTensors on the
+        canonical grid), "query_probs"} (ensembler.py:20-131)."""
+        n_sub = len(panop_predictions)
+        dev = panop_predictions[0]["query_logits"].device
+        be = backend_for(dev)
+        sites = self.sites(dev)
+        cache = {} if cache is None else cache
+        rows_per_subnet, probs_per_subnet, query_probs = [], [], []
+        occupied = None
+        for i in range(n_sub):
+            vl = panop_predictions[i]["voxel_logits"]
+            rows = _lookup_rows(vl, self.projected(Ts[i], dev, cache))
+            rows_per_subnet.append(rows)
+            probs_per_subnet.append(torch.sigmoid(vl.F))
+            occupied = (rows >= 0) if occupied is None else (occupied | (rows >= 0))
+            query_probs.append(F.softmax(panop_predictions[i]["query_logits"], dim=-1))
+        union_sites = be.mask_compact(occupied.contiguous())                # canonical site ids, lexicographic
+        site_coords = sites[union_sites.long()]                             # [U, 3]
+        masks = []                                                          # per subnet [U, Q] (0 where absent)
+        for i in range(n_sub):
+            r = rows_per_subnet[i][union_sites.long()].contiguous()
+            masks.append(be.gather_rows(probs_per_subnet[i].contiguous(), r))
+        anchor_q = query_probs[0].clone()
+        anchor_m = masks[0].clone()
+        ious = []
+        for i in range(1, n_sub):
+            a_idx, b_idx, iou = self.match_queries(anchor_m, masks[i], iou_threshold)
+            anchor_q[:, a_idx, :] = (anchor_q[:, a_idx, :] * i + query_probs[i][:, b_idx, :]) / (i + 1)
+            anchor_m[:, a_idx] = (anchor_m[:, a_idx] * i + masks[i][:, b_idx]) / (i + 1)
+            ious.append(iou)
+        if ious:
+            keep = torch.stack(ious, dim=0).mean(0) > iou_threshold
+            anchor_m = anchor_m[:, keep]
+            anchor_q = anchor_q[:, keep, :]
+        # zero the ensemble where the ensembled semantic class is "empty"
+        ens_class = ensemble_sem_prob_denses[-1].argmax(0).reshape(-1)[union_sites.long()]
+        anchor_m = anchor_m * (ens_class != 0).float()[:, None]
+        masks.append(anchor_m)
+        query_probs.append(anchor_q)
+        out = []
+        coords4 = torch.cat([torch.zeros((site_coords.shape[0], 1), dtype=torch.int32, device=dev), site_coords], dim=1)
+        for i, m in enumerate(masks):
+            nz = (m != 0).any(dim=1)                                          # ME.to_sparse keeps non-zero sites
+            c = coords4[nz].contiguous()
+            voxel_prob = ME.SparseTensor(m[nz].contiguous(), c)
+            sem = ensemble_sem_prob_denses[i]
+            cl = c.long()
+            sem_rows = sem[:, cl[:, 1], cl[:, 2], cl[:, 3]].t().contiguous()
+            sem_prob = ME.SparseTensor(sem_rows, coordinate_map_key=voxel_prob.coordinate_map_key,
+                                       coordinate_manager=voxel_prob.coordinate_manager)
+            out.append({"sem_probs": sem_prob, "voxel_probs": voxel_prob, "query_probs": query_probs[i]})
+        return out

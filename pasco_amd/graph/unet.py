@@ -18,7 +18,12 @@ from .. import me as ME
 from .bottleneck import SPCDense3Dv2
 from .decoder import DecoderGenerativeSepConvV2
 from .encoder import Encoder3DSepV2
+from .ensemble import Ensembler
+from .panoptic import panoptic_inference
 from .transformer import TransformerPredictorV2
+
+# SemanticKITTI "thing" class ids (pasco/data/semantic_kitti/params.py, `thing_ids`)
+THING_IDS = (1, 2, 3, 4, 5, 6, 7, 8)
 
 
 def compute_scene_size(min_coords, max_coords, scale=1):
@@ -133,7 +138,8 @@ class PascoNet(nn.Module):
     next rows of SURVEY.md 8(f)."""
 
     def __init__(self, n_classes=20, n_infers=1, in_channels=27 + 256, f=64, num_queries=100, heavy_decoder=True,
-                 encoder_dropouts=(0.0, 0.0, 0.0), decoder_dropouts=(0.0, 0.0, 0.0), dense3d_dropout=0.0):
+                 encoder_dropouts=(0.0, 0.0, 0.0), decoder_dropouts=(0.0, 0.0, 0.0), dense3d_dropout=0.0,
+                 iou_threshold=0.2, overlap_threshold=0.4, object_mask_threshold=0.7, thing_ids=THING_IDS):
         super().__init__()
         self.n_infers = n_infers
         self.n_classes = n_classes
@@ -146,6 +152,11 @@ class PascoNet(nn.Module):
                                dense3d_dropout=dense3d_dropout, decoder_dropouts=decoder_dropouts,
                                encoder_dropouts=encoder_dropouts)
         self.feat = CylinderFeat(fea_dim=in_channels, out_pt_fea_dim=f)
+        self.ensembler = Ensembler()
+        self.iou_threshold = iou_threshold
+        self.overlap_threshold = overlap_threshold
+        self.object_mask_threshold = object_mask_threshold
+        self.thing_ids = tuple(thing_ids)
 
     def prepare_input(self, in_feats: List[torch.Tensor], in_coords: List[torch.Tensor]) -> ME.SparseTensor:
         """`self.feat` + `ME.SparseTensor` + `Augmenter.merge` (net_panoptic_sparse.py:548-550)."""
@@ -158,3 +169,32 @@ class PascoNet(nn.Module):
         """The reference's timed window: `self.unet3d(...)` (net_panoptic_sparse.py:228-250)."""
         return self.unet3d(in_feat, 1, global_min_coords, global_max_coords, min_Cs, max_Cs,
                            is_predict_panop=is_predict_panop, keep_override=keep_override)
+
+    def ensemble(self, ret, Ts):
+        """`Net.forward(return_ensemble=True)` after the U-Net (net_panoptic_sparse.py:252-310):
+        -> (ssc_confidences, sem_prob_denses, panop_prob_predictions); confidence = max class prob."""
+        cache = {}
+        sem_prob_denses = self.ensembler.ensemble_sem_compl(ret["sem_logits_at_scales"], Ts, cache=cache)
+        panop = self.ensembler.ensemble_panop(ret["panop_predictions"], sem_prob_denses, Ts,
+                                              iou_threshold=self.iou_threshold, cache=cache)
+        ssc_confidences = [p.max(dim=0)[0] for p in sem_prob_denses]
+        return ssc_confidences, sem_prob_denses, panop
+
+    def step_inference(self, in_feats, in_coords, Ts, global_min_coords, global_max_coords, min_Cs, max_Cs,
+                       keep_override=None, eval_list=None):
+        """`Net.step_inference` (net_panoptic_sparse.py:539-608) without the metric bookkeeping: point MLP,
+        merge, U-Net + transformer, ensembling, panoptic post-processing of every subnet + the ensemble."""
+        x = self.prepare_input(in_feats, in_coords)
+        ret = self(x, global_min_coords, global_max_coords, min_Cs, max_Cs, keep_override=keep_override)
+        ssc_conf, sem_probs, panop = self.ensemble(ret, Ts)
+        outs = []
+        for i in (range(len(panop)) if eval_list is None else eval_list):
+            o = panoptic_inference(panop[i]["voxel_probs"], panop[i]["query_probs"],
+                                   overlap_threshold=self.overlap_threshold,
+                                   object_mask_threshold=self.object_mask_threshold, thing_ids=self.thing_ids,
+                                   scene_size=self.ensembler.scene_size,
+                                   min_C=torch.zeros(3, dtype=torch.int32, device=x.device),
+                                   input_query_logit=False, input_voxel_logit=False)
+            o["ssc_confidence"] = ssc_conf[i]
+            outs.append(o)
+        return outs, sem_probs, panop

@@ -232,10 +232,95 @@ def _golden_unet(n_infers, heavy, tag, seed):
     return True
 
 
+def ensemble_inputs(seed=0, n_sub=3, Q=6):
+    """Synthetic per-subnet outputs with matching structure: Q-2 blob instances + background, query ids
+    permuted per subnet, query classes mixing things and (duplicated) stuff."""
+    from pasco_amd.graph.synth import generate_transformation, transform_coords, THETAS_DEG
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(seed)
+    centres = rng.integers([40, 40, 6], [216, 216, 26], size=(Q - 1, 3))
+    pts = []
+    for c in centres:
+        d = rng.integers(-6, 7, size=(700, 3))
+        d[:, 2] = d[:, 2] // 3
+        pts.append(np.clip(c + d, 0, [255, 255, 31]))
+    G, inv = np.unique(np.concatenate(pts), axis=0, return_inverse=True)
+    inst = np.zeros(G.shape[0], np.int64)
+    inst[inv.reshape(-1)] = np.repeat(np.arange(Q - 1), 700)          # instance of every voxel
+    classes = [3, 12, 12, 5, 15, 0][:Q]                               # thing, stuff, same stuff, thing, stuff, empty
+    sem, panop, Ts = [], [], []
+    for i in range(n_sub):
+        t = np.array([((i % 3) - 1) * 0.2, 0.0, 0.0])
+        T = generate_transformation(THETAS_DEG[i], t)
+        Ts.append(torch.from_numpy(T).float())
+        ct = transform_coords(G, T)
+        cu, first = np.unique(ct, axis=0, return_index=True)
+        coords = torch.from_numpy(np.concatenate([np.zeros((cu.shape[0], 1), np.int64), cu], 1)).int()
+        sem_F = torch.randn(cu.shape[0], 20, generator=g) * 2
+        sem_F[:, 0] -= 1.0
+        perm = torch.randperm(Q, generator=g)                        # query id of instance j in this subnet
+        vl = torch.full((cu.shape[0], Q), -4.0) + torch.randn(cu.shape[0], Q, generator=g)
+        own = perm[torch.from_numpy(inst[first])]
+        vl[torch.arange(cu.shape[0]), own] += 8.0
+        drop = torch.rand(cu.shape[0], generator=g) < 0.15           # subnets do not cover the same voxels
+        ql = torch.randn(1, Q, 21, generator=g)
+        for j in range(Q):
+            ql[0, perm[j], classes[j]] += 7.0
+        sem.append(ME.SparseTensor(sem_F, coords))
+        keep = ~drop
+        panop.append({"voxel_logits": ME.SparseTensor(vl[keep].contiguous(), coords[keep].contiguous()),
+                      "query_logits": ql})
+    return sem, panop, Ts
+
+
+@torch.no_grad()
+def golden_ensemble():
+    from pasco.models.ensembler import Ensembler
+    from pasco.models.helper import panoptic_inference
+    sem, panop, Ts = ensemble_inputs()
+    ens = Ensembler()
+    sem_dense = ens.ensemble_sem_compl({1: sem}, Ts)
+    out = ens.ensemble_panop(panop, sem_dense, (256, 256, 32), Ts, iou_threshold=0.2, measure_time=False)
+    arrays = {"Ts": torch.stack(Ts)}
+    g = torch.Generator().manual_seed(5)
+    probe = torch.stack([torch.randint(0, n, (4000,), generator=g) for n in (256, 256, 32)], 1)
+    arrays["probe"] = probe
+    for i, s in enumerate(sem):
+        arrays[f"sem_{i}_C"], arrays[f"sem_{i}_F"] = s.C, s.F
+    for i, p in enumerate(panop):
+        arrays[f"in_voxel_{i}_C"], arrays[f"in_voxel_{i}_F"] = p["voxel_logits"].C, p["voxel_logits"].F
+        arrays[f"in_query_{i}"] = p["query_logits"]
+    for i, d in enumerate(sem_dense):
+        arrays[f"semdense_{i}_probe"] = d[:, probe[:, 0], probe[:, 1], probe[:, 2]].T
+        arrays[f"semdense_{i}_argmax_hist"] = torch.bincount(d.argmax(0).reshape(-1), minlength=20)
+    for i, o in enumerate(out):
+        arrays[f"out_{i}_voxel_C"], arrays[f"out_{i}_voxel_F"] = o["voxel_probs"].C, o["voxel_probs"].F
+        arrays[f"out_{i}_sem_F"] = o["sem_probs"].F
+        arrays[f"out_{i}_query"] = o["query_probs"]
+        pi = panoptic_inference(o["voxel_probs"], o["query_probs"], overlap_threshold=0.4, object_mask_threshold=0.7,
+                                thing_ids=[1, 2, 3, 4, 5, 6, 7, 8], scene_size=(256, 256, 32),
+                                min_C=torch.tensor([0, 0, 0], dtype=torch.int32), input_query_logit=False,
+                                input_voxel_logit=False)
+        arrays[f"pi_{i}_panoptic_sparse"] = pi["panoptic_seg_sparses"][0]
+        c = o["voxel_probs"].C.long()
+        for k in ("semantic_seg_denses", "ins_uncertainty_denses", "vox_confidence_denses", "vox_uncertainty_denses"):
+            arrays[f"pi_{i}_{k}"] = pi[k][0][c[:, 1], c[:, 2], c[:, 3]]
+        arrays[f"pi_{i}_seginfo"] = torch.tensor([[s["id"], int(s["isthing"]), s["category_id"], s["query_id"]]
+                                                  for s in pi["segments_infos"][0]]).reshape(-1, 4)
+        arrays[f"pi_{i}_segconf"] = torch.tensor([s["confidence"] for s in pi["segments_infos"][0]])
+        print("ensemble out", i, tuple(o["voxel_probs"].F.shape), tuple(o["query_probs"].shape),
+              arrays[f"pi_{i}_seginfo"].tolist())
+    save("ensemble.npz", **arrays)
+
+
 if __name__ == "__main__":
+    if "--ensemble-only" in sys.argv:
+        golden_ensemble()
+        sys.exit(0)
     golden_pe()
     golden_attention_layers()
     golden_dense3d()
     golden_unet(1, False, "m1_light")
     golden_unet(2, False, "m2_light")
     golden_unet(1, True, "m1_heavy")
+    golden_ensemble()

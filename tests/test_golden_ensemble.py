@@ -1,0 +1,66 @@
+"""Ensembler + panoptic post-processing against vectors produced by the REFERENCE's own
+`Ensembler.ensemble_sem_compl / ensemble_panop` (pasco/models/ensembler.py) and
+`panoptic_inference` (pasco/models/helper.py), run in the build container on its dense
+[Q,256,256,32] formulation (tests/golden/make_golden.py::golden_ensemble)."""
+import pytest
+import torch
+
+import pasco_amd.me as ME
+from pasco_amd.graph.ensemble import Ensembler
+from pasco_amd.graph.panoptic import panoptic_inference
+from tests.test_golden import compare_sparse, load
+
+
+def run_case(device, rtol, atol):
+    d = load("ensemble.npz")
+    n_sub = d["Ts"].shape[0]
+    Ts = [d["Ts"][i] for i in range(n_sub)]
+    sem = [ME.SparseTensor(d[f"sem_{i}_F"].to(device), d[f"sem_{i}_C"].to(device)) for i in range(n_sub)]
+    panop = [{"voxel_logits": ME.SparseTensor(d[f"in_voxel_{i}_F"].to(device), d[f"in_voxel_{i}_C"].to(device)),
+              "query_logits": d[f"in_query_{i}"].to(device)} for i in range(n_sub)]
+    ens = Ensembler()
+    with torch.no_grad():
+        sem_dense = ens.ensemble_sem_compl({1: sem}, Ts)
+        out = ens.ensemble_panop(panop, sem_dense, Ts, iou_threshold=0.2)
+    assert len(sem_dense) == n_sub + 1 and len(out) == n_sub + 1
+    probe = d["probe"].long()
+    for i, sd in enumerate(sem_dense):
+        assert tuple(sd.shape) == (20, 256, 256, 32)
+        got = sd[:, probe[:, 0], probe[:, 1], probe[:, 2]].T.cpu()
+        exp = d[f"semdense_{i}_probe"]
+        bad = ((got - exp).abs() > atol + rtol * exp.abs()).any(dim=1).float().mean()
+        assert bad < 2e-3, f"semantic ensemble {i}: {float(bad):.2e} of probed sites differ"
+        hist = torch.bincount(sd.argmax(0).reshape(-1).cpu(), minlength=20)
+        assert (hist - d[f"semdense_{i}_argmax_hist"]).abs().sum() <= 40
+    for i, o in enumerate(out):
+        assert torch.allclose(o["query_probs"].cpu(), d[f"out_{i}_query"], rtol=rtol, atol=atol), f"query probs {i}"
+        compare_sparse(o["voxel_probs"].C, o["voxel_probs"].F, d[f"out_{i}_voxel_C"], d[f"out_{i}_voxel_F"],
+                       rtol, atol, f"voxel_probs_{i}", min_jaccard=0.995)
+        compare_sparse(o["sem_probs"].C, o["sem_probs"].F, d[f"out_{i}_voxel_C"], d[f"out_{i}_sem_F"],
+                       rtol, atol, f"sem_probs_{i}", min_jaccard=0.995)
+        pi = panoptic_inference(o["voxel_probs"], o["query_probs"], overlap_threshold=0.4, object_mask_threshold=0.7,
+                                thing_ids=[1, 2, 3, 4, 5, 6, 7, 8], scene_size=(256, 256, 32),
+                                min_C=torch.zeros(3, dtype=torch.int32), input_query_logit=False,
+                                input_voxel_logit=False)
+        info = torch.tensor([[s["id"], int(s["isthing"]), s["category_id"], s["query_id"]]
+                             for s in pi["segments_infos"][0]]).reshape(-1, 4)
+        assert torch.equal(info, d[f"pi_{i}_seginfo"]), f"segments of output {i}"
+        conf = torch.tensor([s["confidence"] for s in pi["segments_infos"][0]])
+        assert torch.allclose(conf, d[f"pi_{i}_segconf"], rtol=rtol, atol=atol)
+        compare_sparse(o["voxel_probs"].C, pi["panoptic_seg_sparses"][0].float()[:, None], d[f"out_{i}_voxel_C"],
+                       d[f"pi_{i}_panoptic_sparse"].float()[:, None], 0.0, 0.5, f"panoptic ids {i}", min_jaccard=0.995)
+        c = d[f"out_{i}_voxel_C"].long()
+        for k in ("semantic_seg_denses", "ins_uncertainty_denses", "vox_confidence_denses", "vox_uncertainty_denses"):
+            got = pi[k][0][c[:, 1], c[:, 2], c[:, 3]].cpu().float()
+            exp = d[f"pi_{i}_{k}"].float()
+            bad = ((got - exp).abs() > 1e-3 + 1e-3 * exp.abs()).float().mean()
+            assert bad < 5e-3, f"{k} of output {i}: {float(bad):.2e} off"
+
+
+def test_ensemble_and_panoptic_match_reference_cpu(oracle_registered):
+    run_case("cpu", rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_ensemble_and_panoptic_match_reference_gpu(hip):
+    run_case("cuda", rtol=1e-3, atol=1e-4)

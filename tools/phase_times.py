@@ -23,6 +23,9 @@ def timed(name, fn):
 
 u = net.unet3d
 net.prepare_input = timed("prepare_input(pointMLP+merge)", net.prepare_input)
+net.ensemble = timed("ensemble(total)", net.ensemble)
+net.ensembler.ensemble_sem_compl = timed("  ens_sem", net.ensembler.ensemble_sem_compl)
+net.ensembler.ensemble_panop = timed("  ens_panop", net.ensembler.ensemble_panop)
 u.encoder.forward = timed("encoder", u.encoder.forward)
 u.dense_bottleneck = timed("bottleneck", u.dense_bottleneck)
 for i, b in enumerate(u.decoder_generative.dec_blocks):
