@@ -37,9 +37,11 @@ def inside_bounds(coords: torch.Tensor, lo, hi) -> torch.Tensor:
     return ((xyz >= lo) & (xyz <= hi)).all(dim=1)
 
 
-def batch_sparse_tensor(tensors: List[ME.SparseTensor]):
-    """Zero-pad per-subnet tensors to [M, Nmax, C] / [M, Nmax, 4] (reference: pasco/models/utils.py:659-670)."""
-    n_max = max(t.F.shape[0] for t in tensors)
+def batch_sparse_tensor(tensors: List[ME.SparseTensor], n_max: Optional[int] = None):
+    """Zero-pad per-subnet tensors to [M, Nmax, C] / [M, Nmax, 4] (reference: pasco/models/utils.py:659-670).
+    `n_max` overrides the pad length (subnet-parallel heads pad to the longest subnet of ALL ranks, because
+    the padded rows take part in the attention - SURVEY.md section 9 item 5)."""
+    n_max = max([t.F.shape[0] for t in tensors] + ([n_max] if n_max is not None else []))
     f0, c0 = tensors[0].F, tensors[0].C
     bf = f0.new_zeros((len(tensors), n_max, f0.shape[1]))
     bc = c0.new_zeros((len(tensors), n_max, c0.shape[1]))
@@ -127,31 +129,40 @@ class DecoderGenerativeSepConvV2(nn.Module):
         return keep
 
     # -- panoptic branch ----------------------------------------------------------------------------
-    def predict_panop(self, xs, sem_logits_at_scales, min_Cs, max_Cs, keep_override=None):
+    def predict_panop(self, xs, sem_logits_at_scales, min_Cs, max_Cs, keep_override=None, subnets=None):
         xs_infers = defaultdict(list)
         sem_logits_pruneds = []
-        for i in range(self.n_infers):
+
+        def keep_mask(i, scale, x):
+            logits = sem_logits_at_scales[scale][i]
+            keep = keep_override.member(scale, i, x.C) if keep_override is not None else self._occupied(logits)
+            if int(keep.sum()) == 0:  # reference fallback (decoder_v3.py:415-418)
+                keep = torch.zeros_like(keep)
+                keep[:1000] = True
+            return keep & inside_bounds(x.C, min_Cs[i], max_Cs[i])
+
+        pad_to = {s: None for s in xs}
+        if subnets is not None:   # pad like the full batch would: longest subnet over all subnets
+            for scale, x in xs.items():
+                pad_to[scale] = max(int(keep_mask(i, scale, x).sum()) for i in range(self.n_infers))
+        for i in (range(self.n_infers) if subnets is None else subnets):
             for scale, x in xs.items():
                 logits = sem_logits_at_scales[scale][i]
-                keep = keep_override.member(scale, i, x.C) if keep_override is not None else self._occupied(logits)
-                if int(keep.sum()) == 0:  # reference fallback (decoder_v3.py:415-418)
-                    keep = torch.zeros_like(keep)
-                    keep[:1000] = True
-                keep = keep & inside_bounds(x.C, min_Cs[i], max_Cs[i])
+                keep = keep_mask(i, scale, x)
                 if scale == 1:
                     sem_logits_pruneds.append(self.pruning(logits, keep))
                 xi = self.pruning(x, keep)
                 vf = self.voxel_feats[f"scale{scale}_infer{i}"]
                 h = fused.conv(xi, vf[0], epi_bn=vf[1], epi_act=ACT_RELU)
                 xs_infers[scale].append(fused.conv(h, vf[3]))
-        batched = {s: batch_sparse_tensor(v) for s, v in xs_infers.items()}
-        sem_F, sem_C = batch_sparse_tensor(sem_logits_pruneds)
+        batched = {s: batch_sparse_tensor(v, pad_to[s]) for s, v in xs_infers.items()}
+        sem_F, sem_C = batch_sparse_tensor(sem_logits_pruneds, pad_to[1])
         keep_pad = ((sem_F != 0).sum(-1) + (sem_C != 0).sum(-1)) != 0
-        panop = self.transformer_predictor(batched, (sem_F, sem_C), min_Cs, max_Cs, keep_pad)
+        panop = self.transformer_predictor(batched, (sem_F, sem_C), min_Cs, max_Cs, keep_pad, subnets=subnets)
         return panop, sem_logits_pruneds
 
     def forward(self, x, features, global_min_coords, global_max_coords, min_Cs, max_Cs,
-                is_predict_panop=True, keep_override=None):
+                is_predict_panop=True, keep_override=None, subnets=None):
         """features = [enc_s1, enc_s2, enc_s4]; x = bottleneck output at tensor stride 8."""
         assert not self.training, "inference only"
         skips = features[::-1]
@@ -171,7 +182,7 @@ class DecoderGenerativeSepConvV2(nn.Module):
             sem_logits_at_scales[scale] = sem_logits
         ret = {"sem_logits_at_scales": sem_logits_at_scales}
         if is_predict_panop:
-            panop, pruned = self.predict_panop(xs, sem_logits_at_scales, min_Cs, max_Cs, keep_override)
+            panop, pruned = self.predict_panop(xs, sem_logits_at_scales, min_Cs, max_Cs, keep_override, subnets)
             ret["panop_predictions"] = panop
             ret["sem_logits_pruneds"] = pruned
         return ret

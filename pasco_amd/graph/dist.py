@@ -70,3 +70,41 @@ def timed_steps(step: Callable[[], None], steps: int, warmup: int, device_sync: 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+def subnet_parallel_forward(net, in_feat, global_min_coords, global_max_coords, min_Cs, max_Cs, keep_override=None,
+                            group=None):
+    """Config C4 (one MIMO head per GPU): every rank runs the shared trunk on the same scene, then only
+    its own subnets' voxel-feature convolutions and transformer rows; one exchange step all-gathers
+    the per-voxel mask logits (+ coordinates) and the query logits so that every rank can ensemble.
+    Returns the same dict as `net(...)` with `panop_predictions` complete on every rank."""
+    from .. import me as ME
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = shard_indices(net.n_infers, rank, world)
+    ret = net(in_feat, global_min_coords, global_max_coords, min_Cs, max_Cs, keep_override=keep_override,
+              subnets=mine)
+    local = ret["panop_predictions"]
+    dev = in_feat.device
+    n_q = net.transformer_predictor.num_queries
+    n_cls = net.n_classes + 1
+    full = [None] * net.n_infers
+    rounds = (net.n_infers + world - 1) // world
+    for r in range(rounds):                      # rank k owns subnets k, k + world, ...
+        have = r < len(local)
+        if have:
+            vl = local[r]["voxel_logits"]
+            feats, coords, ql = vl.F.contiguous(), vl.C.contiguous(), local[r]["query_logits"].reshape(-1, n_cls)
+        else:                                    # ragged tail: contribute empty rows
+            feats = torch.zeros((0, n_q), device=dev)
+            coords = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+            ql = torch.zeros((0, n_cls), device=dev)
+        fs, cs = allgather_voxel_logits(feats, coords, group)
+        qs = allgather_rows(ql.contiguous(), group)
+        for k in range(world):
+            i = k + r * world
+            if i < net.n_infers and qs[k].shape[0]:
+                full[i] = {"voxel_logits": ME.SparseTensor(fs[k], cs[k]), "query_logits": qs[k].reshape(1, n_q, n_cls),
+                           "aux_outputs": local[r]["aux_outputs"] if (have and k == rank) else []}
+    ret["panop_predictions"] = full
+    return ret

@@ -209,14 +209,23 @@ class TransformerPredictorV2(nn.Module):
         return site_mgr.backend().gather_rows(pooled.F.contiguous(), rows.contiguous())   # -1 -> zeros
 
     # -- forward ------------------------------------------------------------------------------------
-    def forward(self, xs, sem_logits, min_Cs, max_Cs, keep_pad):
-        """xs[scale] = (feats [B,N,C], coords [B,N,4]); returns one dict per subnet."""
+    def forward(self, xs, sem_logits, min_Cs, max_Cs, keep_pad, subnets=None):
+        """xs[scale] = (feats [B,N,C], coords [B,N,4]); returns one dict per subnet.
+        `subnets` (optional list of subnet indices): the batch rows hold only those subnets' voxels and
+        only their query sets run (subnet-parallel heads)."""
         sem_F, sem_C = sem_logits
         B = sem_F.shape[0]
-        assert B == self.n_infers, "batch size should be equal to number of inference"
         D = self.hidden_dim
-        output = self.query_feat.weight.reshape(B, -1, D)
-        query_embed = self.query_embed.weight.reshape(B, -1, D)
+        output = self.query_feat.weight.reshape(self.n_infers, -1, D)
+        query_embed = self.query_embed.weight.reshape(self.n_infers, -1, D)
+        if subnets is None:
+            assert B == self.n_infers, "batch size should be equal to number of inference"
+        else:
+            assert B == len(subnets)
+            sel = torch.as_tensor(list(subnets), device=output.device)
+            output, query_embed = output[sel], query_embed[sel]
+            min_Cs = [min_Cs[i] for i in subnets]
+            max_Cs = [max_Cs[i] for i in subnets]
         srcs, src_Cs, pos = [], [], []
         for s in self.src_scales:
             f, c = xs[s]

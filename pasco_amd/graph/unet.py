@@ -124,12 +124,13 @@ class UNet3DV2(nn.Module):
                                coordinate_manager=deepest.coordinate_manager)
 
     def forward(self, in_feat, bs, global_min_coords, global_max_coords, min_Cs, max_Cs,
-                is_predict_panop=True, keep_override=None):
+                is_predict_panop=True, keep_override=None, subnets=None):
         assert not self.training, "inference only"
         feats = self.encoder(in_feat)
         deepest = self.dense_bottleneck(feats[-1], bs, global_min_coords, global_max_coords)
         return self.decoder_generative(deepest, feats[:-1], global_min_coords, global_max_coords, min_Cs, max_Cs,
-                                       is_predict_panop=is_predict_panop, keep_override=keep_override)
+                                       is_predict_panop=is_predict_panop, keep_override=keep_override,
+                                       subnets=subnets)
 
 
 class PascoNet(nn.Module):
@@ -165,10 +166,10 @@ class PascoNet(nn.Module):
         return merge_subnet_inputs(x, self.n_infers)
 
     def forward(self, in_feat: ME.SparseTensor, global_min_coords, global_max_coords, min_Cs, max_Cs,
-                is_predict_panop=True, keep_override=None):
+                is_predict_panop=True, keep_override=None, subnets=None):
         """The reference's timed window: `self.unet3d(...)` (net_panoptic_sparse.py:228-250)."""
         return self.unet3d(in_feat, 1, global_min_coords, global_max_coords, min_Cs, max_Cs,
-                           is_predict_panop=is_predict_panop, keep_override=keep_override)
+                           is_predict_panop=is_predict_panop, keep_override=keep_override, subnets=subnets)
 
     def ensemble(self, ret, Ts):
         """`Net.forward(return_ensemble=True)` after the U-Net (net_panoptic_sparse.py:252-310):

@@ -57,3 +57,55 @@ def test_world2_gloo():
     e0, e1 = res[0][2], res[1][2]
     assert abs(e0 - e1) < 1e-9 and e0 >= 3 * 0.04 * 0.9, "max over ranks"
     assert res[0][3] == [0, 2, 4, 6] and res[1][3] == [1, 3, 5]
+
+
+def _c4_worker(rank, world, port, q):
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.conftest import load_oracle
+        from pasco_amd.me import backend
+        from pasco_amd.graph import PascoNet
+        from pasco_amd.graph.dist import subnet_parallel_forward
+        from pasco_amd.graph.synth import TeacherKeep, make_scene
+        backend.register_checker_backend(load_oracle())
+        torch.manual_seed(3)
+        net = PascoNet(n_classes=20, n_infers=2, in_channels=12, f=8, num_queries=8, heavy_decoder=False).eval()
+        net.ensembler.scene_size = (24, 24, 8)
+        sc = make_scene(4, n_infers=2, in_channels=12, grid=(24, 24, 8), occupancy=0.12)
+        tk = TeacherKeep(sc, "cpu")
+        with torch.no_grad():
+            x = net.prepare_input(sc.in_feats, sc.in_coords)
+            args = (x, sc.global_min_Cs, sc.global_max_Cs, sc.min_Cs, sc.max_Cs)
+            ref = net(*args, keep_override=tk)                                  # all heads on one process
+            got = subnet_parallel_forward(net, *args, keep_override=tk)         # one head per rank + all-gather
+            ok = True
+            for a, b in zip(got["panop_predictions"], ref["panop_predictions"]):
+                ok = ok and torch.equal(a["voxel_logits"].C, b["voxel_logits"].C)
+                ok = ok and torch.allclose(a["voxel_logits"].F, b["voxel_logits"].F, rtol=1e-4, atol=1e-5)
+                ok = ok and torch.allclose(a["query_logits"], b["query_logits"], rtol=1e-4, atol=1e-5)
+            e_got = net.ensemble(got, sc.Ts)[2]
+            e_ref = net.ensemble(ref, sc.Ts)[2]
+            ok = ok and torch.allclose(e_got[-1]["voxel_probs"].F, e_ref[-1]["voxel_probs"].F, rtol=1e-4, atol=1e-5)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_subnet_parallel_heads_world2_gloo():
+    """Config C4 in miniature: MIMO M=2, one subnet head per process, all-gather of per-voxel logits;
+    every rank ends with the same predictions as the single-process graph."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c4_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)

@@ -1,0 +1,143 @@
+"""Full-size (S10: 256x256x32 at ~10 % occupancy, ~210 k voxels) GPU checks through size-independent
+properties - no oracle run at this size:
+  * insert -> find round trip, idempotent re-insert, dedup of a doubled input
+  * kernel-map symmetry: (i -> o at offset k) <=> (o -> i at offset K-1-k) for the centred k=3 kernel
+  * linearity of the sparse convolution, equality with a per-offset torch formulation on a row sample
+  * prune is order preserving and idempotent; union(a, b) covers both, lhs first
+  * stride / generative expansion: every fine voxel has exactly one parent; children of parents tile
+  * dense <-> sparse round trip
+plus the whole MIMO graph on config-shaped variants (KITTI-360 channel counts, heavy decoder) against
+the CPU oracle on a reduced grid."""
+import numpy as np
+import pytest
+import torch
+
+import pasco_amd.me as ME
+from pasco_amd.graph.synth import make_occupancy, make_scene, TeacherKeep
+from pasco_amd.me.core import kernel_offsets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def s10():
+    g1 = np.argwhere(make_occupancy(0))
+    c = torch.from_numpy(np.concatenate([np.zeros((g1.shape[0], 1), np.int64), g1], 1)).int().cuda()
+    return c
+
+
+def test_insert_find_roundtrip_and_dedup(hip, s10):
+    n = s10.shape[0]
+    tk, tv, r2u, uq, nu = hip.map_insert(s10)
+    assert nu == n and torch.equal(r2u, torch.arange(n, dtype=torch.int32, device="cuda"))
+    assert torch.equal(hip.map_find(s10, tk, tv), r2u)
+    doubled = torch.cat([s10, s10.flip(0)])
+    _, _, r2u2, uq2, nu2 = hip.map_insert(doubled)
+    assert nu2 == n and torch.equal(uq2, torch.arange(n, dtype=torch.int32, device="cuda"))
+    assert torch.equal(r2u2[n:], torch.arange(n - 1, -1, -1, dtype=torch.int32, device="cuda"))
+    shifted = s10 + torch.tensor([0, 1000, 0, 0], dtype=torch.int32, device="cuda")
+    assert int((hip.map_find(shifted, tk, tv) >= 0).sum()) == 0
+
+
+def test_kernel_map_symmetry_and_counts(hip, s10):
+    n = s10.shape[0]
+    tk, tv, _, _, _ = hip.map_insert(s10, dedup=False)
+    nbr = hip.nbr_build(s10, tk, tv, kernel_offsets(3, 1))
+    assert torch.equal(nbr[13], torch.arange(n, dtype=torch.int32, device="cuda"))      # centre offset = identity
+    pin, pout, cnt = hip.kmap_compact(nbr)
+    cnt = cnt.tolist()
+    assert cnt[13] == n and all(cnt[k] == cnt[26 - k] for k in range(27))
+    for k in (0, 5, 12):
+        i, o = pin[k, :cnt[k]].long(), pout[k, :cnt[k]].long()
+        assert torch.equal(nbr[26 - k][i], o.int())                                        # mirrored pair exists
+        assert bool((o[1:] > o[:-1]).all())                                                # pairs sorted by out row
+    assert 14.0 < sum(cnt) / n < 17.0                                                      # S10: ~15.4 pairs / voxel
+
+
+def test_conv_linearity_and_row_sample(hip, s10):
+    n = s10.shape[0]
+    tk, tv, _, _, _ = hip.map_insert(s10, dedup=False)
+    nbr = hip.nbr_build(s10, tk, tv, kernel_offsets(3, 1))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(n, 64, device="cuda", generator=g)
+    y = torch.randn(n, 64, device="cuda", generator=g)
+    w = torch.randn(27, 64, 64, device="cuda", generator=g) / 40
+    cx, cy = hip.conv_fwd(x, w, nbr, n), hip.conv_fwd(y, w, nbr, n)
+    cz = hip.conv_fwd(2.0 * x - 0.5 * y, w, nbr, n)
+    assert torch.allclose(cz, 2.0 * cx - 0.5 * cy, rtol=1e-3, atol=1e-4)
+    rows = torch.randint(0, n, (2000,), device="cuda", generator=g)
+    ref = torch.zeros(2000, 64, device="cuda", dtype=torch.float64)
+    for k in range(27):
+        idx = nbr[k][rows].long()
+        ok = idx >= 0
+        ref[ok] += x[idx[ok]].double() @ w[k].double()
+    assert torch.allclose(cx[rows], ref.float(), rtol=1e-3, atol=1e-4)
+
+
+def test_prune_union_stride_expand_properties(hip, oracle):
+    from pasco_amd.me import backend
+    g1 = np.argwhere(make_occupancy(0))
+    c = torch.from_numpy(np.concatenate([np.zeros((g1.shape[0], 1), np.int64), g1], 1)).int().cuda()
+    x = ME.SparseTensor(torch.randn(c.shape[0], 8, device="cuda"), c)
+    prune = ME.MinkowskiPruning()
+    m = x.F[:, 0] > 0
+    p = prune(x, m)
+    assert torch.equal(p.C, x.C[m]) and torch.equal(p.F, x.F[m])
+    pp = prune(p, torch.ones(p.F.shape[0], dtype=torch.bool, device="cuda"))
+    assert torch.equal(pp.C, p.C) and torch.equal(pp.F, p.F)
+    q = prune(x, x.F[:, 1] > 0)
+    u = p + q
+    both = m | (x.F[:, 1] > 0)
+    assert u.F.shape[0] == int(both.sum()) and torch.equal(u.C[: p.F.shape[0]], p.C)
+    rows = x.coordinate_manager.find(u.coordinate_map_key, x.C[both].contiguous())
+    assert int((rows < 0).sum()) == 0
+    exp = torch.where(m[both][:, None], x.F[both], torch.zeros_like(x.F[both])) + \
+        torch.where((x.F[:, 1] > 0)[both][:, None], x.F[both], torch.zeros_like(x.F[both]))
+    assert torch.allclose(u.F[rows.long()], exp)
+    # stride 2: every voxel has exactly one parent; the parents' children cover the voxels
+    mgr = x.coordinate_manager
+    k2 = mgr.stride(x.coordinate_map_key, 2)
+    nbr = mgr.kernel_map(x.coordinate_map_key, k2, 2)
+    assert int((nbr >= 0).sum()) == x.F.shape[0]
+    kids = mgr.expand(k2, 2)
+    assert mgr.size(kids) == 8 * mgr.size(k2)
+    assert int((mgr.find(kids, x.C) < 0).sum()) == 0
+    # dense round trip on the canonical grid
+    d, _, _ = x.dense(shape=torch.Size([1, 8, 256, 256, 32]), min_coordinate=torch.IntTensor([0, 0, 0]))
+    t = ME.to_sparse(d)
+    assert torch.equal(t.C, x.C) and torch.equal(t.F, x.F)        # S10 rows are already lexicographic
+
+
+@pytest.mark.parametrize("cfg", [dict(n_classes=19, in_channels=8, heavy=True, n_infers=2),
+                                 dict(n_classes=20, in_channels=16, heavy=False, n_infers=3)])
+def test_config_shaped_graphs_vs_oracle(hip, oracle, cfg):
+    """configs[3]-like (SSCBench-KITTI360: 8 input channels, 19 classes) and MIMO-3 graphs: HIP == oracle."""
+    from pasco_amd.graph import PascoNet
+    from pasco_amd.me import backend
+    torch.manual_seed(11)
+    net = PascoNet(n_classes=cfg["n_classes"], n_infers=cfg["n_infers"], in_channels=cfg["in_channels"], f=16,
+                   num_queries=10, heavy_decoder=cfg["heavy"]).eval()
+    scene = make_scene(9, n_infers=cfg["n_infers"], in_channels=cfg["in_channels"], grid=(40, 40, 8), occupancy=0.12)
+
+    def run(device):
+        n, sc = net.to(device), scene.to(device)
+        tk = TeacherKeep(sc, device)
+        with torch.no_grad():
+            x = n.prepare_input(sc.in_feats, sc.in_coords)
+            return n(x, sc.global_min_Cs, sc.global_max_Cs, sc.min_Cs, sc.max_Cs, keep_override=tk)
+
+    got = run(torch.device("cuda"))
+    backend.register_checker_backend(oracle)
+    try:
+        exp = run(torch.device("cpu"))
+    finally:
+        backend.register_checker_backend(None)
+    for s in exp["sem_logits_at_scales"]:
+        for a, b in zip(got["sem_logits_at_scales"][s], exp["sem_logits_at_scales"][s]):
+            assert torch.equal(a.C.cpu(), b.C)
+            assert a.F.shape[1] == cfg["n_classes"]
+            assert torch.allclose(a.F.cpu(), b.F, rtol=1e-3, atol=1e-3)
+    for a, b in zip(got["panop_predictions"], exp["panop_predictions"]):
+        assert torch.equal(a["voxel_logits"].C.cpu(), b["voxel_logits"].C)
+        assert torch.allclose(a["voxel_logits"].F.cpu(), b["voxel_logits"].F, rtol=2e-3, atol=2e-3)
+        assert torch.allclose(a["query_logits"].cpu(), b["query_logits"], rtol=2e-3, atol=2e-3)
