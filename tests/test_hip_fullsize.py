@@ -22,8 +22,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def s10():
     g1 = np.argwhere(make_occupancy(0))
-    c = torch.from_numpy(np.concatenate([np.zeros((g1.shape[0], 1), np.int64), g1], 1)).int().cuda()
-    return c
+    c = torch.from_numpy(np.ascontiguousarray(np.concatenate([np.zeros((g1.shape[0], 1), np.int64), g1], 1)))
+    return c.int().cuda().contiguous()
 
 
 def test_insert_find_roundtrip_and_dedup(hip, s10):
@@ -31,11 +31,11 @@ def test_insert_find_roundtrip_and_dedup(hip, s10):
     tk, tv, r2u, uq, nu = hip.map_insert(s10)
     assert nu == n and torch.equal(r2u, torch.arange(n, dtype=torch.int32, device="cuda"))
     assert torch.equal(hip.map_find(s10, tk, tv), r2u)
-    doubled = torch.cat([s10, s10.flip(0)])
+    doubled = torch.cat([s10, s10.flip(0)]).contiguous()
     _, _, r2u2, uq2, nu2 = hip.map_insert(doubled)
     assert nu2 == n and torch.equal(uq2, torch.arange(n, dtype=torch.int32, device="cuda"))
     assert torch.equal(r2u2[n:], torch.arange(n - 1, -1, -1, dtype=torch.int32, device="cuda"))
-    shifted = s10 + torch.tensor([0, 1000, 0, 0], dtype=torch.int32, device="cuda")
+    shifted = (s10 + torch.tensor([0, 1000, 0, 0], dtype=torch.int32, device="cuda")).contiguous()
     assert int((hip.map_find(shifted, tk, tv) >= 0).sum()) == 0
 
 
