@@ -195,12 +195,20 @@ int PH_FN(dense_gather)(const float *dense, int32_t c, const int32_t *h_dims4,
  *   bits [B, N, 4]: bit q of the 128-bit word = query q may attend that key (NULL = no mask)
  *   any  [B, 4]   : OR of bits over the keys; a query with no allowed key attends everywhere
  *                   (transformer_predictor_v2.py:163-164)
- * attn_mask_pack builds bits / any from allow flags vals [B*N, Qn] (non-zero = allowed).
+ * attn_mask_pack builds bits / any from vals [B*N, Qn]: allowed = (vals != 0), or (vals > 0) when
+ * `positive_only` (mask logits: sigmoid(l) > 0.5 <=> l > 0, transformer_predictor_v2.py:226).
+ * bits_orpool ORs the bit rows of the children of every coarse voxel (the reference max-pools the
+ * 0/1 mask, transformer_predictor_v2.py:232-236); bits_or_reduce ORs all rows of a batch (`any`).
  * ------------------------------------------------------------------------------------------- */
 int64_t PH_FN(attn_workspace_bytes)(int64_t n, int32_t b, int32_t h, int32_t qn, int32_t dh);
 
-int PH_FN(attn_mask_pack)(const float *vals, int64_t n, int32_t b, int32_t qn, uint32_t *bits,
-                          uint32_t *any, ph_stream_t stream);
+int PH_FN(attn_mask_pack)(const float *vals, int64_t n, int32_t b, int32_t qn, int32_t positive_only,
+                          uint32_t *bits, uint32_t *any, ph_stream_t stream);
+
+int PH_FN(bits_orpool)(const uint32_t *bits_in, const int32_t *nbr, int32_t kvol, int64_t n_out,
+                       uint32_t *bits_out, ph_stream_t stream);
+
+int PH_FN(bits_or_reduce)(const uint32_t *bits, int64_t n, int32_t b, uint32_t *any, ph_stream_t stream);
 
 int PH_FN(attn_cross_fwd)(const float *q, const float *k, const float *v, const uint32_t *bits,
                           const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h,

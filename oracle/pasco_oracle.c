@@ -385,15 +385,15 @@ int64_t pho_attn_workspace_bytes(int64_t n, int32_t b, int32_t h, int32_t qn, in
   return 256;
 }
 
-int pho_attn_mask_pack(const float *vals, int64_t n, int32_t b, int32_t qn, uint32_t *bits, uint32_t *any,
-                       ph_stream_t stream) {
+int pho_attn_mask_pack(const float *vals, int64_t n, int32_t b, int32_t qn, int32_t positive_only, uint32_t *bits,
+                       uint32_t *any, ph_stream_t stream) {
   (void)stream;
   if (qn < 1 || qn > 128) return fail("attn_mask_pack: bad qn");
   if (any) memset(any, 0, sizeof(uint32_t) * 4 * (size_t)b);
   for (int64_t row = 0; row < (int64_t)b * n; ++row) {
     uint32_t w[4] = {0, 0, 0, 0};
     for (int q = 0; q < qn; ++q)
-      if (vals[row * qn + q] != 0.f) w[q >> 5] |= 1u << (q & 31);
+      if (positive_only ? vals[row * qn + q] > 0.f : vals[row * qn + q] != 0.f) w[q >> 5] |= 1u << (q & 31);
     for (int i = 0; i < 4; ++i) {
       bits[row * 4 + i] = w[i];
       if (any) any[(row / n) * 4 + i] |= w[i];
@@ -446,3 +446,30 @@ int pho_attn_cross_fwd(const float *q, const float *k, const float *v, const uin
   return 0;
 }
 
+
+int pho_bits_orpool(const uint32_t *bits_in, const int32_t *nbr, int32_t kvol, int64_t n_out, uint32_t *bits_out,
+                    ph_stream_t stream) {
+  (void)stream;
+  if (kvol < 1 || kvol > PH_MAX_KVOL) return fail("bits_orpool: bad kernel volume");
+  for (int64_t o = 0; o < n_out; ++o)
+    for (int w = 0; w < 4; ++w) {
+      uint32_t m = 0;
+      for (int k = 0; k < kvol; ++k) {
+        int r = nbr[(int64_t)k * n_out + o];
+        if (r >= 0) m |= bits_in[(int64_t)r * 4 + w];
+      }
+      bits_out[o * 4 + w] = m;
+    }
+  return 0;
+}
+
+int pho_bits_or_reduce(const uint32_t *bits, int64_t n, int32_t b, uint32_t *any, ph_stream_t stream) {
+  (void)stream;
+  for (int bi = 0; bi < b; ++bi)
+    for (int w = 0; w < 4; ++w) {
+      uint32_t m = 0;
+      for (int64_t i = 0; i < n; ++i) m |= bits[((int64_t)bi * n + i) * 4 + w];
+      any[bi * 4 + w] = m;
+    }
+  return 0;
+}

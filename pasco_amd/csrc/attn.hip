@@ -189,44 +189,56 @@ __global__ void __launch_bounds__(256, 1) k_attn_cross(AttnArgs a) {
   }
 }
 
-// One workgroup per (b, h): combine the per-wave partials.
+// One workgroup per (b, h, 16-query tile): combine the per-wave partials.
 template <int QT, int DT>
 __global__ void __launch_bounds__(256) k_attn_merge(AttnArgs a) {
   constexpr int DH = DT * 16;
   constexpr int QP = QT * 16;
-  __shared__ float Ms[QP];
-  __shared__ float Ls[QP];
+  constexpr int PS = DH + 4;
+  __shared__ float Ms[16];
+  __shared__ float Ls[16];
   const int bh = blockIdx.x;
+  const int qt = blockIdx.y;
   const int b = bh / a.H, h = bh - b * a.H;
-  const float *base = a.part + (int64_t)bh * a.splits * QP * (DH + 4);
-  for (int q = threadIdx.x; q < QP; q += blockDim.x) {
+  const float *base = a.part + ((int64_t)bh * a.splits * QP + qt * 16) * PS;   // + s * QP * PS + ql * PS
+  // 16 threads per query reduce (m, l) over the splits
+  {
+    const int ql = threadIdx.x >> 4, part = threadIdx.x & 15;
     float M = -INFINITY;
-    for (int s = 0; s < a.splits; ++s) M = fmaxf(M, base[((int64_t)s * QP + q) * (DH + 4) + DH]);
-    float L = 0.f;
+    for (int s = part; s < a.splits; s += 16) M = fmaxf(M, base[((int64_t)s * QP + ql) * PS + DH]);
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) M = fmaxf(M, __shfl_xor(M, d));
     const float Msafe = (M == -INFINITY) ? 0.f : M;
-    for (int s = 0; s < a.splits; ++s) {
-      const float *row = base + ((int64_t)s * QP + q) * (DH + 4);
+    float L = 0.f;
+    for (int s = part; s < a.splits; s += 16) {
+      const float *row = base + ((int64_t)s * QP + ql) * PS;
       L += row[DH + 1] * __expf(row[DH] - Msafe);
     }
-    Ms[q] = Msafe;
-    Ls[q] = L;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) L += __shfl_xor(L, d);
+    if (part == 0) {
+      Ms[ql] = Msafe;
+      Ls[ql] = L;
+    }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < a.Qn * DH; e += blockDim.x) {
-    const int q = e / DH, d = e - q * DH;
+  for (int e = threadIdx.x; e < 16 * DH; e += blockDim.x) {
+    const int ql = e / DH, d = e - ql * DH;
+    const int q = qt * 16 + ql;
+    if (q >= a.Qn) continue;
     float o = 0.f;
     for (int s = 0; s < a.splits; ++s) {
-      const float *row = base + ((int64_t)s * QP + q) * (DH + 4);
-      o += row[d] * __expf(row[DH] - Ms[q]);
+      const float *row = base + ((int64_t)s * QP + ql) * PS;
+      o += row[d] * __expf(row[DH] - Ms[ql]);
     }
-    const float L = Ls[q];
+    const float L = Ls[ql];
     a.out[((int64_t)b * a.Qn + q) * (a.H * DH) + h * DH + d] = L > 0.f ? o / L : 0.f;
   }
 }
 
 // vals [R, Qn] (non-zero = allowed) -> bits [R, 4] ; any[b, 4] |= bits (R = B * N, b = row / N).
 __global__ void __launch_bounds__(256)
-    k_mask_pack(const float *__restrict__ vals, int64_t rows, int64_t n_per_b, int qn,
+    k_mask_pack(const float *__restrict__ vals, int64_t rows, int64_t n_per_b, int qn, int positive_only,
                 uint32_t *__restrict__ bits, uint32_t *__restrict__ any) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= rows * 4) return;
@@ -236,7 +248,7 @@ __global__ void __launch_bounds__(256)
   uint32_t word = 0;
   const int lim = qn - wsel * 32;
   for (int i = 0; i < 32; ++i)
-    if (i < lim && src[i] != 0.f) word |= (1u << i);
+    if (i < lim && (positive_only ? src[i] > 0.f : src[i] != 0.f)) word |= (1u << i);
   bits[t] = word;
   if (any != nullptr && word != 0u) {
     uint32_t *dst = any + (row / n_per_b) * 4 + wsel;
@@ -244,15 +256,67 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-extern "C" int ph_attn_mask_pack(const float *vals, int64_t n, int32_t b, int32_t qn, uint32_t *bits,
-                                 uint32_t *any, ph_stream_t stream) {
+extern "C" int ph_attn_mask_pack(const float *vals, int64_t n, int32_t b, int32_t qn, int32_t positive_only,
+                                 uint32_t *bits, uint32_t *any, ph_stream_t stream) {
   PH_REQUIRE(qn >= 1 && qn <= 128 && b >= 1 && n >= 0, "attn_mask_pack: bad shape");
   hipStream_t st = ph_stream(stream);
   if (any) PH_CHECK_HIP(hipMemsetAsync(any, 0, (size_t)b * 16, st));
   const int64_t rows = (int64_t)b * n;
   if (rows == 0) return 0;
   hipLaunchKernelGGL(k_mask_pack, dim3((unsigned)((rows * 4 + 255) / 256)), dim3(256), 0, st, vals, rows, n, qn,
-                     bits, any);
+                     positive_only, bits, any);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+// bits_out[o] = OR_k bits_in[nbr[k][o]]   (one thread per (o, word))
+__global__ void __launch_bounds__(256)
+    k_bits_orpool(const uint32_t *__restrict__ bin, const int32_t *__restrict__ nbr, int kvol, int64_t n_out,
+                  uint32_t *__restrict__ bout) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out * 4) return;
+  const int64_t o = t >> 2;
+  const int w = (int)(t & 3);
+  uint32_t m = 0;
+  for (int k = 0; k < kvol; ++k) {
+    const int r = nbr[(int64_t)k * n_out + o];
+    if (r >= 0) m |= bin[(int64_t)r * 4 + w];
+  }
+  bout[t] = m;
+}
+
+extern "C" int ph_bits_orpool(const uint32_t *bits_in, const int32_t *nbr, int32_t kvol, int64_t n_out,
+                              uint32_t *bits_out, ph_stream_t stream) {
+  PH_REQUIRE(kvol >= 1 && kvol <= PH_MAX_KVOL, "bits_orpool: bad kernel volume");
+  if (n_out == 0) return 0;
+  hipLaunchKernelGGL(k_bits_orpool, dim3((unsigned)((n_out * 4 + 255) / 256)), dim3(256), 0, ph_stream(stream),
+                     bits_in, nbr, kvol, n_out, bits_out);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+// any[b][w] = OR over the n rows of batch b (wave OR-reduction, one atomicOr per wave)
+__global__ void __launch_bounds__(256)
+    k_bits_or_reduce(const uint32_t *__restrict__ bits, int64_t n, uint32_t *__restrict__ any) {
+  const int b = blockIdx.y;
+  const uint32_t *src = bits + (int64_t)b * n * 4;
+  uint32_t m = 0;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * 4; t += (int64_t)gridDim.x * blockDim.x)
+    m |= src[t];   // t & 3 is constant per thread (stride is a multiple of 4)
+  // lanes with equal (lane & 3) hold the same word
+#pragma unroll
+  for (int d = 4; d < 64; d <<= 1) m |= __shfl_xor(m, d);
+  if ((threadIdx.x & 63) < 4 && m != 0u) atomicOr(any + b * 4 + (threadIdx.x & 3), m);
+}
+
+extern "C" int ph_bits_or_reduce(const uint32_t *bits, int64_t n, int32_t b, uint32_t *any, ph_stream_t stream) {
+  PH_REQUIRE(b >= 1 && n >= 0, "bits_or_reduce: bad shape");
+  hipStream_t st = ph_stream(stream);
+  PH_CHECK_HIP(hipMemsetAsync(any, 0, (size_t)b * 16, st));
+  if (n == 0) return 0;
+  int64_t blocks = (n * 4 + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(k_bits_or_reduce, dim3((unsigned)blocks, (unsigned)b), dim3(256), 0, st, bits, n, any);
   PH_LAUNCH_CHECK();
   return 0;
 }
@@ -292,11 +356,11 @@ extern "C" int ph_attn_cross_fwd(const float *q, const float *k, const float *v,
   if (qn <= 112) {
     hipLaunchKernelGGL((k_attn_cross<7, 3>), dim3(grid), dim3(256), 0, st, a);
     PH_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_attn_merge<7, 3>), dim3(bh), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_attn_merge<7, 3>), dim3(bh, 7), dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL((k_attn_cross<8, 3>), dim3(grid), dim3(256), 0, st, a);
     PH_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_attn_merge<8, 3>), dim3(bh), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_attn_merge<8, 3>), dim3(bh, 8), dim3(256), 0, st, a);
   }
   PH_LAUNCH_CHECK();
   return 0;

@@ -174,19 +174,34 @@ class TransformerPredictorV2(nn.Module):
         return outputs_class, outputs_mask
 
     # -- attention mask -----------------------------------------------------------------------------
-    def compute_allow(self, outputs_mask, voxel_coord, src_C, src_scale, min_Cs, max_Cs):
-        """fp32 [B*N_level, Q] allow flags (non-zero = query may attend that voxel).
+    def compute_mask_bits(self, outputs_mask, voxel_coord, src_C, src_scale, min_Cs, max_Cs):
+        """Attention mask of one level as bits: (bits int32 [B, N_level, 4], any int32 [B, 4]).
 
         Query q may attend level voxel p iff some scale-1 voxel v of the same subnet inside p's
-        s^3 block has mask_logit[v,q] > 0 (sigmoid > 0.5) (transformer_predictor_v2.py:220-289)."""
+        s^3 block has mask_logit[v, q] > 0 (sigmoid > 0.5) (transformer_predictor_v2.py:220-289).
+        The reference builds a 0/1 float SparseTensor, max-pools it, densifies it to [1,Q,X,Y,Z] and
+        indexes it; here the mask is 1 bit per (voxel, query) from the start: pack, OR-pool over the
+        children, hash lookup of the level voxels' sites - same values, 25x less traffic."""
         B, P, Q = outputs_mask.shape
-        keep_F = (outputs_mask > 0).float().reshape(B * P, Q)
-        bcol = torch.arange(B, device=keep_F.device, dtype=torch.int32).repeat_interleave(P).reshape(-1, 1)
-        keep_C = torch.cat([bcol, voxel_coord.reshape(B * P, 4)[:, 1:].to(torch.int32)], dim=1)
-        keep = ME.SparseTensor(keep_F, keep_C)       # duplicated (padded) rows keep their first occurrence
-        pooled = self.max_pools[str(src_scale)](keep) if src_scale != 1 else keep
-        N = src_C.shape[1]
         dev = src_C.device
+        be = backend_for(dev)
+        bits1, _ = be.attn_mask_pack(outputs_mask.reshape(B * P, Q).contiguous(), B, P, positive_only=True,
+                                     want_any=False)
+        bcol = torch.arange(B, device=dev, dtype=torch.int32).repeat_interleave(P).reshape(-1, 1)
+        keep_C = torch.cat([bcol, voxel_coord.reshape(B * P, 4)[:, 1:].to(torch.int32)], dim=1).contiguous()
+        mgr = ME.CoordinateManager(D=3, device=dev)
+        key1, (_, uniq) = mgr.insert_and_map(keep_C, 1)    # duplicated (padded) rows keep their first occurrence
+        bits1 = bits1.reshape(B * P, 4)
+        if uniq is not None:
+            bits1 = be.gather_rows(bits1, uniq)
+        if src_scale != 1:
+            pool = self.max_pools[str(src_scale)]
+            keyp = mgr.stride(key1, pool.stride)
+            nbr = mgr.kernel_map(key1, keyp, pool.kernel_size, pool.dilation)
+            pooled_bits = be.bits_orpool(bits1.contiguous(), nbr)
+        else:
+            keyp, pooled_bits = key1, bits1
+        N = src_C.shape[1]
         mn = torch.stack([torch.as_tensor(m) for m in min_Cs]).to(dev).to(torch.int64)   # [B,3]
         mx = torch.stack([torch.as_tensor(m) for m in max_Cs]).to(dev).to(torch.int64)
         size = torch.div(mx - mn, src_scale, rounding_mode="floor") + 1                   # dense extent per subnet
@@ -198,15 +213,15 @@ class TransformerPredictorV2(nn.Module):
             idx = torch.where(idx < 0, idx + size[b_index], idx)
             return torch.cat([b_index.reshape(-1, 1), idx], dim=1).to(torch.int32)
 
-        # table over the dense sites the pooled voxels land on
-        pc = pooled.C
+        pc = mgr.get_coordinates(keyp)
         site_mgr = ME.CoordinateManager(D=3, device=dev)
-        site_key, (_, uniq) = site_mgr.insert_and_map(sites(pc, pc[:, 0].to(torch.int64)), 1)
+        site_key, (_, suniq) = site_mgr.insert_and_map(sites(pc, pc[:, 0].to(torch.int64)), 1)
         bq = torch.arange(B, device=dev, dtype=torch.int64).repeat_interleave(N)
         rows = site_mgr.find(site_key, sites(src_C.reshape(B * N, 4), bq))
-        if uniq is not None:   # two pooled voxels wrapped onto one site: keep the first
-            rows = torch.where(rows >= 0, uniq[rows.clamp(min=0).long()], rows)
-        return site_mgr.backend().gather_rows(pooled.F.contiguous(), rows.contiguous())   # -1 -> zeros
+        if suniq is not None:   # two pooled voxels wrapped onto one site: keep the first
+            rows = torch.where(rows >= 0, suniq[rows.clamp(min=0).long()], rows)
+        bits = be.gather_rows(pooled_bits.contiguous(), rows.contiguous()).reshape(B, N, 4)   # -1 -> no bit
+        return bits, be.bits_or_reduce(bits)
 
     # -- forward ------------------------------------------------------------------------------------
     def forward(self, xs, sem_logits, min_Cs, max_Cs, keep_pad, subnets=None):
@@ -240,15 +255,16 @@ class TransformerPredictorV2(nn.Module):
         predictions_mask.append(om)
         for i in range(self.num_layers):
             src_F = self.input_projs[i](srcs[i])
-            allow = self.compute_allow(om, voxel_coord, src_Cs[i], self.src_scales[i], min_Cs, max_Cs)
+            bits, any_ = self.compute_mask_bits(om, voxel_coord, src_Cs[i], self.src_scales[i], min_Cs, max_Cs)
             N_i, Qn = src_F.shape[1], om.shape[2]
             be = backend_for(src_F.device)
             if be.attn_supported(Qn, D // self.nheads):
-                bits = be.attn_mask_pack(allow, B, N_i)
                 output = self.transformer_cross_attention_layers[i](output, src_F, pos=pos[i], query_pos=query_embed,
-                                                                    mask_bits=bits)
-            else:   # shapes outside the fused kernel: torch attention with the materialised mask
-                attn_mask = ~(allow.reshape(B, N_i, Qn) != 0).permute(0, 2, 1)
+                                                                    mask_bits=(bits, any_))
+            else:   # shapes outside the fused kernel: torch attention with the materialised bool mask
+                q_idx = torch.arange(Qn, device=bits.device)
+                allow = (bits[:, :, (q_idx >> 5).long()] >> (q_idx & 31).to(torch.int32)) & 1      # [B,N,Q]
+                attn_mask = ~(allow != 0).permute(0, 2, 1)
                 attn_mask = attn_mask & ~attn_mask.all(dim=-1, keepdim=True)   # all-masked -> unmasked
                 output = self.transformer_cross_attention_layers[i](output, src_F, attn_mask=attn_mask,
                                                                     pos=pos[i], query_pos=query_embed)

@@ -60,7 +60,9 @@ _SIGNATURES = {
     "to_sparse_coords": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "dense_gather": [_vp, _i32, _vp, _vp, _i64, _vp, _vp],
     "attn_workspace_bytes": [_i64, _i32, _i32, _i32, _i32],
-    "attn_mask_pack": [_vp, _i64, _i32, _i32, _vp, _vp, _vp],
+    "attn_mask_pack": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
+    "bits_orpool": [_vp, _vp, _i32, _i64, _vp, _vp],
+    "bits_or_reduce": [_vp, _i64, _i32, _vp, _vp],
     "attn_cross_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
 }
 _RESTYPES = {"last_error": C.c_char_p, "workspace_bytes": _i64, "attn_workspace_bytes": _i64}
@@ -359,16 +361,37 @@ class CBackend:
 
 
     # -- attention -----------------------------------------------------------------------------------
-    def attn_mask_pack(self, vals: torch.Tensor, b: int, n: int):
-        """allow flags [B*N, Qn] fp32 -> (bits int32 [B, N, 4], any int32 [B, 4])."""
+    def attn_mask_pack(self, vals: torch.Tensor, b: int, n: int, positive_only: bool = False, want_any: bool = True):
+        """[B*N, Qn] fp32 -> (bits int32 [B, N, 4], any int32 [B, 4] | None); a bit is set where the value
+        is non-zero (or > 0 with positive_only)."""
         self._chk(vals, torch.float32, "vals")
         qn = vals.shape[1]
         assert vals.shape[0] == b * n
         bits = torch.empty((b, n, 4), dtype=torch.int32, device=vals.device)
-        any_ = torch.empty((b, 4), dtype=torch.int32, device=vals.device)
-        rc = self.fn["attn_mask_pack"](_ptr(vals), n, b, qn, _ptr(bits), _ptr(any_), self.stream(vals.device))
+        any_ = torch.empty((b, 4), dtype=torch.int32, device=vals.device) if want_any else None
+        rc = self.fn["attn_mask_pack"](_ptr(vals), n, b, qn, 1 if positive_only else 0, _ptr(bits), _ptr(any_),
+                                       self.stream(vals.device))
         self._check(rc, "attn_mask_pack")
         return bits, any_
+
+    def bits_orpool(self, bits: torch.Tensor, nbr: torch.Tensor) -> torch.Tensor:
+        """bits int32 [N_in, 4], nbr [K, N_out] -> OR over the neighbours [N_out, 4]."""
+        self._chk(bits, torch.int32, "bits")
+        self._chk(nbr, torch.int32, "nbr")
+        kvol, n_out = nbr.shape
+        out = torch.empty((n_out, 4), dtype=torch.int32, device=bits.device)
+        rc = self.fn["bits_orpool"](_ptr(bits), _ptr(nbr), kvol, n_out, _ptr(out), self.stream(bits.device))
+        self._check(rc, "bits_orpool")
+        return out
+
+    def bits_or_reduce(self, bits: torch.Tensor) -> torch.Tensor:
+        """bits int32 [B, N, 4] -> OR over N: [B, 4]."""
+        self._chk(bits, torch.int32, "bits")
+        b, n, _ = bits.shape
+        out = torch.empty((b, 4), dtype=torch.int32, device=bits.device)
+        rc = self.fn["bits_or_reduce"](_ptr(bits), n, b, _ptr(out), self.stream(bits.device))
+        self._check(rc, "bits_or_reduce")
+        return out
 
     def attn_supported(self, qn: int, dh: int) -> bool:
         return qn <= 128 and (dh == 48 or self.device_type == "cpu")

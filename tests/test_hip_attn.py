@@ -52,6 +52,13 @@ def test_attn_mask_pack_and_oracle(hip, oracle):
     b_o, a_o = oracle.attn_mask_pack(vals, B, N)
     b_h, a_h = hip.attn_mask_pack(vals.cuda(), B, N)
     assert torch.equal(b_h.cpu(), b_o) and torch.equal(a_h.cpu(), a_o)
+    assert torch.equal(hip.bits_or_reduce(b_h).cpu(), a_o) and torch.equal(oracle.bits_or_reduce(b_o), a_o)
+    logits = torch.randn(B * N, Q, generator=g)
+    p_o, _ = oracle.attn_mask_pack(logits, B, N, positive_only=True, want_any=False)
+    p_h, _ = hip.attn_mask_pack(logits.cuda(), B, N, positive_only=True, want_any=False)
+    assert torch.equal(p_h.cpu(), p_o)
+    nbr = torch.randint(-1, B * N, (8, 500), generator=g).int()
+    assert torch.equal(hip.bits_orpool(p_h.reshape(-1, 4), nbr.cuda()).cpu(), oracle.bits_orpool(p_o.reshape(-1, 4), nbr))
     q = torch.randn(B, H, Q, Dh, generator=g) * Dh ** -0.5
     k = torch.randn(B, N, H * Dh, generator=g)
     v = torch.randn(B, N, H * Dh, generator=g)

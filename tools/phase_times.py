@@ -33,7 +33,7 @@ for i, b in enumerate(u.decoder_generative.dec_blocks):
 u.decoder_generative.predict_panop = timed("predict_panop(total)", u.decoder_generative.predict_panop)
 net.transformer_predictor.forward = timed("  transformer", net.transformer_predictor.forward)
 tp = net.transformer_predictor
-tp.compute_allow = timed("    attn_mask", tp.compute_allow)
+tp.compute_mask_bits = timed("    attn_mask", tp.compute_mask_bits)
 for i, l in enumerate(tp.transformer_cross_attention_layers):
     l.forward = timed(f"    xattn{i}", l.forward)
 tp.pred_heads = timed("    pred_heads", tp.pred_heads)
