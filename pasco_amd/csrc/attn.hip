@@ -236,23 +236,28 @@ __global__ void __launch_bounds__(256) k_attn_merge(AttnArgs a) {
   }
 }
 
-// vals [R, Qn] (non-zero = allowed) -> bits [R, 4] ; any[b, 4] |= bits (R = B * N, b = row / N).
+// vals [R, Qn] -> bits [R, 4] ; any[b, 4] |= bits (R = B * N, b = row / N).  One wave64 per row: two
+// coalesced 256-byte loads, two ballots.
 __global__ void __launch_bounds__(256)
     k_mask_pack(const float *__restrict__ vals, int64_t rows, int64_t n_per_b, int qn, int positive_only,
                 uint32_t *__restrict__ bits, uint32_t *__restrict__ any) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * 4) return;
-  const int64_t row = t >> 2;
-  const int wsel = (int)(t & 3);
-  const float *src = vals + row * qn + wsel * 32;
-  uint32_t word = 0;
-  const int lim = qn - wsel * 32;
-  for (int i = 0; i < 32; ++i)
-    if (i < lim && (positive_only ? src[i] > 0.f : src[i] != 0.f)) word |= (1u << i);
-  bits[t] = word;
-  if (any != nullptr && word != 0u) {
-    uint32_t *dst = any + (row / n_per_b) * 4 + wsel;
-    if ((__hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & word) != word) atomicOr(dst, word);
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < rows; row += nwaves) {
+    const float *src = vals + row * qn;
+    const float v0 = lane < qn ? src[lane] : 0.f;
+    const float v1 = 64 + lane < qn ? src[64 + lane] : 0.f;
+    const unsigned long long b0 = __ballot(positive_only ? v0 > 0.f : v0 != 0.f);
+    const unsigned long long b1 = __ballot(positive_only ? v1 > 0.f : v1 != 0.f);
+    if (lane < 4) {
+      const uint32_t word = lane == 0 ? (uint32_t)b0 : lane == 1 ? (uint32_t)(b0 >> 32)
+                          : lane == 2 ? (uint32_t)b1 : (uint32_t)(b1 >> 32);
+      bits[row * 4 + lane] = word;
+      if (any != nullptr && word != 0u) {
+        uint32_t *dst = any + (row / n_per_b) * 4 + lane;
+        if ((__hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & word) != word) atomicOr(dst, word);
+      }
+    }
   }
 }
 
@@ -263,8 +268,10 @@ extern "C" int ph_attn_mask_pack(const float *vals, int64_t n, int32_t b, int32_
   if (any) PH_CHECK_HIP(hipMemsetAsync(any, 0, (size_t)b * 16, st));
   const int64_t rows = (int64_t)b * n;
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(k_mask_pack, dim3((unsigned)((rows * 4 + 255) / 256)), dim3(256), 0, st, vals, rows, n, qn,
-                     positive_only, bits, any);
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_mask_pack, dim3((unsigned)blocks), dim3(256), 0, st, vals, rows, n, qn, positive_only, bits,
+                     any);
   PH_LAUNCH_CHECK();
   return 0;
 }
