@@ -59,6 +59,10 @@ def main():
                 os.environ["PASCO_CONV_CFG"] = cfg
                 cfg_times[cfg] = round(timeit(lambda: be.conv_fwd(x0, w0, nbr0, n, out=o0), iters=10) * 1e6, 1)
             os.environ.pop("PASCO_CONV_CFG", None)
+            for cfg in ("128", "64", "32"):
+                os.environ["PASCO_CONV_CFG"] = cfg
+                cfg_times[cfg] = round(timeit(lambda: be.conv_fwd(x0, w0, nbr0, n, out=o0), iters=10) * 1e6, 1)
+            os.environ.pop("PASCO_CONV_CFG", None)
         t_ins = timeit(lambda: be.map_insert(coords, dedup=False))
         t_ins_d = timeit(lambda: be.map_insert(coords, dedup=True))
         tk, tv, _, _, _ = be.map_insert(coords, dedup=False)
