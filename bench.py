@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--heavy", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events")
+    ap.add_argument("--conv-precision", choices=["f32", "f16x3"], default="f32",
+                    help="f32 = exact fp32 MFMA (default, the headline); f16x3 = opt-in split-precision products")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,6 +142,8 @@ def main():
     from pasco_amd.graph.profiling import ConvProfiler
 
     be = hip_backend()   # raises if libpascohip.so is missing
+    from pasco_amd.graph import fused
+    fused.set_conv_precision(args.conv_precision)
     net = build_net(args.n_infers, args.in_channels, device, heavy=args.heavy)
     scene = make_scene(seed=rank, n_infers=args.n_infers, in_channels=args.in_channels).to(device)
     teacher = TeacherKeep(scene, device)
@@ -177,7 +181,9 @@ def main():
             "metric": "scenes/sec (256x256x32, ~10% occ) PaSCo MIMO-3",
             "value": round(value, 4), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if args.conv_precision == "f32" else "f32 (conv products as 3 x f16 split MFMA, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": f"PaSCo MIMO M={args.n_infers} ({'heavy' if args.heavy else 'light'} decoder, f=64, "
                                    f"100 queries, {args.in_channels}-ch points), S10 scene 256x256x32 "
                                    f"({int(scene.occ.sum())} occupied voxels, {n1} kept at stride 1), 1 scene/step/GPU",

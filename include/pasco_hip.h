@@ -139,6 +139,14 @@ typedef struct ph_conv_desc {
   int32_t reserved;
   const float *epi2_scale; /* [cout] second per-channel affine, applied after epi_act */
   const float *epi2_shift; /* [cout] */
+  /* matrix-core mode: 0 = fp32 MFMA (exact fp32, default); 1 = opt-in split precision: the product is
+   * formed as hi*hi + hi*lo + lo*hi of f16 halves with fp32 accumulation (fp32-class accuracy at ~5x less
+   * matrix-pipe time).  Mode 1 needs the weights pre-split, pre-transposed and pre-scaled:
+   * w_f16_hi / w_f16_lo = f16 [kvol, cout, cin] of (weight * 2^e); w_unscale = 2^-e; cin % 8 == 0. */
+  int32_t mma_mode;
+  float w_unscale;
+  const void *w_f16_hi;
+  const void *w_f16_lo;
 } ph_conv_desc;
 
 int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);

@@ -206,6 +206,7 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   if (!d) return fail("conv_fwd: null desc");
   if (d->cin <= 0 || d->cout <= 0 || d->kvol < 1 || d->kvol > 4096) return fail("conv_fwd: bad shape");
   if (d->n_out == 0) return 0;
+  /* mma_mode only selects how the device forms the products; the restatement is plain fp32 either way */
   if (!d->nbr && !(d->kvol == 1 && d->n_in == d->n_out)) return fail("conv_fwd: identity map needs kvol == 1");
   const int cin = d->cin, cout = d->cout;
   const int64_t n_out = d->n_out;

@@ -1,0 +1,306 @@
+// Sparse convolution forward, split-precision variant: fp32 operands are split into an f16 "hi" and an
+// f16 "lo" part and the product is formed as  hi*hi + hi*lo + lo*hi  on v_mfma_f32_32x32x16_f16 with
+// fp32 accumulation (the dropped lo*lo term is 2^-22 relative).  Three f16 MFMAs of K = 16 replace eight
+// fp32 MFMAs of K = 2: 5.3x less matrix-pipe time per contraction element at fp32-class accuracy
+// (measured against an fp64 reference in tests/test_hip_f16x3.py).
+//
+// OPT-IN (ph_conv_desc.mma_mode = 1).  Requirements: cin % 8 == 0, cout % 4 == 0, |activations| < 65504
+// (f16 range; the weights are pre-scaled by a power of two so that their lo parts stay normal, the
+// accumulator is unscaled in the epilogue).  Weights arrive pre-split and pre-transposed
+// ([K][cout][cin] f16 hi / lo, prepared once per layer by the host) so that both MFMA operands are
+// 16-byte contiguous k-runs in LDS.
+//
+// Structure = the fp32 kernel's (conv.hip): output-stationary tile, gather prologue, fused epilogue,
+// register-staged software pipeline, XCD-aware tile order.
+#include "ph_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HV_THREADS = 256;
+constexpr int HKC = 32;          // input channels per stage
+constexpr int H_LD = HKC + 8;    // f16 elements per LDS row (80 bytes: 16-byte aligned, conflict-free b128 reads)
+
+struct ConvArgsH {
+  const float *in;
+  const _Float16 *w_hi;   // [kvol][cout][cin]
+  const _Float16 *w_lo;
+  const int32_t *nbr;
+  float *out;
+  int64_t n_in, n_out;
+  int cin, cout, kvol;
+  const float *pro_scale, *pro_shift, *bias, *epi_scale, *epi_shift, *epi2_scale, *epi2_shift, *residual;
+  float pro_neg, epi_neg, res_neg, w_unscale;
+  int has_pro, has_tail;
+  int n_row_tiles, n_col_tiles;
+};
+
+__device__ __forceinline__ float h_act(float v, float neg) { return fmaxf(v, 0.f) + neg * fminf(v, 0.f); }
+
+template <int BM, int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
+  constexpr int BN = WN * TN * 32;
+  constexpr int A_PASSES = BM / 32;                      // 8 threads x float4 per 32-channel row chunk
+  constexpr int B_SLOTS = (BN * 4 + HV_THREADS - 1) / HV_THREADS;   // 16-byte (8 x f16) slots per thread, per hi / lo
+  static_assert(WM * WN == 4 && WM * TM * 32 == BM, "tile shape");
+  static_assert(B_SLOTS >= 1, "loader shape");
+
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[BM * H_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Al[BM * H_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Bh[BN * H_LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Bl[BN * H_LD];
+
+  const int nwg = gridDim.x;
+  const int cpx = nwg >> 3;
+  const int bid = blockIdx.x;
+  const int tile = (bid & 7) * cpx + (bid >> 3);
+  const int ntiles = a.n_row_tiles * a.n_col_tiles;
+  if (tile >= ntiles) return;
+  const int row_tile = tile / a.n_col_tiles;
+  const int col_tile = tile - row_tile * a.n_col_tiles;
+  const int64_t m0 = (int64_t)row_tile * BM;
+  const int n0 = col_tile * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int h = lane >> 5;
+  const int l31 = lane & 31;
+
+  const int cin = a.cin, cout = a.cout;
+  const int nchunks = (cin + HKC - 1) / HKC;
+  const int nstages = a.kvol * nchunks;
+  const int a_c4 = tid & 7;
+  const int a_r0 = tid >> 3;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[A_PASSES];
+  f16x8 rbh[B_SLOTS], rbl[B_SLOTS];
+  int idx_cur[A_PASSES], idx_nxt[A_PASSES];
+  int cur_c0 = 0;
+
+  auto load_idx = [&](int k, int *dst) {
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      const int64_t row = m0 + a_r0 + p * 32;
+      int idx = -1;
+      if (row < a.n_out) idx = a.nbr ? a.nbr[(int64_t)k * a.n_out + row] : (int)row;
+      dst[p] = idx;
+    }
+  };
+
+  auto load_stage = [&](int k, int c0) {
+    cur_c0 = c0;
+    const int cbase = c0 + a_c4 * 4;
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      const int idx = idx_cur[p];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx >= 0 && cbase < cin) v = *reinterpret_cast<const float4 *>(a.in + (int64_t)idx * cin + cbase);
+      ra[p] = v;
+    }
+    // weights: thread slot -> (output channel n, 8-channel segment of the 32-channel chunk)
+#pragma unroll
+    for (int q = 0; q < B_SLOTS; ++q) {
+      const int slot = tid + q * HV_THREADS;
+      const int n = slot >> 2, seg = slot & 3;
+      const int c = c0 + seg * 8;
+      f16x8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (slot < BN * 4 && n0 + n < cout && c < cin) {
+        const int64_t off = ((int64_t)k * cout + n0 + n) * cin + c;
+        vh = *reinterpret_cast<const f16x8 *>(a.w_hi + off);
+        vl = *reinterpret_cast<const f16x8 *>(a.w_lo + off);
+      }
+      rbh[q] = vh;
+      rbl[q] = vl;
+    }
+  };
+
+  auto store_stage = [&](unsigned valid) {
+    const int cbase = cur_c0 + a_c4 * 4;
+    float ps[4] = {1.f, 1.f, 1.f, 1.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.has_pro) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (cbase + j < cin) {
+          if (a.pro_scale) ps[j] = a.pro_scale[cbase + j];
+          if (a.pro_shift) pb[j] = a.pro_shift[cbase + j];
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      float v[4] = {ra[p].x, ra[p].y, ra[p].z, ra[p].w};
+      const bool ok = (valid >> p) & 1u;
+      f16x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = v[j];
+        if (a.has_pro) x = h_act(x * ps[j] + pb[j], a.pro_neg);
+        if (!ok || cbase + j >= cin) x = 0.f;
+        const _Float16 xh = (_Float16)x;
+        hi[j] = xh;
+        lo[j] = (_Float16)(x - (float)xh);
+      }
+      const int o = (a_r0 + p * 32) * H_LD + a_c4 * 4;
+      *reinterpret_cast<f16x4 *>(&Ah[o]) = hi;
+      *reinterpret_cast<f16x4 *>(&Al[o]) = lo;
+    }
+#pragma unroll
+    for (int q = 0; q < B_SLOTS; ++q) {
+      const int slot = tid + q * HV_THREADS;
+      const int n = slot >> 2, seg = slot & 3;
+      if (slot >= BN * 4) continue;
+      *reinterpret_cast<f16x8 *>(&Bh[n * H_LD + seg * 8]) = rbh[q];
+      *reinterpret_cast<f16x8 *>(&Bl[n * H_LD + seg * 8]) = rbl[q];
+    }
+  };
+
+  auto compute_stage = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < HKC / 16; ++ks) {
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int o = ((wm * TM + i) * 32 + l31) * H_LD + ks * 16 + h * 8;
+        ah[i] = *reinterpret_cast<const f16x8 *>(&Ah[o]);
+        al[i] = *reinterpret_cast<const f16x8 *>(&Al[o]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int o = ((wn * TN + j) * 32 + l31) * H_LD + ks * 16 + h * 8;
+        bh[j] = *reinterpret_cast<const f16x8 *>(&Bh[o]);
+        bl[j] = *reinterpret_cast<const f16x8 *>(&Bl[o]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  auto valid_bits = [&]() {
+    unsigned v = 0;
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) v |= (idx_cur[p] >= 0 ? 1u : 0u) << p;
+    return v;
+  };
+
+  load_idx(0, idx_cur);
+  if (a.kvol > 1) load_idx(1, idx_nxt);
+  load_stage(0, 0);
+  unsigned valid = valid_bits();
+  int k = 0, chunk = 0;
+  for (int s = 0; s < nstages; ++s) {
+    store_stage(valid);
+    __syncthreads();
+    if (s + 1 < nstages) {
+      if (++chunk == nchunks) {
+        chunk = 0;
+        ++k;
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) idx_cur[p] = idx_nxt[p];
+        if (k + 1 < a.kvol) load_idx(k + 1, idx_nxt);
+      }
+      load_stage(k, chunk * HKC);
+      valid = valid_bits();
+    }
+    compute_stage();
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + l31;
+    if (col >= cout) continue;
+    const float bias = a.bias ? a.bias[col] : 0.f;
+    const float es = a.epi_scale ? a.epi_scale[col] : 1.f;
+    const float eb = a.epi_shift ? a.epi_shift[col] : 0.f;
+    const float es2 = a.epi2_scale ? a.epi2_scale[col] : 1.f;
+    const float eb2 = a.epi2_shift ? a.epi2_shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= a.n_out) continue;
+        float v = acc[i][j][r] * a.w_unscale + bias;
+        v = h_act(v * es + eb, a.epi_neg);
+        if (a.has_tail) {
+          v = v * es2 + eb2;
+          if (a.residual) v += a.residual[row * cout + col];
+          v = h_act(v, a.res_neg);
+        }
+        a.out[row * cout + col] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int WM, int WN, int TM, int TN>
+static int launch_h(const ConvArgsH &a, hipStream_t st) {
+  constexpr int BN = WN * TN * 32;
+  ConvArgsH args = a;
+  args.n_row_tiles = (int)((a.n_out + BM - 1) / BM);
+  args.n_col_tiles = (a.cout + BN - 1) / BN;
+  const int ntiles = args.n_row_tiles * args.n_col_tiles;
+  const int grid = ((ntiles + 7) / 8) * 8;
+  hipLaunchKernelGGL((k_conv_f16x3<BM, WM, WN, TM, TN>), dim3(grid), dim3(HV_THREADS), 0, st, args);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+// called from ph_conv_fwd (conv.hip) when desc->mma_mode == 1
+int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
+  PH_REQUIRE(d->w_f16_hi && d->w_f16_lo, "conv_fwd(f16x3): pre-split weights missing");
+  PH_REQUIRE(d->cin % 8 == 0 && d->cout % 4 == 0, "conv_fwd(f16x3): needs cin %% 8 == 0 and cout %% 4 == 0");
+  PH_REQUIRE((((uintptr_t)d->in | (uintptr_t)d->w_f16_hi | (uintptr_t)d->w_f16_lo) & 15) == 0,
+             "conv_fwd(f16x3): 16-byte alignment");
+  ConvArgsH a;
+  a.in = d->in;
+  a.w_hi = (const _Float16 *)d->w_f16_hi;
+  a.w_lo = (const _Float16 *)d->w_f16_lo;
+  a.nbr = d->nbr;
+  a.out = d->out;
+  a.n_in = d->n_in;
+  a.n_out = d->n_out;
+  a.cin = d->cin;
+  a.cout = d->cout;
+  a.kvol = d->kvol;
+  a.pro_scale = d->pro_scale;
+  a.pro_shift = d->pro_shift;
+  a.bias = d->bias;
+  a.epi_scale = d->epi_scale;
+  a.epi_shift = d->epi_shift;
+  a.epi2_scale = d->epi2_scale;
+  a.epi2_shift = d->epi2_shift;
+  a.residual = d->residual;
+  auto neg_of = [&](int act) { return act == PH_ACT_RELU ? 0.f : (act == PH_ACT_LEAKY ? d->epi_slope : 1.f); };
+  a.pro_neg = neg_of(d->pro_act);
+  a.epi_neg = neg_of(d->epi_act);
+  a.res_neg = neg_of(d->res_act);
+  a.w_unscale = d->w_unscale;
+  a.has_pro = (d->pro_scale || d->pro_shift || d->pro_act != PH_ACT_NONE) ? 1 : 0;
+  a.has_tail = (d->residual || d->epi2_scale || d->epi2_shift || d->res_act != PH_ACT_NONE) ? 1 : 0;
+  a.n_row_tiles = a.n_col_tiles = 0;
+  const int bn = d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128);
+  const int64_t ncol = (d->cout + bn - 1) / bn;
+  if (bn == 32) return launch_h<128, 4, 1, 1, 1>(a, st);
+  if (bn == 64) return launch_h<64, 2, 2, 1, 1>(a, st);
+  if (((d->n_out + 63) / 64) * ncol < 2 * 256) return launch_h<32, 1, 4, 1, 1>(a, st);
+  return launch_h<64, 2, 2, 1, 2>(a, st);
+}

@@ -73,3 +73,6 @@ static inline int ph_is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 // dropped), and *n_keep.  ws needs ph_workspace_bytes(n).
 int ph_compact_flags(const uint8_t *flags, int64_t n, int32_t *keep_rows, int32_t *rank_of,
                      int32_t *n_keep, void *ws, int64_t ws_bytes, hipStream_t st);
+
+// split-precision convolution (conv_f16x3.hip), reached through ph_conv_fwd when desc->mma_mode == 1
+int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st);

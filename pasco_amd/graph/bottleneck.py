@@ -109,11 +109,21 @@ class SPCDense3Dv2(nn.Module):
         _, tables = self._grid_tables(dims, rows.device)
         n = rows.shape[0]
 
+        from . import fused
+
         def cbr(name, x):
             ks = self._KERNELS[name]
             scale, shift = fold_bn(getattr(self, self._BNS[name]))
-            return be.conv_fwd(x, self._row_weight(name), tables.get(ks), n, epi_scale=scale, epi_shift=shift,
-                               epi_act=ACT_RELU)
+            w = self._row_weight(name)
+            split = None
+            if fused.conv_precision() == "f16x3" and be.split_supported(w.shape[-2], w.shape[-1]):
+                hit = getattr(self, "_split_" + name, None)
+                if hit is None or hit[0] is not w:
+                    hit = (w, be.split_weight_f16(w))
+                    object.__setattr__(self, "_split_" + name, hit)
+                split = hit[1]
+            return be.conv_fwd(x, w, tables.get(ks), n, epi_scale=scale, epi_shift=shift, epi_act=ACT_RELU,
+                               split=split)
 
         x = rows.contiguous()
         x1 = cbr("a_conv1", x)

@@ -12,6 +12,33 @@ from ..me import SparseTensor
 from ..me.backend import ACT_LEAKY, ACT_NONE, ACT_RELU
 from ..me.modules import MinkowskiBatchNorm, _ConvBase
 
+_CONV_PRECISION = "f32"
+
+
+def set_conv_precision(mode: str) -> None:
+    """"f32" (default): every product on the exact fp32 MFMA.  "f16x3" (opt-in): convolutions whose shape
+    allows it (cin % 8 == 0, cout % 4 == 0) form their products as hi*hi + hi*lo + lo*hi of f16 halves
+    with fp32 accumulation (pasco_amd/csrc/conv_f16x3.hip) - fp32-class accuracy, ~5x less matrix-pipe time."""
+    global _CONV_PRECISION
+    assert mode in ("f32", "f16x3")
+    _CONV_PRECISION = mode
+
+
+def conv_precision() -> str:
+    return _CONV_PRECISION
+
+
+def split_weight(mod, be):
+    """Cached (hi, lo, unscale) f16 split of a conv module's kernel."""
+    w = mod.kernel
+    ver = (w._version, w.device)
+    hit = getattr(mod, "_ph_split", None)
+    if hit is None or hit[0] != ver:
+        hit = (ver, be.split_weight_f16(w))
+        object.__setattr__(mod, "_ph_split", hit)
+    return hit[1]
+
+
 def fold_bn(bn) -> Tuple[torch.Tensor, torch.Tensor]:
     """BatchNorm (eval) -> (scale, shift) with y = x * scale + shift. Cached per module version."""
     m = bn.bn if isinstance(bn, MinkowskiBatchNorm) else bn
@@ -51,11 +78,15 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     if epi2_bn is not None:
         e2s, e2b = fold_bn(epi2_bn)
     bias = mod.bias.detach().reshape(-1) if mod.bias is not None else None
-    out = mgr.backend().conv_fwd(
+    be = mgr.backend()
+    split = None
+    if _CONV_PRECISION == "f16x3" and be.split_supported(mod.in_channels, mod.out_channels):
+        split = split_weight(mod, be)
+    out = be.conv_fwd(
         x.F if x.F.is_contiguous() else x.F.contiguous(), mod.kernel.detach(), nbr, n_out, bias=bias,
         pro_scale=ps, pro_shift=pb, pro_act=pro_act, epi_scale=es, epi_shift=eb, epi_act=epi_act,
-        epi2_scale=e2s, epi2_shift=e2b, residual=residual, res_act=res_act, slope=slope)
+        epi2_scale=e2s, epi2_shift=e2b, residual=residual, res_act=res_act, slope=slope, split=split)
     return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
 
 
-__all__ = ["fold_bn", "conv", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]
+__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]

@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ("epi_act", _i32), ("epi_slope", C.c_float),
         ("residual", _vp), ("res_act", _i32), ("reserved", _i32),
         ("epi2_scale", _vp), ("epi2_shift", _vp),
+        ("mma_mode", _i32), ("w_unscale", C.c_float), ("w_f16_hi", _vp), ("w_f16_lo", _vp),
     ]
 
 
@@ -226,7 +227,7 @@ class CBackend:
     def conv_fwd(self, x: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tensor], n_out: int,
                  *, bias=None, pro_scale=None, pro_shift=None, pro_act=ACT_NONE, epi_scale=None,
                  epi_shift=None, epi_act=ACT_NONE, slope=0.01, residual=None, res_act=ACT_NONE,
-                 epi2_scale=None, epi2_shift=None,
+                 epi2_scale=None, epi2_shift=None, split=None,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._chk(x, torch.float32, "in")
         self._chk(weight, torch.float32, "weight")
@@ -262,9 +263,29 @@ class CBackend:
             if tuple(residual.shape) != (n_out, cout):
                 raise ValueError("conv: residual shape mismatch")
         d.residual = _ptr(residual)
+        if split is not None:      # (w_hi, w_lo, unscale) from split_weight_f16: opt-in f16x3 products
+            w_hi, w_lo, unscale = split
+            d.mma_mode, d.w_unscale, d.w_f16_hi, d.w_f16_lo = 1, float(unscale), _ptr(w_hi), _ptr(w_lo)
         rc = self.fn["conv_fwd"](C.byref(d), self.stream(x.device))
         self._check(rc, "conv_fwd")
         return out
+
+    @staticmethod
+    def split_weight_f16(weight: torch.Tensor):
+        """fp32 kernel [K, cin, cout] (or [cin, cout]) -> (hi, lo) f16 [K, cout, cin] of weight * 2^e and the
+        factor 2^-e.  e puts the largest magnitude just below 2^14 so that every lo part is a normal f16."""
+        w = weight.detach().float()
+        if w.dim() == 2:
+            w = w[None]
+        wmax = float(w.abs().max())
+        e = 0 if wmax == 0.0 else 13 - int(torch.frexp(torch.tensor(wmax))[1])
+        scaled = torch.ldexp(w, torch.tensor(e)).transpose(1, 2).contiguous()
+        hi = scaled.to(torch.float16)
+        lo = (scaled - hi.float()).to(torch.float16)
+        return hi.contiguous(), lo.contiguous(), float(2.0 ** (-e))
+
+    def split_supported(self, cin: int, cout: int) -> bool:
+        return self.device_type == "cuda" and cin % 8 == 0 and cout % 4 == 0
 
     def maxpool_fwd(self, x: torch.Tensor, nbr: torch.Tensor) -> torch.Tensor:
         self._chk(x, torch.float32, "in")
