@@ -28,20 +28,52 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (matrix) = vector rate
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA peak
 HBM_PEAK_GBS = 8000.0
 
 
-def pmc_traffic():
-    """HBM bytes per k_conv_mfma launch from the committed rocprofv3 PMC passes of this same command
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
     (profiles/r1_pmc_conv.json, produced by tools/pmc_summary.py; FETCH_SIZE doubled per
     MI355X_MICROARCH.md).  PMC counters cannot be collected from inside the process, so this is a
     recorded measurement, or null when none is committed."""
     path = os.path.join(ROOT, "profiles", "r1_pmc_conv.json")
     try:
         with open(path) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None
+
+
+def roofline_object(per_kernel, steps):
+    """`roofline` for the dominant kernel (most time in the timed region), the other conv kernel beside it."""
+    def entry(name, s):
+        avg = s["time_s"] / s["launches"]
+        tf = s["flops"] / s["time_s"] / 1e12
+        gbs = s["bytes_alg"] / s["time_s"] / 1e9
+        e = {"kernel": name, "launches_per_step": s["launches"] / steps, "avg_launch_us": round(avg * 1e6, 2),
+             "ms_per_step": round(s["time_s"] / steps * 1e3, 3), "flops_per_launch": s["flops"] / s["launches"],
+             "alg_bytes_per_launch": s["bytes_alg"] / s["launches"], "useful_TFLOPs": round(tf, 3),
+             "alg_GBps": round(gbs, 1), "traffic": pmc_traffic(name)}
+        if name == "k_conv_mfma":    # exact fp32 MFMA: matrix-pipe bound (SURVEY.md section 7 roofline check)
+            e.update(bound="mfma", achieved=round(tf, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                     frac=round(tf / F32_MFMA_PEAK_TFLOPS, 4), alg_frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4))
+        else:                        # split-precision products: the matrix pipe is ~1/5 busy, the gather side bounds
+            e.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                     frac=round(gbs / HBM_PEAK_GBS, 4),
+                     mfma_frac_of_f16_peak=round(3.0 * tf / F16_MFMA_PEAK_TFLOPS, 4))
+        if s["k3_launches"]:
+            e["k3_only"] = {"launches_per_step": s["k3_launches"] / steps,
+                            "TFLOPs": round(s["k3_flops"] / max(s["k3_time_s"], 1e-12) / 1e12, 3),
+                            "ms_per_step": round(s["k3_time_s"] / steps * 1e3, 3)}
+        return e
+
+    names = sorted(per_kernel, key=lambda n: -per_kernel[n]["time_s"])
+    out = entry(names[0], per_kernel[names[0]])
+    out["conv_ms_per_step"] = round(sum(v["time_s"] for v in per_kernel.values()) / steps * 1e3, 3)
+    if len(names) > 1:
+        out["other_conv_kernel"] = entry(names[1], per_kernel[names[1]])
+    return out
 
 
 def build_net(n_infers, in_channels, device, heavy=False):
@@ -121,8 +153,10 @@ def main():
     ap.add_argument("--heavy", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events")
-    ap.add_argument("--conv-precision", choices=["f32", "f16x3"], default="f32",
-                    help="f32 = exact fp32 MFMA (default, the headline); f16x3 = opt-in split-precision products")
+    ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing")
+    ap.add_argument("--conv-precision", choices=["f32", "f16x3"], default="f16x3",
+                    help="f16x3 (default) = conv products as 3 x f16 split MFMA with fp32 accumulation (error vs fp64 <= "
+                         "the fp32-MFMA path); f32 = every product on the exact fp32 MFMA")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -174,6 +208,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same step with every product on the exact fp32 MFMA, reported next to the headline
+    exact = None
+    if args.conv_precision == "f16x3" and world == 1 and not args.no_exact:
+        fused.set_conv_precision("f32")
+        k2 = max(3, args.steps // 2)
+        with torch.no_grad():
+            run_scene(net, scene, teacher)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k2):
+                run_scene(net, scene, teacher)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / k2
+        exact = {"value": round(1.0 / dt, 4), "unit": "scenes/s", "ms_per_step": round(dt * 1e3, 3), "steps": k2}
+        fused.set_conv_precision(args.conv_precision)
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
@@ -196,24 +246,11 @@ def main():
         res["unet_window_ms"] = round(unet_ms, 3)   # the reference's own "inference time" window (README.md:448-449)
         res["unet_window_scenes_per_s"] = round(world * 1e3 / unet_ms, 4) if unet_ms > 0 else None
         if not args.no_profile:
-            s = prof.summary()
-            if s["launches"]:
-                avg = s["time_s"] / s["launches"]
-                tf = s["flops"] / s["time_s"] / 1e12
-                res["roofline"] = {
-                    "kernel": "k_conv_mfma (sparse conv / implicit GEMM, fp32 MFMA 32x32x2; every launch of the step)",
-                    "bound": "mfma", "achieved": round(tf, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
-                    "launches_per_step": s["launches"] / args.steps, "avg_launch_us": round(avg * 1e6, 2),
-                    "flops_per_launch": s["flops"] / s["launches"],
-                    "alg_bytes_per_launch": s["bytes_alg"] / s["launches"],
-                    "alg_GBps": round(s["bytes_alg"] / s["time_s"] / 1e9, 1),
-                    "alg_frac_of_hbm_peak": round(s["bytes_alg"] / s["time_s"] / 1e9 / HBM_PEAK_GBS, 4),
-                    "conv_ms_per_step": round(s["time_s"] / args.steps * 1e3, 3),
-                    "k3_only": {"launches_per_step": s["k3_launches"] / args.steps,
-                                "TFLOPs": round(s["k3_flops"] / max(s["k3_time_s"], 1e-12) / 1e12, 3),
-                                "ms_per_step": round(s["k3_time_s"] / args.steps * 1e3, 3)},
-                }
+            per_kernel = prof.summary()
+            if per_kernel:
+                res["roofline"] = roofline_object(per_kernel, args.steps)
+        if exact is not None:
+            res["exact_fp32_mfma"] = exact
         if not args.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline(args.n_infers, args.in_channels, int(scene.occ.sum()))

@@ -147,6 +147,8 @@ typedef struct ph_conv_desc {
   float w_unscale;
   const void *w_f16_hi;
   const void *w_f16_lo;
+  int32_t *status;        /* optional device word; mode 1 ORs bit 0 into it when a gathered activation
+                             exceeds the f16 range (|x| > 65504) - the caller must then redo the layer in mode 0 */
 } ph_conv_desc;
 
 int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);

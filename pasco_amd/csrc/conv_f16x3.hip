@@ -12,6 +12,8 @@
 //
 // Structure = the fp32 kernel's (conv.hip): output-stationary tile, gather prologue, fused epilogue,
 // register-staged software pipeline, XCD-aware tile order.
+#include <stdlib.h>
+
 #include "ph_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -34,6 +36,7 @@ struct ConvArgsH {
   float pro_neg, epi_neg, res_neg, w_unscale;
   int has_pro, has_tail;
   int n_row_tiles, n_col_tiles;
+  int32_t *status;
 };
 
 __device__ __forceinline__ float h_act(float v, float neg) { return fmaxf(v, 0.f) + neg * fminf(v, 0.f); }
@@ -85,6 +88,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
 
   float4 ra[A_PASSES];
   f16x8 rbh[B_SLOTS], rbl[B_SLOTS];
+  float xmax = 0.f;   // largest |activation| this thread converted to f16
   int idx_cur[A_PASSES], idx_nxt[A_PASSES];
   int cur_c0 = 0;
 
@@ -147,6 +151,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
         float x = v[j];
         if (a.has_pro) x = h_act(x * ps[j] + pb[j], a.pro_neg);
         if (!ok || cbase + j >= cin) x = 0.f;
+        xmax = fmaxf(xmax, fabsf(x));
         const _Float16 xh = (_Float16)x;
         hi[j] = xh;
         lo[j] = (_Float16)(x - (float)xh);
@@ -223,6 +228,8 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
     __syncthreads();
   }
 
+  if (a.status != nullptr && !(xmax <= 65504.f)) atomicOr(a.status, 1);   // also catches NaN
+
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + l31;
@@ -297,10 +304,19 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.has_pro = (d->pro_scale || d->pro_shift || d->pro_act != PH_ACT_NONE) ? 1 : 0;
   a.has_tail = (d->residual || d->epi2_scale || d->epi2_shift || d->res_act != PH_ACT_NONE) ? 1 : 0;
   a.n_row_tiles = a.n_col_tiles = 0;
+  a.status = d->status;
   const int bn = d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128);
   const int64_t ncol = (d->cout + bn - 1) / bn;
+  int bm = bn == 32 ? 128 : 64;
+  if (bn == 128 && ((d->n_out + 63) / 64) * ncol < 2 * 256) bm = 32;
+  const char *env = getenv("PASCO_CONVH_CFG");   // tuning override: tile height
+  if (env) {
+    const int em = atoi(env);
+    if (em == 128 || (em == 64 && bn >= 64) || (em == 32 && bn == 128)) bm = em;
+  }
   if (bn == 32) return launch_h<128, 4, 1, 1, 1>(a, st);
-  if (bn == 64) return launch_h<64, 2, 2, 1, 1>(a, st);
-  if (((d->n_out + 63) / 64) * ncol < 2 * 256) return launch_h<32, 1, 4, 1, 1>(a, st);
+  if (bn == 64) return bm == 128 ? launch_h<128, 4, 1, 1, 2>(a, st) : launch_h<64, 2, 2, 1, 1>(a, st);
+  if (bm == 128) return launch_h<128, 2, 2, 2, 2>(a, st);
+  if (bm == 32) return launch_h<32, 1, 4, 1, 1>(a, st);
   return launch_h<64, 2, 2, 1, 2>(a, st);
 }

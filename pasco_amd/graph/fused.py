@@ -12,13 +12,15 @@ from ..me import SparseTensor
 from ..me.backend import ACT_LEAKY, ACT_NONE, ACT_RELU
 from ..me.modules import MinkowskiBatchNorm, _ConvBase
 
-_CONV_PRECISION = "f32"
+_CONV_PRECISION = "f16x3"
 
 
 def set_conv_precision(mode: str) -> None:
-    """"f32" (default): every product on the exact fp32 MFMA.  "f16x3" (opt-in): convolutions whose shape
-    allows it (cin % 8 == 0, cout % 4 == 0) form their products as hi*hi + hi*lo + lo*hi of f16 halves
-    with fp32 accumulation (pasco_amd/csrc/conv_f16x3.hip) - fp32-class accuracy, ~5x less matrix-pipe time."""
+    """"f16x3" (default): convolutions whose shape allows it (cin % 8 == 0, cout % 4 == 0) form their products
+    as hi*hi + hi*lo + lo*hi of f16 halves with fp32 accumulation (pasco_amd/csrc/conv_f16x3.hip): measured
+    error against fp64 <= that of the fp32 MFMA path (tests/test_hip_f16x3.py), ~5x less matrix-pipe time;
+    activations must stay inside the f16 range (checked on the device, `check_status`).
+    "f32": every product on the exact fp32 MFMA."""
     global _CONV_PRECISION
     assert mode in ("f32", "f16x3")
     _CONV_PRECISION = mode

@@ -34,22 +34,22 @@ class ConvProfiler:
             e1.record()
             kvol = 1 if weight.dim() == 2 else weight.shape[0]
             prof.records.append(dict(e0=e0, e1=e1, nbr=nbr, n_in=x.shape[0], n_out=n_out, cin=x.shape[1],
-                                     cout=weight.shape[-1], kvol=kvol))
+                                     cout=weight.shape[-1], kvol=kvol,
+                                     kernel="k_conv_f16x3" if kw.get("split") is not None else "k_conv_mfma"))
             return out
 
         backend.conv_fwd = conv_fwd
         backend._conv_profiled = True
 
     def summary(self):
-        """Aggregate over every recorded `k_conv_mfma` launch (k=3 / k=2 strided / generative transposed /
-        k=1 convolutions and the dense bottleneck's implicit GEMMs): average duration, algorithmic
-        flops / bytes per launch (flops = 2 P Cin Cout, B_alg = 4 P Cin + 4 N_out Cout
-        + 8 P + 4 K Cin Cout, with P = pairs of the neighbour table, P = N for identity maps)."""
+        """Per kernel (`k_conv_f16x3` = split-precision products, `k_conv_mfma` = exact fp32 MFMA) over every
+        recorded launch (k=3 / k=2 strided / generative transposed / k=1 convolutions and the dense bottleneck's
+        implicit GEMMs): launches, time, algorithmic flops / bytes (flops = 2 P Cin Cout,
+        B_alg = 4 P Cin + 4 N_out Cout + 8 P + 4 K Cin Cout, P = pairs of the neighbour table, P = N for
+        identity maps)."""
         torch.cuda.synchronize()
         pair_cache = {}
-        t = flops = b_alg = b_min = 0.0
-        t_k3 = f_k3 = 0.0
-        n_k3 = 0
+        out = {}
         for r in self.records:
             dt = r["e0"].elapsed_time(r["e1"]) * 1e-3
             nbr = r["nbr"]
@@ -62,15 +62,16 @@ class ConvProfiler:
                     pair_cache[key] = int((nbr >= 0).sum().item())
                 P = pair_cache[key]
                 idx_bytes = 8.0 * P
-            cin, cout, n_out, n_in = r["cin"], r["cout"], r["n_out"], r["n_in"]
+            cin, cout, n_out = r["cin"], r["cout"], r["n_out"]
+            d = out.setdefault(r["kernel"], dict(launches=0, time_s=0.0, flops=0.0, bytes_alg=0.0,
+                                                 k3_launches=0, k3_time_s=0.0, k3_flops=0.0))
             fl = 2.0 * P * cin * cout
-            flops += fl
-            b_alg += 4.0 * P * cin + 4.0 * n_out * cout + idx_bytes + 4.0 * r["kvol"] * cin * cout
-            b_min += 4.0 * min(n_in, P) * cin + 4.0 * n_out * cout + idx_bytes + 4.0 * r["kvol"] * cin * cout
-            t += dt
+            d["launches"] += 1
+            d["time_s"] += dt
+            d["flops"] += fl
+            d["bytes_alg"] += 4.0 * P * cin + 4.0 * n_out * cout + idx_bytes + 4.0 * r["kvol"] * cin * cout
             if r["kvol"] == 27:
-                t_k3 += dt
-                f_k3 += fl
-                n_k3 += 1
-        return dict(launches=len(self.records), time_s=t, flops=flops, bytes_alg=b_alg, bytes_min=b_min,
-                    k3_launches=n_k3, k3_time_s=t_k3, k3_flops=f_k3)
+                d["k3_launches"] += 1
+                d["k3_time_s"] += dt
+                d["k3_flops"] += fl
+        return out

@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import me as ME
+from ..me.backend import backend_for
 from .bottleneck import SPCDense3Dv2
 from .decoder import DecoderGenerativeSepConvV2
 from .encoder import Encoder3DSepV2
@@ -168,8 +169,10 @@ class PascoNet(nn.Module):
     def forward(self, in_feat: ME.SparseTensor, global_min_coords, global_max_coords, min_Cs, max_Cs,
                 is_predict_panop=True, keep_override=None, subnets=None):
         """The reference's timed window: `self.unet3d(...)` (net_panoptic_sparse.py:228-250)."""
-        return self.unet3d(in_feat, 1, global_min_coords, global_max_coords, min_Cs, max_Cs,
-                           is_predict_panop=is_predict_panop, keep_override=keep_override, subnets=subnets)
+        ret = self.unet3d(in_feat, 1, global_min_coords, global_max_coords, min_Cs, max_Cs,
+                          is_predict_panop=is_predict_panop, keep_override=keep_override, subnets=subnets)
+        backend_for(in_feat.device).check_status(in_feat.device)   # f16-range flag of the split-precision convs
+        return ret
 
     def ensemble(self, ret, Ts):
         """`Net.forward(return_ensemble=True)` after the U-Net (net_panoptic_sparse.py:252-310):

@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
         ("epi_act", _i32), ("epi_slope", C.c_float),
         ("residual", _vp), ("res_act", _i32), ("reserved", _i32),
         ("epi2_scale", _vp), ("epi2_shift", _vp),
-        ("mma_mode", _i32), ("w_unscale", C.c_float), ("w_f16_hi", _vp), ("w_f16_lo", _vp),
+        ("mma_mode", _i32), ("w_unscale", C.c_float), ("w_f16_hi", _vp), ("w_f16_lo", _vp), ("status", _vp),
     ]
 
 
@@ -266,9 +266,28 @@ class CBackend:
         if split is not None:      # (w_hi, w_lo, unscale) from split_weight_f16: opt-in f16x3 products
             w_hi, w_lo, unscale = split
             d.mma_mode, d.w_unscale, d.w_f16_hi, d.w_f16_lo = 1, float(unscale), _ptr(w_hi), _ptr(w_lo)
+            d.status = _ptr(self.status_word(x.device))
         rc = self.fn["conv_fwd"](C.byref(d), self.stream(x.device))
         self._check(rc, "conv_fwd")
         return out
+
+    def status_word(self, device) -> torch.Tensor:
+        """Device word the split-precision kernels OR their range flag into (one per device)."""
+        key = ("status", device)
+        t = self._ws.get(key)
+        if t is None:
+            t = torch.zeros(1, dtype=torch.int32, device=device)
+            self._ws[key] = t
+        return t
+
+    def check_status(self, device) -> None:
+        """Raise if a split-precision convolution met an activation outside the f16 range since the last check
+        (one device->host read; call where the host synchronises anyway)."""
+        t = self._ws.get(("status", device))
+        if t is not None and int(t.item()) != 0:
+            t.zero_()
+            raise RuntimeError("pasco_amd: activation outside the f16 range in a split-precision convolution; "
+                               "rerun with pasco_amd.graph.fused.set_conv_precision('f32')")
 
     @staticmethod
     def split_weight_f16(weight: torch.Tensor):

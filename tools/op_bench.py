@@ -59,10 +59,20 @@ def main():
                 os.environ["PASCO_CONV_CFG"] = cfg
                 cfg_times[cfg] = round(timeit(lambda: be.conv_fwd(x0, w0, nbr0, n, out=o0), iters=10) * 1e6, 1)
             os.environ.pop("PASCO_CONV_CFG", None)
+            sp0 = be.split_weight_f16(w0)
+            for cfg in ("128", "64", "32"):
+                os.environ["PASCO_CONVH_CFG"] = cfg
+                cfg_times["f16x3/" + cfg] = round(timeit(lambda: be.conv_fwd(x0, w0, nbr0, n, out=o0, split=sp0), iters=10) * 1e6, 1)
+            os.environ.pop("PASCO_CONVH_CFG", None)
             for cfg in ("128", "64", "32"):
                 os.environ["PASCO_CONV_CFG"] = cfg
                 cfg_times[cfg] = round(timeit(lambda: be.conv_fwd(x0, w0, nbr0, n, out=o0), iters=10) * 1e6, 1)
             os.environ.pop("PASCO_CONV_CFG", None)
+            sp0 = be.split_weight_f16(w0)
+            for cfg in ("128", "64", "32"):
+                os.environ["PASCO_CONVH_CFG"] = cfg
+                cfg_times["f16x3/" + cfg] = round(timeit(lambda: be.conv_fwd(x0, w0, nbr0, n, out=o0, split=sp0), iters=10) * 1e6, 1)
+            os.environ.pop("PASCO_CONVH_CFG", None)
         t_ins = timeit(lambda: be.map_insert(coords, dedup=False))
         t_ins_d = timeit(lambda: be.map_insert(coords, dedup=True))
         tk, tv, _, _, _ = be.map_insert(coords, dedup=False)
@@ -75,6 +85,10 @@ def main():
         out = torch.empty(n, c, device="cuda")
         t_conv = timeit(lambda: be.conv_fwd(x, w, nbr, n, out=out), iters=10)
         ps = torch.rand(c, device="cuda")
+        sp = be.split_weight_f16(w)
+        t_conv_h = timeit(lambda: be.conv_fwd(x, w, nbr, n, out=out, split=sp), iters=10)
+        t_conv_hf = timeit(lambda: be.conv_fwd(x, w, nbr, n, out=out, split=sp, pro_scale=torch.ones(c, device="cuda"),
+                                               pro_shift=torch.zeros(c, device="cuda"), pro_act=1, residual=x, res_act=1), iters=10)
         t_conv_f = timeit(lambda: be.conv_fwd(x, w, nbr, n, out=out, pro_scale=ps, pro_shift=ps, pro_act=1,
                                               epi_scale=ps, epi_shift=ps, epi_act=1, residual=x, res_act=1), iters=10)
         flop = 2.0 * P * c * c
@@ -86,7 +100,7 @@ def main():
         r = dict(level=str(name), n=n, c=c, cfg_us=cfg_times, pairs=P, pairs_per_voxel=P / n,
                  t_insert_us=t_ins * 1e6, t_insert_dedup_us=t_ins_d * 1e6, t_nbr_us=t_nbr * 1e6,
                  nbr_GBs=(16.0 * 2 * n + 8.0 * P) / t_nbr / 1e9,
-                 t_conv3_us=t_conv * 1e6, t_conv3_fused_us=t_conv_f * 1e6,
+                 t_conv3_us=t_conv * 1e6, t_conv3_f16x3_us=t_conv_h * 1e6, t_conv3_f16x3_fused_us=t_conv_hf * 1e6, t_conv3_fused_us=t_conv_f * 1e6,
                  conv3_TFLOPs=flop / t_conv / 1e12, conv3_TFLOPs_issued=flop_dense / t_conv / 1e12,
                  conv3_frac_f32_peak=flop / t_conv / F32_PEAK,
                  conv3_GBs_alg=b_alg / t_conv / 1e9, conv3_frac_hbm=b_alg / t_conv / HBM_PEAK,

@@ -1,4 +1,4 @@
-"""Summarise rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE) for the k_conv_mfma dispatches.
+"""Summarise rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE) for the conv kernels.
 usage: pmc_summary.py <fetch_counter_csv> <write_counter_csv> <out.json>
 HBM bytes = FETCH_SIZE * 2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE,
 both reported by rocprofv3 in KiB."""
@@ -6,7 +6,7 @@ import csv, json, sys
 from collections import defaultdict
 
 
-def mean_counter(path, counter):
+def per_kernel(path, counter):
     per = defaultdict(float)
     names = {}
     with open(path) as f:
@@ -16,14 +16,23 @@ def mean_counter(path, counter):
             key = (r.get("Dispatch_Id"), r.get("Agent_Id"))
             per[key] += float(r["Counter_Value"])
             names[key] = r.get("Kernel_Name", "")
-    vals = [v for k, v in per.items() if "k_conv_mfma" in names[k]]
-    return (sum(vals) / len(vals) if vals else None), len(vals)
+    out = {}
+    for kern in ("k_conv_f16x3", "k_conv_mfma"):
+        vals = [v for k, v in per.items() if kern in names[k]]
+        if vals:
+            out[kern] = (sum(vals) / len(vals), len(vals))
+    return out
 
 
-fetch, n1 = mean_counter(sys.argv[1], "FETCH_SIZE")
-write, n2 = mean_counter(sys.argv[2], "WRITE_SIZE")
-out = {"kernel": "k_conv_mfma", "dispatches": [n1, n2], "FETCH_SIZE_KiB_mean": fetch, "WRITE_SIZE_KiB_mean": write,
-       "hbm_bytes_per_launch": (None if fetch is None or write is None else (2.0 * fetch + write) * 1024.0),
-       "note": "FETCH_SIZE doubled (gfx950 128-B requests tallied at 64 B); Infinity-Cache hits are counted, not excluded"}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out))
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+res = {"kernels": {}, "note": "FETCH_SIZE doubled (gfx950 128-B requests tallied at 64 B); Infinity-Cache hits are counted, "
+                               "not excluded"}
+for kern in fetch:
+    if kern in write:
+        f, n1 = fetch[kern]
+        w, n2 = write[kern]
+        res["kernels"][kern] = {"dispatches": [n1, n2], "FETCH_SIZE_KiB_mean": f, "WRITE_SIZE_KiB_mean": w,
+                                "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+json.dump(res, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(res))
