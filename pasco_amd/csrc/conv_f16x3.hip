@@ -12,6 +12,7 @@
 //
 // Structure = the fp32 kernel's (conv.hip): output-stationary tile, gather prologue, fused epilogue,
 // register-staged software pipeline, XCD-aware tile order.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "ph_common.h"
@@ -21,8 +22,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HV_THREADS = 256;
-constexpr int HKC = 32;          // input channels per stage
-constexpr int H_LD = HKC + 8;    // f16 elements per LDS row (80 bytes: 16-byte aligned, conflict-free b128 reads)
+// KC input channels per stage (32 or 64); LDS rows hold KC + 8 f16 (80 / 144 bytes: 16-byte aligned and
+// conflict-free for the b128 fragment reads)
 
 struct ConvArgsH {
   const float *in;
@@ -41,11 +42,16 @@ struct ConvArgsH {
 
 __device__ __forceinline__ float h_act(float v, float neg) { return fmaxf(v, 0.f) + neg * fminf(v, 0.f); }
 
-template <int BM, int WM, int WN, int TM, int TN>
+template <int BM, int KC, int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
   constexpr int BN = WN * TN * 32;
-  constexpr int A_PASSES = BM / 32;                      // 8 threads x float4 per 32-channel row chunk
-  constexpr int B_SLOTS = (BN * 4 + HV_THREADS - 1) / HV_THREADS;   // 16-byte (8 x f16) slots per thread, per hi / lo
+  constexpr int HKC = KC;
+  constexpr int H_LD = KC + 8;
+  constexpr int A_TPR = KC / 4;                          // threads x float4 per row chunk
+  constexpr int A_RPP = HV_THREADS / A_TPR;              // rows per pass
+  constexpr int A_PASSES = BM / A_RPP;
+  constexpr int B_SPR = KC / 8;                          // 16-byte (8 x f16) slots per weight row
+  constexpr int B_SLOTS = (BN * B_SPR + HV_THREADS - 1) / HV_THREADS;   // per thread, per hi / lo
   static_assert(WM * WN == 4 && WM * TM * 32 == BM, "tile shape");
   static_assert(B_SLOTS >= 1, "loader shape");
 
@@ -75,8 +81,8 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
   const int cin = a.cin, cout = a.cout;
   const int nchunks = (cin + HKC - 1) / HKC;
   const int nstages = a.kvol * nchunks;
-  const int a_c4 = tid & 7;
-  const int a_r0 = tid >> 3;
+  const int a_c4 = tid % A_TPR;
+  const int a_r0 = tid / A_TPR;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -95,7 +101,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
   auto load_idx = [&](int k, int *dst) {
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
-      const int64_t row = m0 + a_r0 + p * 32;
+      const int64_t row = m0 + a_r0 + p * A_RPP;
       int idx = -1;
       if (row < a.n_out) idx = a.nbr ? a.nbr[(int64_t)k * a.n_out + row] : (int)row;
       dst[p] = idx;
@@ -116,10 +122,10 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
 #pragma unroll
     for (int q = 0; q < B_SLOTS; ++q) {
       const int slot = tid + q * HV_THREADS;
-      const int n = slot >> 2, seg = slot & 3;
+      const int n = slot / B_SPR, seg = slot % B_SPR;
       const int c = c0 + seg * 8;
       f16x8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (slot < BN * 4 && n0 + n < cout && c < cin) {
+      if (slot < BN * B_SPR && n0 + n < cout && c < cin) {
         const int64_t off = ((int64_t)k * cout + n0 + n) * cin + c;
         vh = *reinterpret_cast<const f16x8 *>(a.w_hi + off);
         vl = *reinterpret_cast<const f16x8 *>(a.w_lo + off);
@@ -156,15 +162,15 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
         hi[j] = xh;
         lo[j] = (_Float16)(x - (float)xh);
       }
-      const int o = (a_r0 + p * 32) * H_LD + a_c4 * 4;
+      const int o = (a_r0 + p * A_RPP) * H_LD + a_c4 * 4;
       *reinterpret_cast<f16x4 *>(&Ah[o]) = hi;
       *reinterpret_cast<f16x4 *>(&Al[o]) = lo;
     }
 #pragma unroll
     for (int q = 0; q < B_SLOTS; ++q) {
       const int slot = tid + q * HV_THREADS;
-      const int n = slot >> 2, seg = slot & 3;
-      if (slot >= BN * 4) continue;
+      const int n = slot / B_SPR, seg = slot % B_SPR;
+      if (slot >= BN * B_SPR) continue;
       *reinterpret_cast<f16x8 *>(&Bh[n * H_LD + seg * 8]) = rbh[q];
       *reinterpret_cast<f16x8 *>(&Bl[n * H_LD + seg * 8]) = rbl[q];
     }
@@ -258,7 +264,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
   }
 }
 
-template <int BM, int WM, int WN, int TM, int TN>
+template <int BM, int KC, int WM, int WN, int TM, int TN>
 static int launch_h(const ConvArgsH &a, hipStream_t st) {
   constexpr int BN = WN * TN * 32;
   ConvArgsH args = a;
@@ -266,7 +272,7 @@ static int launch_h(const ConvArgsH &a, hipStream_t st) {
   args.n_col_tiles = (a.cout + BN - 1) / BN;
   const int ntiles = args.n_row_tiles * args.n_col_tiles;
   const int grid = ((ntiles + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_conv_f16x3<BM, WM, WN, TM, TN>), dim3(grid), dim3(HV_THREADS), 0, st, args);
+  hipLaunchKernelGGL((k_conv_f16x3<BM, KC, WM, WN, TM, TN>), dim3(grid), dim3(HV_THREADS), 0, st, args);
   PH_LAUNCH_CHECK();
   return 0;
 }
@@ -307,16 +313,32 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.status = d->status;
   const int bn = d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128);
   const int64_t ncol = (d->cout + bn - 1) / bn;
-  int bm = bn == 32 ? 128 : 64;
-  if (bn == 128 && ((d->n_out + 63) / 64) * ncol < 2 * 256) bm = 32;
-  const char *env = getenv("PASCO_CONVH_CFG");   // tuning override: tile height
+  // tile height: the tallest tile that still gives >= 2 workgroups per CU (profiles/r1e_op_bench.json)
+  int bm = 128;
+  if (bn >= 64 && ((d->n_out + 127) / 128) * ncol < 2 * 256) bm = 64;
+  if (bn == 128 && bm == 64 && ((d->n_out + 63) / 64) * ncol < 2 * 256) bm = 32;
+  int kc = (d->cin % 64 == 0) ? 64 : 32;
+  const char *env = getenv("PASCO_CONVH_CFG");   // tuning override: "bm,kc"
   if (env) {
-    const int em = atoi(env);
-    if (em == 128 || (em == 64 && bn >= 64) || (em == 32 && bn == 128)) bm = em;
+    int em = 0, ek = 0;
+    if (sscanf(env, "%d,%d", &em, &ek) >= 1) {
+      if (em == 128 || (em == 64 && bn >= 64) || (em == 32 && bn == 128)) bm = em;
+      if (ek == 32 || ek == 64) kc = ek;
+    }
   }
-  if (bn == 32) return launch_h<128, 4, 1, 1, 1>(a, st);
-  if (bn == 64) return bm == 128 ? launch_h<128, 4, 1, 1, 2>(a, st) : launch_h<64, 2, 2, 1, 1>(a, st);
-  if (bm == 128) return launch_h<128, 2, 2, 2, 2>(a, st);
-  if (bm == 32) return launch_h<32, 1, 4, 1, 1>(a, st);
-  return launch_h<64, 2, 2, 1, 2>(a, st);
+#define PH_H_CASE(BM_, WM_, WN_, TM_, TN_)                                                          \
+  if (bm == BM_) return kc == 64 ? launch_h<BM_, 64, WM_, WN_, TM_, TN_>(a, st) : launch_h<BM_, 32, WM_, WN_, TM_, TN_>(a, st)
+  if (bn == 32) {
+    PH_H_CASE(128, 4, 1, 1, 1);
+  } else if (bn == 64) {
+    PH_H_CASE(128, 4, 1, 1, 2);
+    PH_H_CASE(64, 2, 2, 1, 1);
+  } else {
+    PH_H_CASE(128, 2, 2, 2, 2);
+    PH_H_CASE(64, 2, 2, 1, 2);
+    PH_H_CASE(32, 1, 4, 1, 1);
+  }
+#undef PH_H_CASE
+  ph_set_error("conv_fwd(f16x3): no kernel for bm=%d bn=%d", bm, bn);
+  return 1;
 }

@@ -60,7 +60,7 @@ def main():
                 cfg_times[cfg] = round(timeit(lambda: be.conv_fwd(x0, w0, nbr0, n, out=o0), iters=10) * 1e6, 1)
             os.environ.pop("PASCO_CONV_CFG", None)
             sp0 = be.split_weight_f16(w0)
-            for cfg in ("128", "64", "32"):
+            for cfg in ("128,32", "128,64", "64,32", "64,64", "32,32", "32,64"):
                 os.environ["PASCO_CONVH_CFG"] = cfg
                 cfg_times["f16x3/" + cfg] = round(timeit(lambda: be.conv_fwd(x0, w0, nbr0, n, out=o0, split=sp0), iters=10) * 1e6, 1)
             os.environ.pop("PASCO_CONVH_CFG", None)
@@ -69,7 +69,7 @@ def main():
                 cfg_times[cfg] = round(timeit(lambda: be.conv_fwd(x0, w0, nbr0, n, out=o0), iters=10) * 1e6, 1)
             os.environ.pop("PASCO_CONV_CFG", None)
             sp0 = be.split_weight_f16(w0)
-            for cfg in ("128", "64", "32"):
+            for cfg in ("128,32", "128,64", "64,32", "64,64", "32,32", "32,64"):
                 os.environ["PASCO_CONVH_CFG"] = cfg
                 cfg_times["f16x3/" + cfg] = round(timeit(lambda: be.conv_fwd(x0, w0, nbr0, n, out=o0, split=sp0), iters=10) * 1e6, 1)
             os.environ.pop("PASCO_CONVH_CFG", None)
