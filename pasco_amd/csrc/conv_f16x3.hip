@@ -317,7 +317,7 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   int bm = 128;
   if (bn >= 64 && ((d->n_out + 127) / 128) * ncol < 2 * 256) bm = 64;
   if (bn == 128 && bm == 64 && ((d->n_out + 63) / 64) * ncol < 2 * 256) bm = 32;
-  int kc = (d->cin % 64 == 0) ? 64 : 32;
+  int kc = (d->cin % 64 == 0 && d->cin >= 256) ? 64 : 32;   // deeper stages pay only for wide layers (profiles/r1f_op_bench.json)
   const char *env = getenv("PASCO_CONVH_CFG");   // tuning override: "bm,kc"
   if (env) {
     int em = 0, ek = 0;
