@@ -41,6 +41,32 @@ def split_weight(mod, be):
     return hit[1]
 
 
+def linear_rows(x2d: torch.Tensor, weight: torch.Tensor, bias, cache_owner, cache_key: str,
+                min_rows: int = 16384) -> torch.Tensor:
+    """y = x @ weight.T + bias for a tall [N, cin] operand (`weight` is an nn.Linear-style [cout, cin] tensor
+    or a row slice of one).  Large N on the GPU goes through the convolution kernel as an identity-map k=1
+    convolution - the same split-precision MFMA GEMM with fused bias - instead of an fp32 library GEMM;
+    everything else (small N, CPU checker backend, odd shapes) is torch.nn.functional.linear."""
+    n, cin = x2d.shape
+    cout = weight.shape[0]
+    be = None
+    if x2d.is_cuda and n >= min_rows and _CONV_PRECISION == "f16x3":
+        from ..me.backend import backend_for
+        be = backend_for(x2d.device)
+        if not be.split_supported(cin, cout):
+            be = None
+    if be is None:
+        return torch.nn.functional.linear(x2d, weight, bias)
+    ver = (weight._version, weight.device, weight.data_ptr())
+    hit = cache_owner.__dict__.get("_ph_lin_" + cache_key)
+    if hit is None or hit[0] != ver:
+        wt = weight.detach().t().contiguous()                     # [cin, cout]
+        hit = (ver, wt, be.split_weight_f16(wt), bias.detach().contiguous() if bias is not None else None)
+        cache_owner.__dict__["_ph_lin_" + cache_key] = hit
+    _, wt, split, b = hit
+    return be.conv_fwd(x2d.contiguous(), wt, None, n, bias=b, split=split)
+
+
 def fold_bn(bn) -> Tuple[torch.Tensor, torch.Tensor]:
     """BatchNorm (eval) -> (scale, shift) with y = x * scale + shift. Cached per module version."""
     m = bn.bn if isinstance(bn, MinkowskiBatchNorm) else bn
@@ -91,4 +117,4 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
 
 
-__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]
+__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "linear_rows", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from .. import me as ME
 from ..me.backend import backend_for
+from .fused import conv_precision, linear_rows
 
 
 def sine_position_encoding(coords: torch.Tensor, num_pos_feats: int, temperature: float = 10000.0,
@@ -89,8 +90,10 @@ class CrossAttentionLayer(nn.Module):
         H = self.nhead
         w, b = mha.in_proj_weight, mha.in_proj_bias
         qq = F.linear(q if query_pos is None else q + query_pos, w[:D], b[:D])
-        kk = F.linear(kv, w[D:2 * D], b[D:2 * D])
-        vv = F.linear(kv, w[2 * D:], b[2 * D:])
+        N = kv.shape[1]
+        kv2 = kv.reshape(B * N, D)
+        kk = linear_rows(kv2, w[D:2 * D], b[D:2 * D], self, "k").view(B, N, D)
+        vv = linear_rows(kv2, w[2 * D:], b[2 * D:], self, "v").view(B, N, D)
         qq = qq.view(B, Q, H, D // H).transpose(1, 2)
         if mask_bits is not None:
             be = backend_for(q.device)
@@ -170,7 +173,20 @@ class TransformerPredictorV2(nn.Module):
         d = self.decoder_norm(output)
         outputs_class = self.class_embed(d)
         mask_embed = self.mask_embed(d)                                   # [B,Q,D]
-        outputs_mask = torch.matmul(mask_features, mask_embed.transpose(1, 2))   # [B,P,Q]
+        B, P, D = mask_features.shape
+        Q = mask_embed.shape[1]
+        be = backend_for(mask_features.device) if mask_features.is_cuda else None
+        if be is not None and P >= 16384 and conv_precision() == "f16x3" and be.split_supported(D, Q):
+            # [P, D] x [D, Q] per subnet on the split-precision MFMA GEMM (identity-map k=1 convolution);
+            # the per-call operand (|mask_embed| = O(1..100)) is split without the magnitude read-back
+            outs = []
+            for b in range(B):
+                wt = mask_embed[b].t().contiguous()                         # [D, Q]
+                outs.append(be.conv_fwd(mask_features[b].contiguous(), wt, None, P,
+                                        split=be.split_weight_f16(wt, exponent=4)))
+            outputs_mask = torch.stack(outs, dim=0)
+        else:
+            outputs_mask = torch.matmul(mask_features, mask_embed.transpose(1, 2))   # [B,P,Q]
         return outputs_class, outputs_mask
 
     # -- attention mask -----------------------------------------------------------------------------
@@ -248,13 +264,16 @@ class TransformerPredictorV2(nn.Module):
             src_Cs.append(c)
             pos.append(self.pe_layer(c.reshape(-1, 4)[:, 1:]).reshape(B, -1, D))
         voxel_coord = xs[1][1]
-        voxel_feat = self.mask_feat_proj(xs[1][0]) + pos[-1]
+        x1 = xs[1][0]
+        voxel_feat = linear_rows(x1.reshape(-1, x1.shape[-1]), self.mask_feat_proj.weight, self.mask_feat_proj.bias,
+                                 self.mask_feat_proj, "w").view(B, -1, D) + pos[-1]
         predictions_class, predictions_mask = [], []
         oc, om = self.pred_heads(output, voxel_feat)
         predictions_class.append(oc)
         predictions_mask.append(om)
         for i in range(self.num_layers):
-            src_F = self.input_projs[i](srcs[i])
+            lin = self.input_projs[i]
+            src_F = linear_rows(srcs[i].reshape(-1, srcs[i].shape[-1]), lin.weight, lin.bias, lin, "w").view(B, -1, D)
             bits, any_ = self.compute_mask_bits(om, voxel_coord, src_Cs[i], self.src_scales[i], min_Cs, max_Cs)
             N_i, Qn = src_F.shape[1], om.shape[2]
             be = backend_for(src_F.device)

@@ -290,14 +290,19 @@ class CBackend:
                                "rerun with pasco_amd.graph.fused.set_conv_precision('f32')")
 
     @staticmethod
-    def split_weight_f16(weight: torch.Tensor):
+    def split_weight_f16(weight: torch.Tensor, exponent=None):
         """fp32 kernel [K, cin, cout] (or [cin, cout]) -> (hi, lo) f16 [K, cout, cin] of weight * 2^e and the
-        factor 2^-e.  e puts the largest magnitude just below 2^14 so that every lo part is a normal f16."""
+        factor 2^-e.  e puts the largest magnitude just below 2^14 so that every lo part is a normal f16
+        (one device->host read; static weights are split once and cached).  Pass `exponent` to skip the
+        read for per-call operands of known magnitude."""
         w = weight.detach().float()
         if w.dim() == 2:
             w = w[None]
-        wmax = float(w.abs().max())
-        e = 0 if wmax == 0.0 else 13 - int(torch.frexp(torch.tensor(wmax))[1])
+        if exponent is not None:
+            e = int(exponent)
+        else:
+            wmax = float(w.abs().max())
+            e = 0 if wmax == 0.0 else 13 - int(torch.frexp(torch.tensor(wmax))[1])
         scaled = torch.ldexp(w, torch.tensor(e)).transpose(1, 2).contiguous()
         hi = scaled.to(torch.float16)
         lo = (scaled - hi.float()).to(torch.float16)
