@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from .. import me as ME
 from ..me.backend import backend_for
-from .fused import conv_precision, linear_rows
+from .fused import linear_rows
 
 
 def sine_position_encoding(coords: torch.Tensor, num_pos_feats: int, temperature: float = 10000.0,
@@ -173,20 +173,7 @@ class TransformerPredictorV2(nn.Module):
         d = self.decoder_norm(output)
         outputs_class = self.class_embed(d)
         mask_embed = self.mask_embed(d)                                   # [B,Q,D]
-        B, P, D = mask_features.shape
-        Q = mask_embed.shape[1]
-        be = backend_for(mask_features.device) if mask_features.is_cuda else None
-        if be is not None and P >= 16384 and conv_precision() == "f16x3" and be.split_supported(D, Q):
-            # [P, D] x [D, Q] per subnet on the split-precision MFMA GEMM (identity-map k=1 convolution);
-            # the per-call operand (|mask_embed| = O(1..100)) is split without the magnitude read-back
-            outs = []
-            for b in range(B):
-                wt = mask_embed[b].t().contiguous()                         # [D, Q]
-                outs.append(be.conv_fwd(mask_features[b].contiguous(), wt, None, P,
-                                        split=be.split_weight_f16(wt, exponent=4)))
-            outputs_mask = torch.stack(outs, dim=0)
-        else:
-            outputs_mask = torch.matmul(mask_features, mask_embed.transpose(1, 2))   # [B,P,Q]
+        outputs_mask = torch.matmul(mask_features, mask_embed.transpose(1, 2))   # [B,P,Q]
         return outputs_class, outputs_mask
 
     # -- attention mask -----------------------------------------------------------------------------
