@@ -147,6 +147,9 @@ typedef struct ph_conv_desc {
   float w_unscale;
   const void *w_f16_hi;
   const void *w_f16_lo;
+  void *splitk_ws;        /* optional scratch for mode 1: few-row layers may split the kernel offsets over
+                             several workgroups and reduce [splits, n_out, cout] partial sums in a fixed order */
+  int64_t splitk_ws_bytes;
   int32_t *status;        /* optional device word; mode 1 ORs bit 0 into it when a gathered activation
                              exceeds the f16 range (|x| > 65504) - the caller must then redo the layer in mode 0 */
 } ph_conv_desc;

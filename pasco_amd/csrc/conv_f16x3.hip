@@ -38,6 +38,8 @@ struct ConvArgsH {
   int has_pro, has_tail;
   int n_row_tiles, n_col_tiles;
   int32_t *status;
+  int ksplit;       // > 1: blockIdx.y walks one slice of the kernel offsets and stores raw partial sums
+  float *partial;   // [ksplit][n_out][cout]
 };
 
 __device__ __forceinline__ float h_act(float v, float neg) { return fmaxf(v, 0.f) + neg * fminf(v, 0.f); }
@@ -80,7 +82,11 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
 
   const int cin = a.cin, cout = a.cout;
   const int nchunks = (cin + HKC - 1) / HKC;
-  const int nstages = a.kvol * nchunks;
+  // split-K over the kernel offsets (few-row layers: the dense bottleneck's 245 offsets on 6.7 k rows)
+  const int kper = (a.kvol + a.ksplit - 1) / a.ksplit;
+  const int k_begin = (int)blockIdx.y * kper;
+  const int k_end = (k_begin + kper < a.kvol) ? k_begin + kper : a.kvol;
+  const int nstages = (k_end > k_begin ? k_end - k_begin : 0) * nchunks;
   const int a_c4 = tid % A_TPR;
   const int a_r0 = tid / A_TPR;
 
@@ -211,11 +217,13 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
     return v;
   };
 
-  load_idx(0, idx_cur);
-  if (a.kvol > 1) load_idx(1, idx_nxt);
-  load_stage(0, 0);
+  if (nstages > 0) {
+    load_idx(k_begin, idx_cur);
+    if (k_begin + 1 < k_end) load_idx(k_begin + 1, idx_nxt);
+    load_stage(k_begin, 0);
+  }
   unsigned valid = valid_bits();
-  int k = 0, chunk = 0;
+  int k = k_begin, chunk = 0;
   for (int s = 0; s < nstages; ++s) {
     store_stage(valid);
     __syncthreads();
@@ -225,7 +233,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
         ++k;
 #pragma unroll
         for (int p = 0; p < A_PASSES; ++p) idx_cur[p] = idx_nxt[p];
-        if (k + 1 < a.kvol) load_idx(k + 1, idx_nxt);
+        if (k + 1 < k_end) load_idx(k + 1, idx_nxt);
       }
       load_stage(k, chunk * HKC);
       valid = valid_bits();
@@ -235,6 +243,23 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
   }
 
   if (a.status != nullptr && !(xmax <= 65504.f)) atomicOr(a.status, 1);   // also catches NaN
+
+  if (a.ksplit > 1) {   // raw partial sums; k_splitk_epilogue reduces them in a fixed order
+    float *part = a.partial + (int64_t)blockIdx.y * a.n_out * cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + l31;
+      if (col >= cout) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < a.n_out) part[row * cout + col] = acc[i][j][r];
+        }
+    }
+    return;
+  }
 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -264,6 +289,24 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
   }
 }
 
+// out = epilogue( sum_s partial[s] )  - one thread per output element, splits summed in index order
+__global__ void __launch_bounds__(256) k_splitk_epilogue(ConvArgsH a) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = a.n_out * a.cout;
+  if (t >= total) return;
+  const int col = (int)(t % a.cout);
+  float acc = 0.f;
+  for (int s = 0; s < a.ksplit; ++s) acc += a.partial[(int64_t)s * total + t];
+  float v = acc * a.w_unscale + (a.bias ? a.bias[col] : 0.f);
+  v = h_act(v * (a.epi_scale ? a.epi_scale[col] : 1.f) + (a.epi_shift ? a.epi_shift[col] : 0.f), a.epi_neg);
+  if (a.has_tail) {
+    v = v * (a.epi2_scale ? a.epi2_scale[col] : 1.f) + (a.epi2_shift ? a.epi2_shift[col] : 0.f);
+    if (a.residual) v += a.residual[t];
+    v = h_act(v, a.res_neg);
+  }
+  a.out[t] = v;
+}
+
 template <int BM, int KC, int WM, int WN, int TM, int TN>
 static int launch_h(const ConvArgsH &a, hipStream_t st) {
   constexpr int BN = WN * TN * 32;
@@ -272,8 +315,13 @@ static int launch_h(const ConvArgsH &a, hipStream_t st) {
   args.n_col_tiles = (a.cout + BN - 1) / BN;
   const int ntiles = args.n_row_tiles * args.n_col_tiles;
   const int grid = ((ntiles + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_conv_f16x3<BM, KC, WM, WN, TM, TN>), dim3(grid), dim3(HV_THREADS), 0, st, args);
+  hipLaunchKernelGGL((k_conv_f16x3<BM, KC, WM, WN, TM, TN>), dim3(grid, args.ksplit), dim3(HV_THREADS), 0, st, args);
   PH_LAUNCH_CHECK();
+  if (args.ksplit > 1) {
+    const int64_t total = a.n_out * a.cout;
+    hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, args);
+    PH_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -324,6 +372,22 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
     if (sscanf(env, "%d,%d", &em, &ek) >= 1) {
       if (em == 128 || (em == 64 && bn >= 64) || (em == 32 && bn == 128)) bm = em;
       if (ek == 32 || ek == 64) kc = ek;
+    }
+  }
+  // split-K over the kernel offsets when even the chosen tiling leaves CUs idle and there are offsets to share;
+  // the caller provides the partial-sum scratch (desc->splitk_ws), else no split
+  a.ksplit = 1;
+  a.partial = nullptr;
+  {
+    const int64_t tiles = ((d->n_out + bm - 1) / bm) * ncol;
+    int want = (int)(768 / (tiles > 0 ? tiles : 1));
+    if (want > 8) want = 8;
+    if (want > d->kvol / 8) want = d->kvol / 8;
+    const char *se = getenv("PASCO_CONVH_KSPLIT");
+    if (se) want = atoi(se);
+    if (want > 1 && d->splitk_ws != nullptr && d->splitk_ws_bytes >= (int64_t)want * d->n_out * d->cout * 4) {
+      a.ksplit = want;
+      a.partial = (float *)d->splitk_ws;
     }
   }
 #define PH_H_CASE(BM_, WM_, WN_, TM_, TN_)                                                          \

@@ -37,7 +37,8 @@ class ConvDesc(C.Structure):
         ("epi_act", _i32), ("epi_slope", C.c_float),
         ("residual", _vp), ("res_act", _i32), ("reserved", _i32),
         ("epi2_scale", _vp), ("epi2_shift", _vp),
-        ("mma_mode", _i32), ("w_unscale", C.c_float), ("w_f16_hi", _vp), ("w_f16_lo", _vp), ("status", _vp),
+        ("mma_mode", _i32), ("w_unscale", C.c_float), ("w_f16_hi", _vp), ("w_f16_lo", _vp),
+        ("splitk_ws", _vp), ("splitk_ws_bytes", _i64), ("status", _vp),
     ]
 
 
@@ -267,6 +268,14 @@ class CBackend:
             w_hi, w_lo, unscale = split
             d.mma_mode, d.w_unscale, d.w_f16_hi, d.w_f16_lo = 1, float(unscale), _ptr(w_hi), _ptr(w_lo)
             d.status = _ptr(self.status_word(x.device))
+            if n_out * cout <= (1 << 23):          # few-row layer: offer scratch for a split over the offsets
+                need = 8 * n_out * cout * 4
+                key = ("splitk", x.device)
+                sk = self._ws.get(key)
+                if sk is None or sk.numel() < need:
+                    sk = torch.empty(need, dtype=torch.uint8, device=x.device)
+                    self._ws[key] = sk
+                d.splitk_ws, d.splitk_ws_bytes = _ptr(sk), sk.numel()
         rc = self.fn["conv_fwd"](C.byref(d), self.stream(x.device))
         self._check(rc, "conv_fwd")
         return out
