@@ -374,18 +374,25 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
       if (ek == 32 || ek == 64) kc = ek;
     }
   }
-  // split-K over the kernel offsets when even the chosen tiling leaves CUs idle and there are offsets to share;
-  // the caller provides the partial-sum scratch (desc->splitk_ws), else no split
+  // Few-row layers (dense bottleneck: 245 offsets on 6.7 k rows; stride-4/8 layers): every workgroup streams
+  // the whole W[k] slab sequence from L2, so small row tiles multiply the weight traffic.  Keep the tall
+  // 128-row tile and get the parallelism from a split over the kernel offsets instead (partial sums reduced
+  // in a fixed order by k_splitk_epilogue).  The caller provides the scratch (desc->splitk_ws), else no split.
   a.ksplit = 1;
   a.partial = nullptr;
   {
-    const int64_t tiles = ((d->n_out + bm - 1) / bm) * ncol;
-    int want = (int)(768 / (tiles > 0 ? tiles : 1));
-    if (want > 8) want = 8;
-    if (want > d->kvol / 8) want = d->kvol / 8;
     const char *se = getenv("PASCO_CONVH_KSPLIT");
+    const int64_t t128 = ((d->n_out + 127) / 128) * ncol;
+    int want = (int)(2048 / (t128 > 0 ? t128 : 1));
+    if (want > 8) want = 8;
+    if (want > d->kvol / 4) want = d->kvol / 4;
     if (se) want = atoi(se);
-    if (want > 1 && d->splitk_ws != nullptr && d->splitk_ws_bytes >= (int64_t)want * d->n_out * d->cout * 4) {
+    const bool room = d->splitk_ws != nullptr && d->splitk_ws_bytes >= (int64_t)want * d->n_out * d->cout * 4;
+    if (bn == 128 && t128 < 2 * 256 && want >= 2 && room && !env) {
+      bm = 128;
+      a.ksplit = want;
+      a.partial = (float *)d->splitk_ws;
+    } else if (se && want >= 2 && room) {
       a.ksplit = want;
       a.partial = (float *)d->splitk_ws;
     }
