@@ -102,6 +102,8 @@ class Ensembler(torch.nn.Module):
             dense_rows[:, 0] = torch.where(empty, torch.ones_like(dense_rows[:, 0]), dense_rows[:, 0])
             outs.append(dense_rows)
         outs.append(torch.stack(outs, dim=0).mean(0))
+        if cache is not None:
+            cache["sem_rows"] = outs          # channels-last rows [XYZ, C] of the returned dense views
         return [o.reshape(X, Y, Z, -1).permute(3, 0, 1, 2) for o in outs]
 
     # -- a22 -----------------------------------------------------------------------------------------
@@ -145,15 +147,23 @@ class Ensembler(torch.nn.Module):
         ious = []
         for i in range(1, n_sub):
             a_idx, b_idx, iou = self.match_queries(anchor_m, masks[i], iou_threshold)
-            anchor_q[:, a_idx, :] = (anchor_q[:, a_idx, :] * i + query_probs[i][:, b_idx, :]) / (i + 1)
-            anchor_m[:, a_idx] = (anchor_m[:, a_idx] * i + masks[i][:, b_idx]) / (i + 1)
+            # the assignment of a square cost matrix lists every anchor query once, in order (a_idx = 0..Q-1)
+            anchor_q = (anchor_q * i + query_probs[i][:, b_idx, :]) / (i + 1)
+            anchor_m = (anchor_m * i + masks[i][:, b_idx]) / (i + 1)
             ious.append(iou)
         if ious:
             keep = torch.stack(ious, dim=0).mean(0) > iou_threshold
             anchor_m = anchor_m[:, keep]
             anchor_q = anchor_q[:, keep, :]
         # zero the ensemble where the ensembled semantic class is "empty"
-        ens_class = ensemble_sem_prob_denses[-1].argmax(0).reshape(-1)[union_sites.long()]
+        sem_rows = cache.get("sem_rows")
+        if sem_rows is not None and (len(sem_rows) != len(ensemble_sem_prob_denses) or any(
+                r.data_ptr() != d.data_ptr() for r, d in zip(sem_rows, ensemble_sem_prob_denses))):
+            sem_rows = None                      # denses did not come from this cache's ensemble_sem_compl
+        if sem_rows is not None:                 # rows of the same tensors, channels last: contiguous reads
+            ens_class = sem_rows[-1][union_sites.long()].argmax(dim=1)
+        else:
+            ens_class = ensemble_sem_prob_denses[-1].argmax(0).reshape(-1)[union_sites.long()]
         anchor_m = anchor_m * (ens_class != 0).float()[:, None]
         masks.append(anchor_m)
         query_probs.append(anchor_q)
@@ -162,11 +172,14 @@ class Ensembler(torch.nn.Module):
         for i, m in enumerate(masks):
             nz = (m != 0).any(dim=1)                                          # ME.to_sparse keeps non-zero sites
             c = coords4[nz].contiguous()
-            voxel_prob = ME.SparseTensor(m[nz].contiguous(), c)
-            sem = ensemble_sem_prob_denses[i]
-            cl = c.long()
-            sem_rows = sem[:, cl[:, 1], cl[:, 2], cl[:, 3]].t().contiguous()
-            sem_prob = ME.SparseTensor(sem_rows, coordinate_map_key=voxel_prob.coordinate_map_key,
-                                       coordinate_manager=voxel_prob.coordinate_manager)
+            mgr = ME.CoordinateManager(D=3, device=dev)
+            key = mgr.insert_unique(c, 1)                                     # canonical sites are unique
+            voxel_prob = ME.SparseTensor(m[nz].contiguous(), coordinate_map_key=key, coordinate_manager=mgr)
+            if sem_rows is not None:
+                sem_f = sem_rows[i][union_sites.long()[nz]].contiguous()
+            else:
+                cl = c.long()
+                sem_f = ensemble_sem_prob_denses[i][:, cl[:, 1], cl[:, 2], cl[:, 3]].t().contiguous()
+            sem_prob = ME.SparseTensor(sem_f, coordinate_map_key=key, coordinate_manager=mgr)
             out.append({"sem_probs": sem_prob, "voxel_probs": voxel_prob, "query_probs": query_probs[i]})
         return out
