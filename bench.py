@@ -68,11 +68,17 @@ def roofline_object(per_kernel, steps):
                             "ms_per_step": round(s["k3_time_s"] / steps * 1e3, 3)}
         return e
 
-    names = sorted(per_kernel, key=lambda n: -per_kernel[n]["time_s"])
+    names = sorted((n for n in per_kernel if n.startswith("k_conv")), key=lambda n: -per_kernel[n]["time_s"])
     out = entry(names[0], per_kernel[names[0]])
-    out["conv_ms_per_step"] = round(sum(v["time_s"] for v in per_kernel.values()) / steps * 1e3, 3)
+    out["conv_ms_per_step"] = round(sum(per_kernel[n]["time_s"] for n in names) / steps * 1e3, 3)
     if len(names) > 1:
         out["other_conv_kernel"] = entry(names[1], per_kernel[names[1]])
+    sp = per_kernel.get("k_split_rows")
+    if sp:     # operand preparation of the split kernel (one pass per conv input, not per gather)
+        out["operand_split"] = {"kernel": "k_split_rows", "launches_per_step": sp["launches"] / steps,
+                                "ms_per_step": round(sp["time_s"] / steps * 1e3, 3),
+                                "alg_GBps": round(sp["bytes_alg"] / sp["time_s"] / 1e9, 1),
+                                "traffic": pmc_traffic("k_split_rows")}
     return out
 
 

@@ -152,9 +152,23 @@ typedef struct ph_conv_desc {
   int64_t splitk_ws_bytes;
   int32_t *status;        /* optional device word; mode 1 ORs bit 0 into it when a gathered activation
                              exceeds the f16 range (|x| > 65504) - the caller must then redo the layer in mode 0 */
+  /* mode 2 = mode 1 with BOTH operands pre-split by ph_split_rows (the gather becomes a 16-byte copy: no
+   * per-gather conversion).  in_split = ph_split_rows(in [n_in, cin], pro_*) - the prologue is applied there
+   * and NOT again by the device; w_split = ph_split_rows of the [kvol*cout, cin] rows of (weight * 2^e)
+   * transposed to [kvol, cout, cin]; w_unscale = 2^-e.  `in` / `weight` / w_f16_* are not read by the device
+   * library in mode 2 (the checker build reads in / weight / pro_*).  The range flag is raised by ph_split_rows. */
+  const void *in_split;
+  const void *w_split;
 } ph_conv_desc;
 
 int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);
+
+/* Operand preparation for mma_mode 2.  x = act(in * pro_scale + pro_shift) (any of them NULL / PH_ACT_NONE),
+ * hi = f16(x) (round to nearest even), lo = f16(x - hi); out_split is f16 [n][cpad/32][2][32] with
+ * cpad = c rounded up to 32: group g holds channels 32g..32g+31 as 32 hi values then 32 lo values; channels
+ * >= c are zero.  c % 8 == 0.  ORs bit 0 into *status (optional) when some |x| > 65504 or is NaN. */
+int PH_FN(split_rows)(const float *in, int64_t n, int32_t c, const float *pro_scale, const float *pro_shift,
+                      int32_t pro_act, float slope, void *out_split, int32_t *status, ph_stream_t stream);
 
 /* Local max pooling over a neighbour table (MinkowskiMaxPooling,
  * transformer_predictor_v2.py:100-102,234-236).  Rows without any neighbour give 0. */

@@ -199,6 +199,88 @@ static float act_apply(float v, int act, float slope) {
   return v;
 }
 
+/* ---- operand split for mma_mode 2 (include/pasco_hip.h ph_split_rows) ------------------------------------
+ * IEEE binary16 conversion restated in integer arithmetic (round to nearest even, overflow -> inf,
+ * gradual underflow), so the checker does not depend on compiler _Float16 support. */
+static uint16_t f32_to_f16_bits(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const uint32_t ax = x & 0x7FFFFFFFu;
+  if (ax >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((ax > 0x7F800000u) ? 0x0200u : 0u));   /* inf / nan */
+  if (ax >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);   /* >= 65520 rounds to inf */
+  if (ax < 0x33000001u) return (uint16_t)sign;                /* <= 2^-25 rounds to zero */
+  int e = (int)(ax >> 23) - 127;
+  uint32_t m = (ax & 0x7FFFFFu) | 0x800000u;                  /* 24-bit significand */
+  int shift;                                                  /* bits dropped from m */
+  uint32_t base;
+  if (e >= -14) {                                             /* normal half */
+    shift = 13;
+    base = (uint32_t)(e + 15) << 10;
+    m &= 0x7FFFFFu;
+  } else {                                                    /* subnormal half: value = m * 2^(e-23), unit 2^-24 */
+    shift = 13 + (-14 - e);
+    base = 0;
+  }
+  uint32_t q = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1u);
+  const uint32_t half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) ++q;           /* may carry into the exponent: still correct */
+  return (uint16_t)(sign | (base + q));
+}
+
+static float f16_bits_to_f32(uint16_t h) {
+  const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+  const int e = (h >> 10) & 0x1F;
+  const uint32_t m = h & 0x3FFu;
+  uint32_t x;
+  if (e == 0) {
+    if (m == 0) x = sign;
+    else {
+      float v = (float)m * 5.9604644775390625e-08f;           /* m * 2^-24 */
+      memcpy(&x, &v, 4);
+      x |= sign;
+    }
+  } else if (e == 31) x = sign | 0x7F800000u | (m << 13);
+  else x = sign | ((uint32_t)(e - 15 + 127) << 23) | (m << 13);
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+}
+
+int pho_split_rows(const float *in, int64_t n, int32_t c, const float *pro_scale, const float *pro_shift,
+                   int32_t pro_act, float slope, void *out_split, int32_t *status, ph_stream_t stream) {
+  (void)stream;
+  if (n < 0 || c <= 0 || c % 8 != 0) return fail("split_rows: needs c % 8 == 0");
+  if (n == 0) return 0;
+  if (!in || !out_split) return fail("split_rows: null buffer");
+  const int cpad = (c + 31) / 32 * 32;
+  uint16_t *out = (uint16_t *)out_split;
+  const int has_pro = pro_scale || pro_shift || pro_act != PH_ACT_NONE;
+  int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+  for (int64_t r = 0; r < n; ++r) {
+    uint16_t *row = out + r * 2 * cpad;
+    for (int ch = 0; ch < cpad; ++ch) {
+      uint16_t hi = 0, lo = 0;
+      if (ch < c) {
+        float v = in[r * c + ch];
+        if (has_pro) {
+          v = v * (pro_scale ? pro_scale[ch] : 1.f) + (pro_shift ? pro_shift[ch] : 0.f);
+          v = act_apply(v, pro_act, slope);
+        }
+        if (!(fabsf(v) <= 65504.f)) bad = 1;
+        hi = f32_to_f16_bits(v);
+        lo = f32_to_f16_bits(v - f16_bits_to_f32(hi));
+      }
+      row[(ch >> 5) * 64 + (ch & 31)] = hi;
+      row[(ch >> 5) * 64 + 32 + (ch & 31)] = lo;
+    }
+  }
+  if (bad && status) *status |= 1;
+  return 0;
+}
+
 /* a2-a5: per output row, per kernel offset, row-vector x W[k] accumulate (fp32, like upstream's
  * CPU gather -> SGEMM -> scatter-add). Rows are processed in blocks so W[k] stays cache resident. */
 int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {

@@ -40,6 +40,10 @@ struct ConvArgsH {
   int32_t *status;
   int ksplit;       // > 1: blockIdx.y walks one slice of the kernel offsets and stores raw partial sums
   float *partial;   // [ksplit][n_out][cout]
+  // mode 2 (both operands pre-split by ph_split_rows): rows of cpad/32 groups [hi x32 | lo x32]
+  const _Float16 *in_split;   // [n_in][cpad/32][2][32]
+  const _Float16 *w_split;    // [kvol][cout][cpad/32][2][32]
+  int cpad;
 };
 
 __device__ __forceinline__ float h_act(float v, float neg) { return fmaxf(v, 0.f) + neg * fminf(v, 0.f); }
@@ -289,6 +293,272 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Mode 2: both operands arrive pre-split (ph_split_rows) in the layout the LDS tiles use, so the gather is
+// a pure 16-byte copy: no per-gather conversion (the in-kernel split of mode 1 spends ~2x the matrix-pipe
+// time in VALU converting every row up to 27 times, profiles/README.md "SQ counters, split kernel").
+// A row of a tile = KC/32 groups of [32 hi | 32 lo] f16 (+8 pad): LD = 2*KC + 8.
+// ------------------------------------------------------------------------------------------------------
+template <int BM, int KC, int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
+  constexpr int BN = WN * TN * 32;
+  constexpr int LD = 2 * KC + 8;
+  constexpr int SPR = KC / 4;                 // 16-byte slots per tile row (hi + lo)
+  constexpr int RPP = HV_THREADS / SPR;       // tile rows filled per pass
+  constexpr int A_PASSES = BM / RPP;
+  constexpr int B_PASSES = (BN + RPP - 1) / RPP;
+  static_assert(WM * WN == 4 && WM * TM * 32 == BM, "tile shape");
+  static_assert(BM % RPP == 0, "loader shape");
+
+  __shared__ __attribute__((aligned(16))) _Float16 As[BM * LD];
+  __shared__ __attribute__((aligned(16))) _Float16 Bs[BN * LD];
+
+  const int nwg = gridDim.x;
+  const int cpx = nwg >> 3;
+  const int bid = blockIdx.x;
+  const int tile = (bid & 7) * cpx + (bid >> 3);
+  const int ntiles = a.n_row_tiles * a.n_col_tiles;
+  if (tile >= ntiles) return;
+  const int row_tile = tile / a.n_col_tiles;
+  const int col_tile = tile - row_tile * a.n_col_tiles;
+  const int64_t m0 = (int64_t)row_tile * BM;
+  const int n0 = col_tile * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int h = lane >> 5;
+  const int l31 = lane & 31;
+
+  const int cout = a.cout;
+  const int nchunks = a.cpad / KC;
+  const int kper = (a.kvol + a.ksplit - 1) / a.ksplit;
+  const int k_begin = (int)blockIdx.y * kper;
+  const int k_end = (k_begin + kper < a.kvol) ? k_begin + kper : a.kvol;
+  const int nstages = (k_end > k_begin ? k_end - k_begin : 0) * nchunks;
+  const int l_j = tid % SPR;                  // slot inside the row chunk
+  const int l_r = tid / SPR;                  // first tile row of this thread
+  const uint32_t rs = 2u * (uint32_t)a.cpad;  // f16 per operand row
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f16x8 ra[A_PASSES], rb[B_PASSES];
+  int idx_cur[A_PASSES], idx_nxt[A_PASSES];
+  // weight rows of this thread: (n0 + l_r + q * RPP); -1 when outside cout
+  int64_t boff[B_PASSES];
+#pragma unroll
+  for (int q = 0; q < B_PASSES; ++q) {
+    const int n = l_r + q * RPP;
+    boff[q] = (n < BN && n0 + n < cout) ? (int64_t)(n0 + n) * rs + l_j * 8 : -1;
+  }
+
+  auto load_idx = [&](int k, int *dst) {
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      const int64_t row = m0 + l_r + p * RPP;
+      int idx = -1;
+      if (row < a.n_out) idx = a.nbr ? a.nbr[(int64_t)k * a.n_out + row] : (int)row;
+      dst[p] = idx;
+    }
+  };
+
+  auto load_stage = [&](int k, int chunk) {
+    const int coff = chunk * (2 * KC) + l_j * 8;
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      const int idx = idx_cur[p];
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (idx >= 0) v = *reinterpret_cast<const f16x8 *>(a.in_split + (uint64_t)(uint32_t)idx * rs + coff);
+      ra[p] = v;
+    }
+    const _Float16 *wk = a.w_split + (int64_t)k * cout * rs + chunk * (2 * KC);
+#pragma unroll
+    for (int q = 0; q < B_PASSES; ++q) {
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (boff[q] >= 0) v = *reinterpret_cast<const f16x8 *>(wk + boff[q]);
+      rb[q] = v;
+    }
+  };
+
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p)
+      *reinterpret_cast<f16x8 *>(&As[(l_r + p * RPP) * LD + l_j * 8]) = ra[p];
+#pragma unroll
+    for (int q = 0; q < B_PASSES; ++q) {
+      const int n = l_r + q * RPP;
+      if (n < BN) *reinterpret_cast<f16x8 *>(&Bs[n * LD + l_j * 8]) = rb[q];
+    }
+  };
+
+  auto compute_stage = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < KC / 16; ++ks) {
+      const int co = (ks >> 1) * 64 + (ks & 1) * 16 + h * 8;   // hi run; the lo run is 32 further
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int o = ((wm * TM + i) * 32 + l31) * LD + co;
+        ah[i] = *reinterpret_cast<const f16x8 *>(&As[o]);
+        al[i] = *reinterpret_cast<const f16x8 *>(&As[o + 32]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int o = ((wn * TN + j) * 32 + l31) * LD + co;
+        bh[j] = *reinterpret_cast<const f16x8 *>(&Bs[o]);
+        bl[j] = *reinterpret_cast<const f16x8 *>(&Bs[o + 32]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          // weights as the first operand: the accumulator is the TRANSPOSED 32x32 block - lane = output row,
+          // registers = 4-channel runs - so the epilogue moves float4s (smallest terms first)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  if (nstages > 0) {
+    load_idx(k_begin, idx_cur);
+    if (k_begin + 1 < k_end) load_idx(k_begin + 1, idx_nxt);
+    load_stage(k_begin, 0);
+  }
+  int k = k_begin, chunk = 0;
+  for (int s = 0; s < nstages; ++s) {
+    store_stage();
+    __syncthreads();
+    if (s + 1 < nstages) {
+      if (++chunk == nchunks) {
+        chunk = 0;
+        ++k;
+#pragma unroll
+        for (int p = 0; p < A_PASSES; ++p) idx_cur[p] = idx_nxt[p];
+        if (k + 1 < k_end) load_idx(k + 1, idx_nxt);
+      }
+      load_stage(k, chunk);
+    }
+    compute_stage();
+    __syncthreads();
+  }
+
+  // accumulator layout (transposed block): acc[i][j][4g + q] = out[row = m0 + (wm*TM+i)*32 + l31]
+  //                                                          [col = n0 + (wn*TN+j)*32 + 8g + 4h + q]
+  if (a.ksplit > 1) {   // raw partial sums; k_splitk_epilogue reduces them in a fixed order
+    float *part = a.partial + (int64_t)blockIdx.y * a.n_out * cout;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int64_t row = m0 + (wm * TM + i) * 32 + l31;
+      if (row >= a.n_out) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = n0 + (wn * TN + j) * 32 + 8 * g + 4 * h;
+          if (col >= cout) continue;
+          *reinterpret_cast<float4 *>(part + row * cout + col) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = n0 + (wn * TN + j) * 32 + 8 * g + 4 * h;
+      if (col >= cout) continue;          // cout % 4 == 0: a run is entirely inside or outside
+      float bias[4], es[4], eb[4], es2[4], eb2[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bias[q] = a.bias ? a.bias[col + q] : 0.f;
+        es[q] = a.epi_scale ? a.epi_scale[col + q] : 1.f;
+        eb[q] = a.epi_shift ? a.epi_shift[col + q] : 0.f;
+        es2[q] = a.epi2_scale ? a.epi2_scale[col + q] : 1.f;
+        eb2[q] = a.epi2_shift ? a.epi2_shift[col + q] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int64_t row = m0 + (wm * TM + i) * 32 + l31;
+        if (row >= a.n_out) continue;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = h_act((acc[i][j][4 * g + q] * a.w_unscale + bias[q]) * es[q] + eb[q], a.epi_neg);
+        if (a.has_tail) {
+          float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.residual) rs = *reinterpret_cast<const float4 *>(a.residual + row * cout + col);
+          const float r4[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = h_act(v[q] * es2[q] + eb2[q] + r4[q], a.res_neg);
+        }
+        *reinterpret_cast<float4 *>(a.out + row * cout + col) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+}
+
+// fp32 rows -> [hi x32 | lo x32] groups; one thread per 8 channels.  Channels >= c (pad to 32) are zero.
+__global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ in, int64_t n, int c, int cpad,
+                                                     const float *__restrict__ ps, const float *__restrict__ pb,
+                                                     int has_pro, float neg, _Float16 *__restrict__ out,
+                                                     int32_t *status) {
+  const int segs = cpad >> 3;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * segs) return;
+  const int64_t row = t / segs;
+  const int c0 = (int)(t - row * segs) * 8;
+  f16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < c) {   // c % 8 == 0: the segment is entirely inside or entirely padding
+    const float4 v0 = *reinterpret_cast<const float4 *>(in + row * c + c0);
+    const float4 v1 = *reinterpret_cast<const float4 *>(in + row * c + c0 + 4);
+    float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float xmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = x[j];
+      if (has_pro) {   // separate multiply and add (no FMA contraction): bit-identical to the C restatement in oracle/
+#pragma clang fp contract(off)
+        const float m = v * (ps ? ps[c0 + j] : 1.f);
+        v = h_act(m + (pb ? pb[c0 + j] : 0.f), neg);
+      }
+      xmax = fmaxf(xmax, fabsf(v));
+      const _Float16 vh = (_Float16)v;
+      hi[j] = vh;
+      lo[j] = (_Float16)(v - (float)vh);
+    }
+    if (status != nullptr && !(xmax <= 65504.f)) atomicOr(status, 1);   // also catches NaN
+  }
+  _Float16 *dst = out + (row * (cpad >> 5) + (c0 >> 5)) * 64 + (c0 & 31);
+  *reinterpret_cast<f16x8 *>(dst) = hi;
+  *reinterpret_cast<f16x8 *>(dst + 32) = lo;
+}
+
+extern "C" int ph_split_rows(const float *in, int64_t n, int32_t c, const float *pro_scale, const float *pro_shift,
+                             int32_t pro_act, float slope, void *out_split, int32_t *status, ph_stream_t stream) {
+  PH_REQUIRE(n >= 0 && c > 0 && c % 8 == 0, "split_rows: needs c %% 8 == 0 (c=%d)", c);
+  if (n == 0) return 0;
+  PH_REQUIRE(in && out_split, "split_rows: null buffer");
+  PH_REQUIRE((((uintptr_t)in | (uintptr_t)out_split) & 15) == 0, "split_rows: 16-byte alignment");
+  const int cpad = (c + 31) / 32 * 32;
+  const int64_t total = n * (cpad / 8);
+  const float neg = pro_act == PH_ACT_RELU ? 0.f : (pro_act == PH_ACT_LEAKY ? slope : 1.f);
+  const int has_pro = (pro_scale || pro_shift || pro_act != PH_ACT_NONE) ? 1 : 0;
+  hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ph_stream(stream), in, n, c, cpad,
+                     pro_scale, pro_shift, has_pro, neg, (_Float16 *)out_split, status);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
 // out = epilogue( sum_s partial[s] )  - one thread per output element, splits summed in index order
 __global__ void __launch_bounds__(256) k_splitk_epilogue(ConvArgsH a) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -325,13 +595,43 @@ static int launch_h(const ConvArgsH &a, hipStream_t st) {
   return 0;
 }
 
-// called from ph_conv_fwd (conv.hip) when desc->mma_mode == 1
+template <int BM, int KC, int WM, int WN, int TM, int TN>
+static int launch_h2(const ConvArgsH &a, hipStream_t st) {
+  constexpr int BN = WN * TN * 32;
+  ConvArgsH args = a;
+  args.n_row_tiles = (int)((a.n_out + BM - 1) / BM);
+  args.n_col_tiles = (a.cout + BN - 1) / BN;
+  const int ntiles = args.n_row_tiles * args.n_col_tiles;
+  const int grid = ((ntiles + 7) / 8) * 8;
+  hipLaunchKernelGGL((k_conv_h2<BM, KC, WM, WN, TM, TN>), dim3(grid, args.ksplit), dim3(HV_THREADS), 0, st, args);
+  PH_LAUNCH_CHECK();
+  if (args.ksplit > 1) {
+    const int64_t total = a.n_out * a.cout;
+    hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, args);
+    PH_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// called from ph_conv_fwd (conv.hip) when desc->mma_mode is 1 or 2
 int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
-  PH_REQUIRE(d->w_f16_hi && d->w_f16_lo, "conv_fwd(f16x3): pre-split weights missing");
+  const bool pre = d->mma_mode == 2;
   PH_REQUIRE(d->cin % 8 == 0 && d->cout % 4 == 0, "conv_fwd(f16x3): needs cin %% 8 == 0 and cout %% 4 == 0");
-  PH_REQUIRE((((uintptr_t)d->in | (uintptr_t)d->w_f16_hi | (uintptr_t)d->w_f16_lo) & 15) == 0,
-             "conv_fwd(f16x3): 16-byte alignment");
+  if (pre) {
+    PH_REQUIRE(d->in_split && d->w_split, "conv_fwd(f16x3, mode 2): pre-split operands missing");
+    PH_REQUIRE((((uintptr_t)d->in_split | (uintptr_t)d->w_split) & 15) == 0, "conv_fwd(f16x3): 16-byte alignment");
+    PH_REQUIRE(d->n_in < ((int64_t)1 << 31), "conv_fwd(f16x3): n_in too large");
+    PH_REQUIRE((((uintptr_t)d->out | (uintptr_t)d->residual | (uintptr_t)d->splitk_ws) & 15) == 0,
+               "conv_fwd(f16x3, mode 2): out / residual / splitk_ws must be 16-byte aligned");
+  } else {
+    PH_REQUIRE(d->w_f16_hi && d->w_f16_lo, "conv_fwd(f16x3): pre-split weights missing");
+    PH_REQUIRE((((uintptr_t)d->in | (uintptr_t)d->w_f16_hi | (uintptr_t)d->w_f16_lo) & 15) == 0,
+               "conv_fwd(f16x3): 16-byte alignment");
+  }
   ConvArgsH a;
+  a.in_split = (const _Float16 *)d->in_split;
+  a.w_split = (const _Float16 *)d->w_split;
+  a.cpad = (d->cin + 31) / 32 * 32;
   a.in = d->in;
   a.w_hi = (const _Float16 *)d->w_f16_hi;
   a.w_lo = (const _Float16 *)d->w_f16_lo;
@@ -355,7 +655,7 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.epi_neg = neg_of(d->epi_act);
   a.res_neg = neg_of(d->res_act);
   a.w_unscale = d->w_unscale;
-  a.has_pro = (d->pro_scale || d->pro_shift || d->pro_act != PH_ACT_NONE) ? 1 : 0;
+  a.has_pro = (d->pro_scale || d->pro_shift || d->pro_act != PH_ACT_NONE) ? 1 : 0;   // mode 2: already applied by ph_split_rows
   a.has_tail = (d->residual || d->epi2_scale || d->epi2_shift || d->res_act != PH_ACT_NONE) ? 1 : 0;
   a.n_row_tiles = a.n_col_tiles = 0;
   a.status = d->status;
@@ -366,12 +666,13 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   if (bn >= 64 && ((d->n_out + 127) / 128) * ncol < 2 * 256) bm = 64;
   if (bn == 128 && bm == 64 && ((d->n_out + 63) / 64) * ncol < 2 * 256) bm = 32;
   int kc = (d->cin % 64 == 0 && d->cin >= 256) ? 64 : 32;   // deeper stages pay only for wide layers (profiles/r1f_op_bench.json)
+  if (pre && a.cpad % 64 != 0) kc = 32;
   const char *env = getenv("PASCO_CONVH_CFG");   // tuning override: "bm,kc"
   if (env) {
     int em = 0, ek = 0;
     if (sscanf(env, "%d,%d", &em, &ek) >= 1) {
       if (em == 128 || (em == 64 && bn >= 64) || (em == 32 && bn == 128)) bm = em;
-      if (ek == 32 || ek == 64) kc = ek;
+      if (ek == 32 || (ek == 64 && (!pre || a.cpad % 64 == 0))) kc = ek;
     }
   }
   // Few-row layers (dense bottleneck: 245 offsets on 6.7 k rows; stride-4/8 layers): every workgroup streams
@@ -397,8 +698,11 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
       a.partial = (float *)d->splitk_ws;
     }
   }
-#define PH_H_CASE(BM_, WM_, WN_, TM_, TN_)                                                          \
-  if (bm == BM_) return kc == 64 ? launch_h<BM_, 64, WM_, WN_, TM_, TN_>(a, st) : launch_h<BM_, 32, WM_, WN_, TM_, TN_>(a, st)
+#define PH_H_CASE(BM_, WM_, WN_, TM_, TN_)                                                                \
+  if (bm == BM_) {                                                                                        \
+    if (pre) return kc == 64 ? launch_h2<BM_, 64, WM_, WN_, TM_, TN_>(a, st) : launch_h2<BM_, 32, WM_, WN_, TM_, TN_>(a, st); \
+    return kc == 64 ? launch_h<BM_, 64, WM_, WN_, TM_, TN_>(a, st) : launch_h<BM_, 32, WM_, WN_, TM_, TN_>(a, st);            \
+  }
   if (bn == 32) {
     PH_H_CASE(128, 4, 1, 1, 1);
   } else if (bn == 64) {

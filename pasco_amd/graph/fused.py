@@ -13,6 +13,7 @@ from ..me.backend import ACT_LEAKY, ACT_NONE, ACT_RELU
 from ..me.modules import MinkowskiBatchNorm, _ConvBase
 
 _CONV_PRECISION = "f16x3"
+_PRESPLIT = True     # f16x3 operands pre-split once per tensor (mma_mode 2) instead of per gather (mode 1)
 
 
 def set_conv_precision(mode: str) -> None:
@@ -21,32 +22,61 @@ def set_conv_precision(mode: str) -> None:
     error against fp64 <= that of the fp32 MFMA path (tests/test_hip_f16x3.py), ~5x less matrix-pipe time;
     activations must stay inside the f16 range (checked on the device, `check_status`).
     "f32": every product on the exact fp32 MFMA."""
-    global _CONV_PRECISION
-    assert mode in ("f32", "f16x3")
-    _CONV_PRECISION = mode
+    global _CONV_PRECISION, _PRESPLIT
+    assert mode in ("f32", "f16x3", "f16x3-inline")
+    _PRESPLIT = mode != "f16x3-inline"       # "-inline": the kernel converts at gather time (mode 1; for comparison)
+    _CONV_PRECISION = "f32" if mode == "f32" else "f16x3"
 
 
 def conv_precision() -> str:
     return _CONV_PRECISION
 
 
+def _split_of(w, be):
+    return be.split_weight_rows(w) if _PRESPLIT else be.split_weight_f16(w)
+
+
 def split_weight(mod, be):
-    """Cached (hi, lo, unscale) f16 split of a conv module's kernel."""
+    """Cached f16 split of a conv module's kernel: (w_split, unscale) for mode 2, (hi, lo, unscale) for mode 1."""
     w = mod.kernel
-    ver = (w._version, w.device)
+    ver = (w._version, w.device, _PRESPLIT)
     hit = getattr(mod, "_ph_split", None)
     if hit is None or hit[0] != ver:
-        hit = (ver, be.split_weight_f16(w))
+        hit = (ver, _split_of(w, be))
         object.__setattr__(mod, "_ph_split", hit)
     return hit[1]
 
 
+def split_input(x: SparseTensor, be, ps, pb, pro_act, slope):
+    """Pre-split rows of act(x.F * ps + pb), cached on the SparseTensor (several consumers of one tensor with the
+    same prologue - e.g. the per-subnet heads - split it once)."""
+    F = x.F if x.F.is_contiguous() else x.F.contiguous()
+    key = (F.data_ptr(), F._version, None if ps is None else ps.data_ptr(), None if pb is None else pb.data_ptr(),
+           pro_act, float(slope))
+    cache = x.__dict__.setdefault("_ph_in_split", {})
+    hit = cache.get(key)
+    if hit is None:
+        hit = be.split_rows(F, pro_scale=ps, pro_shift=pb, pro_act=pro_act, slope=slope)
+        cache[key] = hit
+    return hit
+
+
+def split_rows_2d(x2d: torch.Tensor):
+    """Pre-split operand of a tall [N, cin] matrix for several `linear_rows` calls on it (None when the split
+    path does not apply)."""
+    if not (x2d.is_cuda and _CONV_PRECISION == "f16x3" and _PRESPLIT and x2d.shape[1] % 8 == 0):
+        return None
+    from ..me.backend import backend_for
+    return backend_for(x2d.device).split_rows(x2d.contiguous())
+
+
 def linear_rows(x2d: torch.Tensor, weight: torch.Tensor, bias, cache_owner, cache_key: str,
-                min_rows: int = 16384) -> torch.Tensor:
+                min_rows: int = 16384, in_split=None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = x @ weight.T + bias for a tall [N, cin] operand (`weight` is an nn.Linear-style [cout, cin] tensor
     or a row slice of one).  Large N on the GPU goes through the convolution kernel as an identity-map k=1
     convolution - the same split-precision MFMA GEMM with fused bias - instead of an fp32 library GEMM;
-    everything else (small N, CPU checker backend, odd shapes) is torch.nn.functional.linear."""
+    everything else (small N, CPU checker backend, odd shapes) is torch.nn.functional.linear.
+    `residual` [N, cout] (optional) is added in the same launch (y + residual)."""
     n, cin = x2d.shape
     cout = weight.shape[0]
     be = None
@@ -56,15 +86,38 @@ def linear_rows(x2d: torch.Tensor, weight: torch.Tensor, bias, cache_owner, cach
         if not be.split_supported(cin, cout):
             be = None
     if be is None:
-        return torch.nn.functional.linear(x2d, weight, bias)
-    ver = (weight._version, weight.device, weight.data_ptr())
+        y = torch.nn.functional.linear(x2d, weight, bias)
+        return y if residual is None else y + residual
+    ver = (weight._version, weight.device, weight.data_ptr(), _PRESPLIT)
     hit = cache_owner.__dict__.get("_ph_lin_" + cache_key)
     if hit is None or hit[0] != ver:
         wt = weight.detach().t().contiguous()                     # [cin, cout]
-        hit = (ver, wt, be.split_weight_f16(wt), bias.detach().contiguous() if bias is not None else None)
+        hit = (ver, wt, _split_of(wt, be), bias.detach().contiguous() if bias is not None else None)
         cache_owner.__dict__["_ph_lin_" + cache_key] = hit
     _, wt, split, b = hit
-    return be.conv_fwd(x2d.contiguous(), wt, None, n, bias=b, split=split)
+    return be.conv_fwd(x2d.contiguous(), wt, None, n, bias=b, split=split, in_split=in_split if _PRESPLIT else None,
+                       residual=None if residual is None else residual.contiguous())
+
+
+def batched_rows_matmul(x: torch.Tensor, w: torch.Tensor, x_split: torch.Tensor) -> torch.Tensor:
+    """out[b] = x[b] @ w[b].T for tall x [B, P, D] and per-batch w [B, Q, D] that change every call (the mask
+    logits of the query heads), on the split-precision kernel with `x_split` = split_rows(x) prepared once.
+    The power-of-two weight scale is chosen on the device (no host read) and undone by the epilogue scale."""
+    from ..me.backend import backend_for
+    be = backend_for(x.device)
+    B, P, D = x.shape
+    Q = w.shape[1]
+    w = w.detach()
+    e = 13 - torch.frexp(w.abs().amax())[1]                        # device int: largest magnitude just below 2^14
+    w_split = be.split_rows(torch.ldexp(w, e).reshape(B * Q, D).contiguous())
+    unscale = torch.ldexp(torch.ones(Q, device=x.device), -e).contiguous()
+    out = torch.empty((B, P, Q), dtype=torch.float32, device=x.device)
+    xs = x_split.reshape(B, P, -1)
+    ws = w_split.reshape(B, Q, -1)
+    for b in range(B):
+        be.conv_fwd(x[b], None, None, P, wshape=(1, D, Q), split=(ws[b], 1.0), in_split=xs[b], epi_scale=unscale,
+                    out=out[b])
+    return out
 
 
 def fold_bn(bn) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -107,14 +160,17 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
         e2s, e2b = fold_bn(epi2_bn)
     bias = mod.bias.detach().reshape(-1) if mod.bias is not None else None
     be = mgr.backend()
-    split = None
+    split = in_split = None
     if _CONV_PRECISION == "f16x3" and be.split_supported(mod.in_channels, mod.out_channels):
         split = split_weight(mod, be)
+        if _PRESPLIT and n_out > 0:
+            in_split = split_input(x, be, ps, pb, pro_act, slope)
     out = be.conv_fwd(
         x.F if x.F.is_contiguous() else x.F.contiguous(), mod.kernel.detach(), nbr, n_out, bias=bias,
         pro_scale=ps, pro_shift=pb, pro_act=pro_act, epi_scale=es, epi_shift=eb, epi_act=epi_act,
-        epi2_scale=e2s, epi2_shift=e2b, residual=residual, res_act=res_act, slope=slope, split=split)
+        epi2_scale=e2s, epi2_shift=e2b, residual=residual, res_act=res_act, slope=slope, split=split,
+        in_split=in_split)
     return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
 
 
-__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "linear_rows", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]
+__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "linear_rows", "split_rows_2d", "batched_rows_matmul", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]

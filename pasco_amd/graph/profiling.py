@@ -32,17 +32,36 @@ class ConvProfiler:
             e0.record()
             out = inner(x, weight, nbr, n_out, **kw)
             e1.record()
-            kvol = 1 if weight.dim() == 2 else weight.shape[0]
+            if weight is None:
+                kvol, _, cout = kw["wshape"]
+            else:
+                kvol, cout = (1 if weight.dim() == 2 else weight.shape[0]), weight.shape[-1]
             prof.records.append(dict(e0=e0, e1=e1, nbr=nbr, n_in=x.shape[0], n_out=n_out, cin=x.shape[1],
-                                     cout=weight.shape[-1], kvol=kvol,
-                                     kernel="k_conv_f16x3" if kw.get("split") is not None else "k_conv_mfma"))
+                                     cout=cout, kvol=kvol,
+                                     kernel=("k_conv_mfma" if kw.get("split") is None else
+                                             ("k_conv_h2" if len(kw["split"]) == 2 else "k_conv_f16x3"))))
+            return out
+
+        inner_split = backend.split_rows
+
+        def split_rows(x, **kw):
+            if not prof.enabled or x.device.type != "cuda":
+                return inner_split(x, **kw)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = inner_split(x, **kw)
+            e1.record()
+            prof.records.append(dict(e0=e0, e1=e1, kernel="k_split_rows", n=x.shape[0], c=x.shape[1]))
             return out
 
         backend.conv_fwd = conv_fwd
+        backend.split_rows = split_rows
         backend._conv_profiled = True
 
     def summary(self):
-        """Per kernel (`k_conv_f16x3` = split-precision products, `k_conv_mfma` = exact fp32 MFMA) over every
+        """Per kernel (`k_conv_h2` / `k_conv_f16x3` = split-precision products with pre-split / in-kernel split
+        operands, `k_conv_mfma` = exact fp32 MFMA, `k_split_rows` = the operand split of mode 2) over every
         recorded launch (k=3 / k=2 strided / generative transposed / k=1 convolutions and the dense bottleneck's
         implicit GEMMs): launches, time, algorithmic flops / bytes (flops = 2 P Cin Cout,
         B_alg = 4 P Cin + 4 N_out Cout + 8 P + 4 K Cin Cout, P = pairs of the neighbour table, P = N for
@@ -52,6 +71,13 @@ class ConvProfiler:
         out = {}
         for r in self.records:
             dt = r["e0"].elapsed_time(r["e1"]) * 1e-3
+            if r["kernel"] == "k_split_rows":      # operand preparation of mode 2: 4 B read + 4 B written per element
+                d = out.setdefault("k_split_rows", dict(launches=0, time_s=0.0, flops=0.0, bytes_alg=0.0,
+                                                        k3_launches=0, k3_time_s=0.0, k3_flops=0.0))
+                d["launches"] += 1
+                d["time_s"] += dt
+                d["bytes_alg"] += 4.0 * r["n"] * r["c"] + 4.0 * r["n"] * ((r["c"] + 31) // 32 * 32)
+                continue
             nbr = r["nbr"]
             if nbr is None:
                 P = r["n_out"]

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from .. import me as ME
 from ..me.backend import backend_for
-from .fused import linear_rows
+from .fused import batched_rows_matmul, linear_rows, split_rows_2d
 
 
 def sine_position_encoding(coords: torch.Tensor, num_pos_feats: int, temperature: float = 10000.0,
@@ -80,9 +80,10 @@ class CrossAttentionLayer(nn.Module):
         _xavier(self)
 
     def forward(self, q_embed, feats, attn_mask=None, pos=None, query_pos=None, mask_bits=None):
-        """q_embed [B,Q,D]; feats [B,N,D].  Mask either as `attn_mask` bool [B,Q,N] (True = masked,
-        shared by the heads; torch path) or as `mask_bits` = (bits [B,N,4], any [B,4]) for the fused
-        HIP kernel (ph_attn_cross_fwd), which also applies the all-masked -> unmasked rule."""
+        """q_embed [B,Q,D]; feats [B,N,D] (pass pos=None when the positional term is already added).  Mask
+        either as `attn_mask` bool [B,Q,N] (True = masked, shared by the heads; torch path) or as `mask_bits`
+        = (bits [B,N,4], any [B,4]) for the fused HIP kernel (ph_attn_cross_fwd), which also applies the
+        all-masked -> unmasked rule."""
         q = self.norm(q_embed)
         kv = feats if pos is None else feats + pos
         mha = self.multihead_attn
@@ -92,8 +93,9 @@ class CrossAttentionLayer(nn.Module):
         qq = F.linear(q if query_pos is None else q + query_pos, w[:D], b[:D])
         N = kv.shape[1]
         kv2 = kv.reshape(B * N, D)
-        kk = linear_rows(kv2, w[D:2 * D], b[D:2 * D], self, "k").view(B, N, D)
-        vv = linear_rows(kv2, w[2 * D:], b[2 * D:], self, "v").view(B, N, D)
+        kv_split = split_rows_2d(kv2) if kv2.shape[0] >= 16384 else None     # one operand split for K and V
+        kk = linear_rows(kv2, w[D:2 * D], b[D:2 * D], self, "k", in_split=kv_split).view(B, N, D)
+        vv = linear_rows(kv2, w[2 * D:], b[2 * D:], self, "v", in_split=kv_split).view(B, N, D)
         qq = qq.view(B, Q, H, D // H).transpose(1, 2)
         if mask_bits is not None:
             be = backend_for(q.device)
@@ -169,15 +171,18 @@ class TransformerPredictorV2(nn.Module):
         self.mask_feat_proj = nn.Linear(mask_dim, hidden_dim)
 
     # -- heads --------------------------------------------------------------------------------------
-    def pred_heads(self, output, mask_features):
+    def pred_heads(self, output, mask_features, mask_features_split=None):
         d = self.decoder_norm(output)
         outputs_class = self.class_embed(d)
         mask_embed = self.mask_embed(d)                                   # [B,Q,D]
-        outputs_mask = torch.matmul(mask_features, mask_embed.transpose(1, 2))   # [B,P,Q]
+        if mask_features_split is not None and mask_embed.shape[1] % 4 == 0:
+            outputs_mask = batched_rows_matmul(mask_features, mask_embed, mask_features_split)
+        else:
+            outputs_mask = torch.matmul(mask_features, mask_embed.transpose(1, 2))   # [B,P,Q]
         return outputs_class, outputs_mask
 
     # -- attention mask -----------------------------------------------------------------------------
-    def compute_mask_bits(self, outputs_mask, voxel_coord, src_C, src_scale, min_Cs, max_Cs):
+    def compute_mask_bits(self, outputs_mask, voxel_coord, src_C, src_scale, min_Cs, max_Cs, cache=None):
         """Attention mask of one level as bits: (bits int32 [B, N_level, 4], any int32 [B, 4]).
 
         Query q may attend level voxel p iff some scale-1 voxel v of the same subnet inside p's
@@ -190,10 +195,15 @@ class TransformerPredictorV2(nn.Module):
         be = backend_for(dev)
         bits1, _ = be.attn_mask_pack(outputs_mask.reshape(B * P, Q).contiguous(), B, P, positive_only=True,
                                      want_any=False)
-        bcol = torch.arange(B, device=dev, dtype=torch.int32).repeat_interleave(P).reshape(-1, 1)
-        keep_C = torch.cat([bcol, voxel_coord.reshape(B * P, 4)[:, 1:].to(torch.int32)], dim=1).contiguous()
-        mgr = ME.CoordinateManager(D=3, device=dev)
-        key1, (_, uniq) = mgr.insert_and_map(keep_C, 1)    # duplicated (padded) rows keep their first occurrence
+        if cache is not None and "key1" in cache:            # the scale-1 map depends on the coordinates only
+            mgr, key1, uniq = cache["key1"]
+        else:
+            bcol = torch.arange(B, device=dev, dtype=torch.int32).repeat_interleave(P).reshape(-1, 1)
+            keep_C = torch.cat([bcol, voxel_coord.reshape(B * P, 4)[:, 1:].to(torch.int32)], dim=1).contiguous()
+            mgr = ME.CoordinateManager(D=3, device=dev)
+            key1, (_, uniq) = mgr.insert_and_map(keep_C, 1)    # duplicated (padded) rows keep their first occurrence
+            if cache is not None:
+                cache["key1"] = (mgr, key1, uniq)
         bits1 = bits1.reshape(B * P, 4)
         if uniq is not None:
             bits1 = be.gather_rows(bits1, uniq)
@@ -253,19 +263,25 @@ class TransformerPredictorV2(nn.Module):
         voxel_coord = xs[1][1]
         x1 = xs[1][0]
         voxel_feat = linear_rows(x1.reshape(-1, x1.shape[-1]), self.mask_feat_proj.weight, self.mask_feat_proj.bias,
-                                 self.mask_feat_proj, "w").view(B, -1, D) + pos[-1]
+                                 self.mask_feat_proj, "w", residual=pos[-1].reshape(-1, D)).view(B, -1, D)
         predictions_class, predictions_mask = [], []
-        oc, om = self.pred_heads(output, voxel_feat)
+        mask_cache = {}
+        vf_split = split_rows_2d(voxel_feat.reshape(-1, D)) if voxel_feat.shape[0] * voxel_feat.shape[1] >= 16384 else None
+        oc, om = self.pred_heads(output, voxel_feat, vf_split)
         predictions_class.append(oc)
         predictions_mask.append(om)
         for i in range(self.num_layers):
             lin = self.input_projs[i]
-            src_F = linear_rows(srcs[i].reshape(-1, srcs[i].shape[-1]), lin.weight, lin.bias, lin, "w").view(B, -1, D)
-            bits, any_ = self.compute_mask_bits(om, voxel_coord, src_Cs[i], self.src_scales[i], min_Cs, max_Cs)
+            # input projection with the positional term added in the same launch: the layer only ever uses
+            # src + pos (transformer/blocks.py:83-86, key = value = bb_feat + pos)
+            src_F = linear_rows(srcs[i].reshape(-1, srcs[i].shape[-1]), lin.weight, lin.bias, lin, "w",
+                                residual=pos[i].reshape(-1, D)).view(B, -1, D)
+            bits, any_ = self.compute_mask_bits(om, voxel_coord, src_Cs[i], self.src_scales[i], min_Cs, max_Cs,
+                                                cache=mask_cache)
             N_i, Qn = src_F.shape[1], om.shape[2]
             be = backend_for(src_F.device)
             if be.attn_supported(Qn, D // self.nheads):
-                output = self.transformer_cross_attention_layers[i](output, src_F, pos=pos[i], query_pos=query_embed,
+                output = self.transformer_cross_attention_layers[i](output, src_F, pos=None, query_pos=query_embed,
                                                                     mask_bits=(bits, any_))
             else:   # shapes outside the fused kernel: torch attention with the materialised bool mask
                 q_idx = torch.arange(Qn, device=bits.device)
@@ -273,23 +289,22 @@ class TransformerPredictorV2(nn.Module):
                 attn_mask = ~(allow != 0).permute(0, 2, 1)
                 attn_mask = attn_mask & ~attn_mask.all(dim=-1, keepdim=True)   # all-masked -> unmasked
                 output = self.transformer_cross_attention_layers[i](output, src_F, attn_mask=attn_mask,
-                                                                    pos=pos[i], query_pos=query_embed)
+                                                                    pos=None, query_pos=query_embed)
             output = self.transformer_self_attention_layers[i](output, query_pos=query_embed)
             output = self.transformer_ffn_layers[i](output)
-            oc, om = self.pred_heads(output, voxel_feat)
+            oc, om = self.pred_heads(output, voxel_feat, vf_split)
             predictions_class.append(oc)
             predictions_mask.append(om)
         panop_predictions = []
         for b in range(B):
-            keep = keep_pad[b]
-            first = ME.SparseTensor(predictions_mask[0][b][keep].contiguous(), voxel_coord[b][keep])
+            kept = keep_pad[b].nonzero().reshape(-1)          # one compaction per subnet, reused by every mask
+            first = ME.SparseTensor(predictions_mask[0][b].index_select(0, kept), voxel_coord[b].index_select(0, kept))
             key, mgr = first.coordinate_map_key, first.coordinate_manager
             idx = first.unique_index        # None unless coordinates repeat
+            rows = kept if idx is None else kept.index_select(0, idx.long())
             masks = [first]
             for m in predictions_mask[1:]:
-                f = m[b][keep]
-                f = f[idx.long()] if idx is not None else f
-                masks.append(ME.SparseTensor(f.contiguous(), coordinate_map_key=key, coordinate_manager=mgr))
+                masks.append(ME.SparseTensor(m[b].index_select(0, rows), coordinate_map_key=key, coordinate_manager=mgr))
             classes = [c[b].unsqueeze(0) for c in predictions_class]
             panop_predictions.append({
                 "query_logits": classes[-1],

@@ -39,6 +39,7 @@ class ConvDesc(C.Structure):
         ("epi2_scale", _vp), ("epi2_shift", _vp),
         ("mma_mode", _i32), ("w_unscale", C.c_float), ("w_f16_hi", _vp), ("w_f16_lo", _vp),
         ("splitk_ws", _vp), ("splitk_ws_bytes", _i64), ("status", _vp),
+        ("in_split", _vp), ("w_split", _vp),
     ]
 
 
@@ -54,6 +55,7 @@ _SIGNATURES = {
     "nbr_build": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "kmap_compact": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
     "conv_fwd": [C.POINTER(ConvDesc), _vp],
+    "split_rows": [_vp, _i64, _i32, _vp, _vp, _i32, C.c_float, _vp, _vp, _vp],
     "maxpool_fwd": [_vp, _i32, _vp, _i32, _i64, _vp, _vp],
     "mask_compact": [_vp, _i64, _vp, _vp, _vp, _i64, _vp],
     "gather_rows": [_vp, _i32, _vp, _i64, _vp, _vp],
@@ -225,17 +227,22 @@ class CBackend:
         return pin, pout, counts
 
     # -- convolution -------------------------------------------------------------------------------
-    def conv_fwd(self, x: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tensor], n_out: int,
-                 *, bias=None, pro_scale=None, pro_shift=None, pro_act=ACT_NONE, epi_scale=None,
+    def conv_fwd(self, x: torch.Tensor, weight: Optional[torch.Tensor], nbr: Optional[torch.Tensor], n_out: int,
+                 *, wshape=None, bias=None, pro_scale=None, pro_shift=None, pro_act=ACT_NONE, epi_scale=None,
                  epi_shift=None, epi_act=ACT_NONE, slope=0.01, residual=None, res_act=ACT_NONE,
-                 epi2_scale=None, epi2_shift=None, split=None,
+                 epi2_scale=None, epi2_shift=None, split=None, in_split: Optional[torch.Tensor] = None,
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._chk(x, torch.float32, "in")
-        self._chk(weight, torch.float32, "weight")
-        if weight.dim() == 2:
-            kvol, (cin, cout) = 1, weight.shape
+        if weight is None:     # pre-split operands only (mode 2): the fp32 kernel is not read, `wshape` = (kvol, cin, cout)
+            if wshape is None or split is None or len(split) != 2 or self.device_type != "cuda":
+                raise ValueError("conv: weight=None needs wshape and a mode-2 split on the device backend")
+            kvol, cin, cout = wshape
         else:
-            kvol, cin, cout = weight.shape
+            self._chk(weight, torch.float32, "weight")
+            if weight.dim() == 2:
+                kvol, (cin, cout) = 1, weight.shape
+            else:
+                kvol, cin, cout = weight.shape
         if x.shape[1] != cin:
             raise ValueError(f"conv: input has {x.shape[1]} channels, kernel expects {cin}")
         if nbr is not None:
@@ -264,9 +271,20 @@ class CBackend:
             if tuple(residual.shape) != (n_out, cout):
                 raise ValueError("conv: residual shape mismatch")
         d.residual = _ptr(residual)
-        if split is not None:      # (w_hi, w_lo, unscale) from split_weight_f16: opt-in f16x3 products
-            w_hi, w_lo, unscale = split
-            d.mma_mode, d.w_unscale, d.w_f16_hi, d.w_f16_lo = 1, float(unscale), _ptr(w_hi), _ptr(w_lo)
+        if split is not None:      # opt-in f16x3 products
+            if len(split) == 2:    # (w_split, unscale) from split_weight_rows + in_split from split_rows: mode 2
+                w_split, unscale = split
+                if in_split is None:
+                    in_split = self.split_rows(x, pro_scale=pro_scale, pro_shift=pro_shift, pro_act=pro_act, slope=slope)
+                cpad = (cin + 31) // 32 * 32
+                if in_split.dtype != torch.float16 or in_split.numel() != x.shape[0] * 2 * cpad:
+                    raise ValueError("conv: in_split does not match the input rows")
+                if w_split.numel() != kvol * cout * 2 * cpad:
+                    raise ValueError("conv: w_split does not match the kernel")
+                d.mma_mode, d.w_unscale, d.in_split, d.w_split = 2, float(unscale), _ptr(in_split), _ptr(w_split)
+            else:                  # (w_hi, w_lo, unscale) from split_weight_f16: mode 1, activations split in-kernel
+                w_hi, w_lo, unscale = split
+                d.mma_mode, d.w_unscale, d.w_f16_hi, d.w_f16_lo = 1, float(unscale), _ptr(w_hi), _ptr(w_lo)
             d.status = _ptr(self.status_word(x.device))
             if n_out * cout <= (1 << 23):          # few-row layer: offer scratch for a split over the offsets
                 need = 8 * n_out * cout * 4
@@ -316,6 +334,42 @@ class CBackend:
         hi = scaled.to(torch.float16)
         lo = (scaled - hi.float()).to(torch.float16)
         return hi.contiguous(), lo.contiguous(), float(2.0 ** (-e))
+
+    def split_rows(self, x: torch.Tensor, *, pro_scale=None, pro_shift=None, pro_act=ACT_NONE, slope=0.01,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """fp32 rows [n, c] -> f16 [n, cpad/32, 2, 32] (hi | lo groups) of act(x * scale + shift): the operand
+        layout of mma_mode 2 (include/pasco_hip.h ph_split_rows)."""
+        self._chk(x, torch.float32, "in")
+        n, c = x.shape
+        if c % 8 != 0:
+            raise ValueError("split_rows: needs c % 8 == 0")
+        cpad = (c + 31) // 32 * 32
+        if out is None:
+            out = torch.empty((n, cpad // 32, 2, 32), dtype=torch.float16, device=x.device)
+        for name, t in (("pro_scale", pro_scale), ("pro_shift", pro_shift)):
+            if t is not None:
+                self._chk(t, torch.float32, name)
+                if t.numel() != c:
+                    raise ValueError(f"split_rows: {name} has {t.numel()} entries, expected {c}")
+        rc = self.fn["split_rows"](_ptr(x), n, c, _ptr(pro_scale), _ptr(pro_shift), pro_act, float(slope), _ptr(out),
+                                   _ptr(self.status_word(x.device)), self.stream(x.device))
+        self._check(rc, "split_rows")
+        return out
+
+    def split_weight_rows(self, weight: torch.Tensor, exponent=None):
+        """fp32 kernel [K, cin, cout] (or [cin, cout]) -> (w_split, 2^-e): the mode-2 operand of weight * 2^e,
+        transposed to [K, cout, cin] rows and split by `split_rows` (static weights: once, cached by callers)."""
+        w = weight.detach().float()
+        if w.dim() == 2:
+            w = w[None]
+        if exponent is not None:
+            e = int(exponent)
+        else:
+            wmax = float(w.abs().max())
+            e = 0 if wmax == 0.0 else 13 - int(torch.frexp(torch.tensor(wmax))[1])
+        k, cin, cout = w.shape
+        rows = torch.ldexp(w, torch.tensor(e, device=w.device)).transpose(1, 2).contiguous().view(k * cout, cin)
+        return self.split_rows(rows), float(2.0 ** (-e))
 
     def split_supported(self, cin: int, cout: int) -> bool:
         return self.device_type == "cuda" and cin % 8 == 0 and cout % 4 == 0

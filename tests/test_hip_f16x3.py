@@ -39,11 +39,18 @@ def test_split_conv_matches_oracle_and_fp64(hip, oracle, cin, cout, n):
     split = hip.split_weight_f16(w.cuda())
     got = hip.conv_fwd(x.cuda(), w.cuda(), nbr_h, m, split=split, **kw_h).cpu()
     assert torch.allclose(got, exp, rtol=1e-4, atol=1e-4), float((got - exp).abs().max())
+    # mode 2 (operands pre-split once): the same hi / lo values reach the same MFMAs -> identical to mode 1
+    split2 = hip.split_weight_rows(w.cuda())
+    got2 = hip.conv_fwd(x.cuda(), w.cuda(), nbr_h, m, split=split2, **kw_h).cpu()
+    assert torch.allclose(got2, exp, rtol=1e-4, atol=1e-4), float((got2 - exp).abs().max())
     # accuracy against fp64, plain conv (no fusion), next to the exact-fp32 MFMA path
     rows = torch.randint(0, m, (1500,), generator=g).cuda()
     ref = fp64_reference(x.cuda(), w.cuda(), nbr_h, rows)
     f32 = hip.conv_fwd(x.cuda(), w.cuda(), nbr_h, m)[rows].double()
-    spl = hip.conv_fwd(x.cuda(), w.cuda(), nbr_h, m, split=split)[rows].double()
+    spl_all = hip.conv_fwd(x.cuda(), w.cuda(), nbr_h, m, split=split)
+    # without a prologue the two modes feed identical hi / lo values to identical MFMA sequences
+    assert torch.equal(hip.conv_fwd(x.cuda(), w.cuda(), nbr_h, m, split=split2), spl_all)
+    spl = spl_all[rows].double()
     scale = ref.abs().mean()
     e32 = float((f32 - ref).abs().max() / scale)
     esp = float((spl - ref).abs().max() / scale)
@@ -60,3 +67,41 @@ def test_split_conv_identity_map_and_strided(hip, oracle):
     exp = oracle.conv_fwd(x, w, None, n, bias=b)
     got = hip.conv_fwd(x.cuda(), w.cuda(), None, n, bias=b.cuda(), split=hip.split_weight_f16(w.cuda())).cpu()
     assert torch.allclose(got, exp, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,c", [(1, 8), (333, 24), (5000, 64), (4097, 200), (2000, 384)])
+def test_split_rows_bit_exact(hip, oracle, n, c):
+    """ph_split_rows against the oracle's integer restatement of the f32 -> f16 hi / lo split."""
+    g = torch.Generator().manual_seed(40 + c)
+    x = (torch.randn(n, c, generator=g) * torch.exp(3 * torch.randn(n, 1, generator=g))).clamp(-6.0e4, 6.0e4)
+    x[0, 0] = 0.0
+    if n > 3:
+        x[1, 1], x[2, 2], x[3, 3] = 65504.0, -6.1e-5, 5.9e-8          # largest finite, near-subnormal, tiny
+    ps, pb = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+    for kw in ({}, dict(pro_scale=ps, pro_shift=pb, pro_act=2, slope=0.1)):
+        if kw:
+            x = x.clamp(-3.0e4, 3.0e4)
+        exp = oracle.split_rows(x, **kw)
+        kw_h = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+        got = hip.split_rows(x.cuda(), **kw_h).cpu()
+        assert torch.equal(got.view(torch.int16), exp.view(torch.int16))
+    hip.check_status(torch.device("cuda", 0))
+
+
+def test_split_conv_mode2_fullgrid_splitk(hip, oracle):
+    """Few-row / many-offset layer (the dense bottleneck shape class): split-K path with pre-split operands."""
+    g = torch.Generator().manual_seed(41)
+    xs = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(4), indexing="ij"), -1).reshape(-1, 3)
+    coords = torch.from_numpy(np.concatenate([np.zeros((xs.shape[0], 1), np.int64), xs], 1)).int()
+    tk_o, tv_o, c_o, _, _ = unique_map(oracle, coords)
+    tk_h, tv_h, c_h, _, _ = unique_map(hip, coords.cuda())
+    offs = kernel_offsets(3, 1)
+    nbr_o = oracle.nbr_build(c_o, tk_o, tv_o, offs)
+    nbr_h = hip.nbr_build(c_h, tk_h, tv_h, offs)
+    m = c_o.shape[0]
+    x = torch.randn(m, 256, generator=g)
+    w = torch.randn(27, 256, 256, generator=g) / 60
+    b = torch.randn(256, generator=g)
+    exp = oracle.conv_fwd(x, w, nbr_o, m, bias=b, epi_act=1)
+    got = hip.conv_fwd(x.cuda(), w.cuda(), nbr_h, m, bias=b.cuda(), epi_act=1, split=hip.split_weight_rows(w.cuda())).cpu()
+    assert torch.allclose(got, exp, rtol=1e-4, atol=2e-4), float((got - exp).abs().max())

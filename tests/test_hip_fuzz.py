@@ -55,6 +55,9 @@ def test_conv_fuzz(hip, oracle):
             got2 = hip.conv_fwd(x.cuda(), w.cuda(), nbr_h, m, split=hip.split_weight_f16(w.cuda()), **kw_h).cpu()
             assert torch.allclose(got2, exp, rtol=1e-3, atol=2e-4), ("split", it, ks, cin, cout, n,
                                                                       float((got2 - exp).abs().max()))
+            got3 = hip.conv_fwd(x.cuda(), w.cuda(), nbr_h, m, split=hip.split_weight_rows(w.cuda()), **kw_h).cpu()
+            assert torch.allclose(got3, exp, rtol=1e-3, atol=2e-4), ("pre-split", it, ks, cin, cout, n,
+                                                                      float((got3 - exp).abs().max()))
     hip.check_status(torch.device("cuda", 0))
 
 
@@ -71,6 +74,9 @@ def test_split_conv_range_flag(hip):
     with pytest.raises(RuntimeError, match="f16 range"):
         hip.check_status(x.device)
     hip.check_status(x.device)                       # flag cleared
+    hip.conv_fwd(x, w, None, n, split=hip.split_weight_rows(w))      # mode 2: raised by the operand split
+    with pytest.raises(RuntimeError, match="f16 range"):
+        hip.check_status(x.device)
 
 
 def test_coordinate_chain_fuzz(hip, oracle):

@@ -1,5 +1,6 @@
 """Property tests (hypothesis) of the coordinate-map semantics on the CPU oracle: negative
 coordinates, duplicates, empty inputs, strides (SURVEY.md section 4 plan item 4)."""
+import numpy as np
 import torch
 from hypothesis import given, settings, strategies as st
 
@@ -66,3 +67,29 @@ def test_expand_children_have_their_parent(oracle, rows):
         nbr = oracle.nbr_build(kids, tk, tv, kernel_offsets(2, 1, transposed=True))
         assert int((nbr >= 0).sum()) == 8 * nu            # exactly one (parent, offset) per child
         assert nbr.reshape(8, nu, 8)[0, :, 0].tolist() == list(range(nu))
+
+
+def test_oracle_split_rows_matches_numpy_float16(oracle):
+    """pho_split_rows (integer restatement of IEEE binary16 rounding) against numpy's float16 conversion,
+    including subnormals, ties and the overflow threshold; layout [n][cpad/32][hi x32 | lo x32]."""
+    rng = np.random.default_rng(5)
+    n, c = 257, 40
+    x = (rng.standard_normal((n, c)) * np.exp(rng.standard_normal((n, 1)) * 6)).astype(np.float32)
+    x = np.clip(x, -65000, 65000)
+    specials = np.array([0.0, -0.0, 65504.0, 65519.9, 6.1035156e-05, 6.0975552e-05, 5.9604645e-08, 2.9802322e-08,
+                         2.9802326e-08, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, -(1.0 + 2.0 ** -11), 1e-10], np.float32)
+    x[0, :specials.size] = specials
+    got = oracle.split_rows(torch.from_numpy(x)).numpy()                   # [n, 2, 2, 32] f16
+    assert got.shape == (n, 2, 2, 32)
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    pad = np.zeros((n, 64), np.float16)
+    exp_hi, exp_lo = pad.copy(), pad.copy()
+    exp_hi[:, :c], exp_lo[:, :c] = hi, lo
+    assert np.array_equal(got[:, :, 0, :].reshape(n, 64).view(np.int16), exp_hi.view(np.int16))
+    assert np.array_equal(got[:, :, 1, :].reshape(n, 64).view(np.int16), exp_lo.view(np.int16))
+    # hi + lo reproduces x to 2^-21 relative, or to half an f16 subnormal step (2^-25) where lo underflows
+    # (what the three-product scheme relies on)
+    rec = hi.astype(np.float64) + lo.astype(np.float64)
+    err = np.abs(rec - x.astype(np.float64))
+    assert np.all(err <= np.maximum(np.abs(x) * 2.0 ** -21, 2.0 ** -25))

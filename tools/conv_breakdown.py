@@ -25,8 +25,12 @@ with torch.no_grad():
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
 for r in prof.records:
-    key = (r["kernel"], r["kvol"], r["cin"], r["cout"], r["n_out"])
     dt = r["e0"].elapsed_time(r["e1"])
+    if r["kernel"] == "k_split_rows":
+        a = agg.setdefault(("k_split_rows", 0, r["c"], 0, r["n"]), [0, 0.0, 0])
+        a[0] += 1; a[1] += dt
+        continue
+    key = (r["kernel"], r["kvol"], r["cin"], r["cout"], r["n_out"])
     P = int((r["nbr"] >= 0).sum().item()) if r["nbr"] is not None else r["n_out"]
     a = agg.setdefault(key, [0, 0.0, P])
     a[0] += 1; a[1] += dt

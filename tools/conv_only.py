@@ -1,4 +1,4 @@
-"""Run only the k=3 conv at one S10 level (for PMC passes): conv_only.py <level: 1|2|4|U4> [iters]"""
+"""Run only the k=3 conv at one S10 level (for PMC passes): conv_only.py <level: 1|2|4|U4> [iters] [split|split2]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +18,10 @@ tk, tv, _, _, _ = be.map_insert(coords, dedup=False)
 nbr = be.nbr_build(coords, tk, tv, kernel_offsets(3, ts))
 n = coords.shape[0]
 x = torch.randn(n, c, device="cuda"); w = torch.randn(27, c, c, device="cuda") / 40; out = torch.empty(n, c, device="cuda")
+mode = sys.argv[3] if len(sys.argv) > 3 else ""
+split = be.split_weight_f16(w) if mode == "split" else (be.split_weight_rows(w) if mode == "split2" else None)
+xs2 = be.split_rows(x) if mode == "split2" else None
 for _ in range(iters):
-    be.conv_fwd(x, w, nbr, n, out=out)
+    be.conv_fwd(x, w, nbr, n, out=out, split=split, in_split=xs2)
 torch.cuda.synchronize()
 print("done", level, n, c)

@@ -17,7 +17,7 @@ def per_kernel(path, counter):
             per[key] += float(r["Counter_Value"])
             names[key] = r.get("Kernel_Name", "")
     out = {}
-    for kern in ("k_conv_f16x3", "k_conv_mfma"):
+    for kern in ("k_conv_h2", "k_conv_f16x3", "k_conv_mfma", "k_split_rows"):
         vals = [v for k, v in per.items() if kern in names[k]]
         if vals:
             out[kern] = (sum(vals) / len(vals), len(vals))
