@@ -329,8 +329,9 @@ extern "C" int ph_bits_or_reduce(const uint32_t *bits, int64_t n, int32_t b, uin
 }
 
 extern "C" int64_t ph_attn_workspace_bytes(int64_t n, int32_t b, int32_t h, int32_t qn, int32_t dh) {
-  // at most 2048 + b*h partial records
-  const int64_t qp = ((qn + 15) / 16) * 16;
+  // at most 2048 + b*h partial records, each as large as the kernel instantiation writes (7 or 8 query tiles,
+  // whatever qn is - sizing it by qn under-allocated for qn < 97)
+  const int64_t qp = qn <= 112 ? 112 : 128;
   return (int64_t)(2048 + (int64_t)b * h * 4) * qp * (dh + 4) * 4 + 256;
 }
 

@@ -111,19 +111,25 @@ class SPCDense3Dv2(nn.Module):
 
         from . import fused
 
+        in_splits = {}     # operand split of each intermediate, shared by the three branches that read it
+
         def cbr(name, x):
             ks = self._KERNELS[name]
             scale, shift = fold_bn(getattr(self, self._BNS[name]))
             w = self._row_weight(name)
-            split = None
+            split = in_split = None
             if fused.conv_precision() == "f16x3" and be.split_supported(w.shape[-2], w.shape[-1]):
                 hit = getattr(self, "_split_" + name, None)
-                if hit is None or hit[0] is not w:
-                    hit = (w, be.split_weight_f16(w))
+                if hit is None or hit[0] is not w or hit[1] != fused._PRESPLIT:
+                    hit = (w, fused._PRESPLIT, fused._split_of(w, be))
                     object.__setattr__(self, "_split_" + name, hit)
-                split = hit[1]
+                split = hit[2]
+                if fused._PRESPLIT:
+                    if id(x) not in in_splits:
+                        in_splits[id(x)] = (x, be.split_rows(x))
+                    in_split = in_splits[id(x)][1]
             return be.conv_fwd(x, w, tables.get(ks), n, epi_scale=scale, epi_shift=shift, epi_act=ACT_RELU,
-                               split=split)
+                               split=split, in_split=in_split)
 
         x = rows.contiguous()
         x1 = cbr("a_conv1", x)

@@ -65,3 +65,27 @@ def test_attn_mask_pack_and_oracle(hip, oracle):
     exp = oracle.attn_cross_fwd(q, k, v, b_o, a_o)
     got = hip.attn_cross_fwd(q.cuda(), k.cuda(), v.cuda(), b_h, a_h).cpu()
     assert torch.allclose(got, exp, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("Q", [3, 10, 100, 128])
+def test_attn_workspace_is_large_enough(hip, Q):
+    """The partial-result records are sized by the kernel instantiation (112 / 128 queries), not by Q:
+    run with an exactly-sized scratch followed by a canary region and check the canary survives."""
+    from pasco_amd.me.backend import _ptr
+    B, H, Dh, N = 2, 8, 48, 5000
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(B, H, Q, Dh, generator=g).cuda()
+    k = torch.randn(B, N, H * Dh, generator=g).cuda()
+    v = torch.randn(B, N, H * Dh, generator=g).cuda()
+    need = int(hip.fn["attn_workspace_bytes"](N, B, H, Q, Dh))
+    guard = 1 << 20
+    ws = torch.full((need + guard,), 0x5A, dtype=torch.uint8, device="cuda")
+    out = torch.empty(B, Q, H * Dh, device="cuda")
+    rc = hip.fn["attn_cross_fwd"](_ptr(q), _ptr(k), _ptr(v), None, None, _ptr(out), N, B, H, Q, Dh, _ptr(ws), need,
+                                  hip.stream(q.device))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert bool((ws[need:] == 0x5A).all()), "attention kernel wrote past its declared workspace"
+    ref = torch.nn.functional.scaled_dot_product_attention(
+        q, k.view(B, N, H, Dh).transpose(1, 2), v.view(B, N, H, Dh).transpose(1, 2), scale=1.0)
+    assert torch.allclose(out, ref.transpose(1, 2).reshape(B, Q, H * Dh), rtol=1e-4, atol=1e-4)
