@@ -99,6 +99,39 @@ def linear_rows(x2d: torch.Tensor, weight: torch.Tensor, bias, cache_owner, cach
                        residual=None if residual is None else residual.contiguous())
 
 
+def linear_bn_act(x2d: torch.Tensor, lin: nn.Linear, *, pro_bn=None, epi_bn=None, epi_act: int = ACT_NONE,
+                  min_rows: int = 16384) -> torch.Tensor:
+    """act(BN_epi(Linear(BN_pro(x)))) for a tall [N, cin] operand as ONE launch of the convolution kernel
+    (identity map, eval BatchNorm folded into the gather prologue / store epilogue) - the point MLP of
+    CylinderFeat (unet3d_sparse_v2.py:27-43) without separate normalisation / activation passes.
+    Small N, CPU tensors: plain torch modules."""
+    n, cin = x2d.shape
+    cout = lin.out_features
+    if not (x2d.is_cuda and n >= min_rows):
+        y = x2d if pro_bn is None else pro_bn(x2d)
+        y = lin(y)
+        y = y if epi_bn is None else epi_bn(y)
+        return torch.relu(y) if epi_act == ACT_RELU else y
+    from ..me.backend import backend_for
+    be = backend_for(x2d.device)
+    ps = pb = es = eb = None
+    if pro_bn is not None:
+        ps, pb = fold_bn(pro_bn)
+    if epi_bn is not None:
+        es, eb = fold_bn(epi_bn)
+    w = lin.weight
+    ver = (w._version, w.device, w.data_ptr(), _PRESPLIT, _CONV_PRECISION)
+    hit = lin.__dict__.get("_ph_lin_w")
+    if hit is None or hit[0] != ver:
+        wt = w.detach().t().contiguous()                          # [cin, cout]
+        split = _split_of(wt, be) if (_CONV_PRECISION == "f16x3" and be.split_supported(cin, cout)) else None
+        hit = (ver, wt, split, lin.bias.detach().contiguous() if lin.bias is not None else None)
+        lin.__dict__["_ph_lin_w"] = hit
+    _, wt, split, b = hit
+    return be.conv_fwd(x2d.contiguous(), wt, None, n, bias=b, pro_scale=ps, pro_shift=pb, epi_scale=es, epi_shift=eb,
+                       epi_act=epi_act, split=split)
+
+
 def batched_rows_matmul(x: torch.Tensor, w: torch.Tensor, x_split: torch.Tensor) -> torch.Tensor:
     """out[b] = x[b] @ w[b].T for tall x [B, P, D] and per-batch w [B, Q, D] that change every call (the mask
     logits of the query heads), on the split-precision kernel with `x_split` = split_rows(x) prepared once.
@@ -173,4 +206,4 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
 
 
-__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "linear_rows", "split_rows_2d", "batched_rows_matmul", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]
+__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "linear_rows", "split_rows_2d", "batched_rows_matmul", "linear_bn_act", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]

@@ -16,6 +16,8 @@ import torch.nn.functional as F
 
 from .. import me as ME
 from ..me.backend import backend_for
+from . import fused
+from .fused import ACT_RELU
 from .bottleneck import SPCDense3Dv2
 from .decoder import DecoderGenerativeSepConvV2
 from .encoder import Encoder3DSepV2
@@ -46,11 +48,21 @@ class CylinderFeat(nn.Module):
             nn.Linear(128, 256), nn.BatchNorm1d(256), nn.ReLU(),
             nn.Linear(256, out_pt_fea_dim))
 
+    def _mlp(self, fea: torch.Tensor) -> torch.Tensor:
+        """PPmodel; in eval mode each Linear runs as one fused launch with its BatchNorms / ReLU folded in."""
+        if self.training:
+            return self.PPmodel(fea)
+        m = self.PPmodel
+        h = fused.linear_bn_act(fea, m[1], pro_bn=m[0], epi_bn=m[2], epi_act=ACT_RELU)
+        h = fused.linear_bn_act(h, m[4], epi_bn=m[5], epi_act=ACT_RELU)
+        h = fused.linear_bn_act(h, m[7], epi_bn=m[8], epi_act=ACT_RELU)
+        return fused.linear_bn_act(h, m[10])
+
     def forward(self, pt_fea: List[torch.Tensor], xy_ind: List[torch.Tensor]):
         ind = torch.cat([F.pad(c, (1, 0), value=i) for i, c in enumerate(xy_ind)], dim=0)
         fea = torch.cat(pt_fea, dim=0)
         unq, inv = torch.unique(ind, return_inverse=True, dim=0)
-        h = self.PPmodel(fea)
+        h = self._mlp(fea)
         pooled = torch.full((unq.shape[0], h.shape[1]), float("-inf"), dtype=h.dtype, device=h.device)
         pooled.scatter_reduce_(0, inv[:, None].expand_as(h), h, reduce="amax", include_self=True)
         return unq.to(torch.int64), pooled

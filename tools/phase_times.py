@@ -12,12 +12,19 @@ net = bench.build_net(M, 283, dev)
 scene = make_scene(0, n_infers=M).to(dev)
 tk = TeacherKeep(scene, dev)
 times = {}
+stack = []
+from pasco_amd.graph.profiling import ConvProfiler
+from pasco_amd.me.backend import hip_backend
+prof = ConvProfiler(); prof.wrap(hip_backend())
+marks = []      # (phase name, first record index, one-past-last record index)
 
 def timed(name, fn):
     def w(*a, **k):
         torch.cuda.synchronize(); t = time.perf_counter()
+        i0 = len(prof.records)
         r = fn(*a, **k)
         torch.cuda.synchronize(); times[name] = times.get(name, 0.0) + time.perf_counter() - t
+        marks.append((name, i0, len(prof.records)))
         return r
     return w
 
@@ -40,10 +47,16 @@ tp.pred_heads = timed("    pred_heads", tp.pred_heads)
 with torch.no_grad():
     for _ in range(2):
         bench.run_scene(net, scene, tk)
-    times.clear()
+    times.clear(); marks.clear(); prof.enabled = True
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(3):
         bench.run_scene(net, scene, tk)
     torch.cuda.synchronize(); tot = (time.perf_counter() - t0) / 3
-print(json.dumps({k: round(v / 3 * 1e3, 2) for k, v in times.items()}, indent=1))
+conv = {}
+for name, i0, i1 in marks:
+    conv[name] = conv.get(name, 0.0) + sum(r["e0"].elapsed_time(r["e1"]) for r in prof.records[i0:i1])
+print("phase: wall ms  (conv + operand-split kernels ms)  other ms")
+for k, v in times.items():
+    w, c = v / 3 * 1e3, conv.get(k, 0.0) / 3
+    print(f"{k:34s} {w:7.2f}  ({c:6.2f})  {w - c:6.2f}")
 print("total ms/step (with sync overhead):", round(tot * 1e3, 2))
