@@ -159,6 +159,14 @@ typedef struct ph_conv_desc {
    * library in mode 2 (the checker build reads in / weight / pro_*).  The range flag is raised by ph_split_rows. */
   const void *in_split;
   const void *w_split;
+  /* mode 2, optional second output (cout % 32 == 0): out_split = ph_split_rows(out, osp_scale, osp_shift,
+   * osp_act, epi_slope) - the operand of the NEXT convolution, with that convolution's prologue already applied -
+   * written by the same launch.  With out_split given, `out` may be NULL (fp32 result not needed). */
+  void *out_split;
+  const float *osp_scale; /* [cout] */
+  const float *osp_shift; /* [cout] */
+  int32_t osp_act;
+  int32_t reserved2;
 } ph_conv_desc;
 
 int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);
@@ -174,6 +182,16 @@ int PH_FN(split_rows)(const float *in, int64_t n, int32_t c, const float *pro_sc
  * transformer_predictor_v2.py:100-102,234-236).  Rows without any neighbour give 0. */
 int PH_FN(maxpool_fwd)(const float *in, int32_t c, const int32_t *nbr, int32_t kvol,
                        int64_t n_out, float *out, ph_stream_t stream);
+
+/* Sine position encoding of voxel coordinates (PositionEmbeddingSineSparse, normalize=True:
+ * pasco/models/transformer/position_encoding.py via transformer_predictor_v2.py:93-95,190-199).
+ * coords = int32 rows of `cstride` ints whose x,y,z start at column `coff`; out [n, 3*f] fp32.  Per axis a:
+ *   c = float(coord); c = c / (c + 1e-6f) * scale;  ang_i = c / dim_t[i]  (dim_t [f], given by the caller)
+ *   out[row, a*f + p]       = sin(ang_{2p})      p < f/2
+ *   out[row, a*f + f/2 + p] = cos(ang_{2p+1})
+ * f even. */
+int PH_FN(sine_pe)(const int32_t *coords, int64_t n, int32_t cstride, int32_t coff, int32_t f,
+                   const float *dim_t, float scale, float *out, ph_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pruning / row movement (ME.MinkowskiPruning decoder_v3.py:159,421,427,432,496-497,

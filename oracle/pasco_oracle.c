@@ -345,6 +345,11 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
     free(acc);
     free(arow);
   }
+  if (d->out_split) {   /* second output of mma_mode 2: the next convolution's operand */
+    if (!d->out || d->cout % 32 != 0) return fail("conv_fwd: out_split needs out and cout % 32 == 0");
+    return pho_split_rows(d->out, d->n_out, d->cout, d->osp_scale, d->osp_shift, d->osp_act, d->epi_slope,
+                          d->out_split, d->status, stream);
+  }
   return 0;
 }
 
@@ -554,5 +559,29 @@ int pho_bits_or_reduce(const uint32_t *bits, int64_t n, int32_t b, uint32_t *any
       for (int64_t i = 0; i < n; ++i) m |= bits[((int64_t)bi * n + i) * 4 + w];
       any[bi * 4 + w] = m;
     }
+  return 0;
+}
+
+/* sine position encoding (include/pasco_hip.h ph_sine_pe; reference: PositionEmbeddingSineSparse with
+ * normalize=True as used by transformer_predictor_v2.py:93-95) */
+int pho_sine_pe(const int32_t *coords, int64_t n, int32_t cstride, int32_t coff, int32_t f, const float *dim_t,
+                float scale, float *out, ph_stream_t stream) {
+  (void)stream;
+  if (n < 0 || f <= 0 || f % 2 != 0 || cstride < 3 || coff < 0 || coff + 3 > cstride) return fail("sine_pe: bad shape");
+  if (n == 0) return 0;
+  if (!coords || !dim_t || !out) return fail("sine_pe: null buffer");
+  const int half = f / 2;
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < n; ++r) {
+    for (int a = 0; a < 3; ++a) {
+      float c = (float)coords[r * cstride + coff + a];
+      c = c / (c + 1e-6f) * scale;
+      float *o = out + r * 3 * f + a * f;
+      for (int p = 0; p < half; ++p) {
+        o[p] = sinf(c / dim_t[2 * p]);
+        o[half + p] = cosf(c / dim_t[2 * p + 1]);
+      }
+    }
+  }
   return 0;
 }

@@ -343,7 +343,8 @@ extern "C" int ph_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   if (d->n_out == 0) return 0;
   PH_REQUIRE(d->nbr != nullptr || (d->kvol == 1 && d->n_in == d->n_out),
              "conv_fwd: identity map needs kvol == 1 and n_in == n_out");
-  PH_REQUIRE(d->out && (d->mma_mode == 2 || (d->in && d->weight)), "conv_fwd: null tensor");   // mode 2 reads only the pre-split operands
+  // mode 2 reads only the pre-split operands and may write only the split output
+  PH_REQUIRE((d->out || (d->mma_mode == 2 && d->out_split)) && (d->mma_mode == 2 || (d->in && d->weight)), "conv_fwd: null tensor");
   if (d->mma_mode == 1 || d->mma_mode == 2) return ph_conv_fwd_f16x3(d, ph_stream(stream));
   PH_REQUIRE(d->mma_mode == 0, "conv_fwd: unknown mma_mode %d", d->mma_mode);
   ConvArgs a;

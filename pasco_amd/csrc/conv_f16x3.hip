@@ -25,6 +25,8 @@ constexpr int HV_THREADS = 256;
 // KC input channels per stage (32 or 64); LDS rows hold KC + 8 f16 (80 / 144 bytes: 16-byte aligned and
 // conflict-free for the b128 fragment reads)
 
+__device__ __forceinline__ float h_act(float v, float neg) { return fmaxf(v, 0.f) + neg * fminf(v, 0.f); }
+
 struct ConvArgsH {
   const float *in;
   const _Float16 *w_hi;   // [kvol][cout][cin]
@@ -44,9 +46,36 @@ struct ConvArgsH {
   const _Float16 *in_split;   // [n_in][cpad/32][2][32]
   const _Float16 *w_split;    // [kvol][cout][cpad/32][2][32]
   int cpad;
+  // optional second output: split operand of act(out * osp_scale + osp_shift) for the next convolution
+  _Float16 *out_split;        // [n_out][cout/32][2][32]  (cout % 32 == 0)
+  const float *osp_scale, *osp_shift;
+  float osp_neg;
+  int osp_has;
 };
 
-__device__ __forceinline__ float h_act(float v, float neg) { return fmaxf(v, 0.f) + neg * fminf(v, 0.f); }
+// hi / lo halves of four values -> the [hi x32 | lo x32] group layout (dst points at the run's hi slot)
+__device__ __forceinline__ float emit_split4(const float v[4], const float *sc, const float *sh, int has, float neg,
+                                             _Float16 *dst) {
+  f16x4 hi, lo;
+  float xmax = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float t = v[q];
+    if (has) {   // separate multiply and add, like ph_split_rows and the C restatement
+#pragma clang fp contract(off)
+      const float m = t * (sc ? sc[q] : 1.f);
+      t = h_act(m + (sh ? sh[q] : 0.f), neg);
+    }
+    xmax = fmaxf(xmax, fabsf(t));
+    const _Float16 th = (_Float16)t;
+    hi[q] = th;
+    lo[q] = (_Float16)(t - (float)th);
+  }
+  *reinterpret_cast<f16x4 *>(dst) = hi;
+  *reinterpret_cast<f16x4 *>(dst + 32) = lo;
+  return xmax;
+}
+
 
 template <int BM, int KC, int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
@@ -473,6 +502,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
     return;
   }
 
+  float omax = 0.f;
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -502,9 +532,20 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = h_act(v[q] * es2[q] + eb2[q] + r4[q], a.res_neg);
         }
-        *reinterpret_cast<float4 *>(a.out + row * cout + col) = make_float4(v[0], v[1], v[2], v[3]);
+        if (a.out) *reinterpret_cast<float4 *>(a.out + row * cout + col) = make_float4(v[0], v[1], v[2], v[3]);
+        if (a.out_split) {
+          float sc[4], sh[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            sc[q] = a.osp_scale ? a.osp_scale[col + q] : 1.f;
+            sh[q] = a.osp_shift ? a.osp_shift[col + q] : 0.f;
+          }
+          omax = fmaxf(omax, emit_split4(v, sc, sh, a.osp_has, a.osp_neg,
+                                         a.out_split + (row * (cout >> 5) + (col >> 5)) * 64 + (col & 31)));
+        }
       }
     }
+  if (a.out_split && a.status != nullptr && !(omax <= 65504.f)) atomicOr(a.status, 1);
 }
 
 // fp32 rows -> [hi x32 | lo x32] groups; one thread per 8 channels.  Channels >= c (pad to 32) are zero.
@@ -559,22 +600,46 @@ extern "C" int ph_split_rows(const float *in, int64_t n, int32_t c, const float 
   return 0;
 }
 
-// out = epilogue( sum_s partial[s] )  - one thread per output element, splits summed in index order
+// out = epilogue( sum_s partial[s] )  - one thread per 4-channel run, splits summed in index order
 __global__ void __launch_bounds__(256) k_splitk_epilogue(ConvArgsH a) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int64_t total = a.n_out * a.cout;
   if (t >= total) return;
-  const int col = (int)(t % a.cout);
-  float acc = 0.f;
-  for (int s = 0; s < a.ksplit; ++s) acc += a.partial[(int64_t)s * total + t];
-  float v = acc * a.w_unscale + (a.bias ? a.bias[col] : 0.f);
-  v = h_act(v * (a.epi_scale ? a.epi_scale[col] : 1.f) + (a.epi_shift ? a.epi_shift[col] : 0.f), a.epi_neg);
-  if (a.has_tail) {
-    v = v * (a.epi2_scale ? a.epi2_scale[col] : 1.f) + (a.epi2_shift ? a.epi2_shift[col] : 0.f);
-    if (a.residual) v += a.residual[t];
-    v = h_act(v, a.res_neg);
+  const int64_t row = t / a.cout;
+  const int col = (int)(t - row * a.cout);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < a.ksplit; ++s) {
+    const float4 p = *reinterpret_cast<const float4 *>(a.partial + (int64_t)s * total + t);
+    acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
   }
-  a.out[t] = v;
+  const float av[4] = {acc.x, acc.y, acc.z, acc.w};
+  float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.has_tail && a.residual) rs = *reinterpret_cast<const float4 *>(a.residual + t);
+  const float r4[4] = {rs.x, rs.y, rs.z, rs.w};
+  float v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = col + q;
+    float x = av[q] * a.w_unscale + (a.bias ? a.bias[c] : 0.f);
+    x = h_act(x * (a.epi_scale ? a.epi_scale[c] : 1.f) + (a.epi_shift ? a.epi_shift[c] : 0.f), a.epi_neg);
+    if (a.has_tail) {
+      x = x * (a.epi2_scale ? a.epi2_scale[c] : 1.f) + (a.epi2_shift ? a.epi2_shift[c] : 0.f);
+      x = h_act(x + r4[q], a.res_neg);
+    }
+    v[q] = x;
+  }
+  if (a.out) *reinterpret_cast<float4 *>(a.out + t) = make_float4(v[0], v[1], v[2], v[3]);
+  if (a.out_split) {
+    float sc[4], sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      sc[q] = a.osp_scale ? a.osp_scale[col + q] : 1.f;
+      sh[q] = a.osp_shift ? a.osp_shift[col + q] : 0.f;
+    }
+    const float omax = emit_split4(v, sc, sh, a.osp_has, a.osp_neg,
+                                   a.out_split + (row * (a.cout >> 5) + (col >> 5)) * 64 + (col & 31));
+    if (a.status != nullptr && !(omax <= 65504.f)) atomicOr(a.status, 1);
+  }
 }
 
 template <int BM, int KC, int WM, int WN, int TM, int TN>
@@ -589,7 +654,7 @@ static int launch_h(const ConvArgsH &a, hipStream_t st) {
   PH_LAUNCH_CHECK();
   if (args.ksplit > 1) {
     const int64_t total = a.n_out * a.cout;
-    hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, args);
+    hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, args);
     PH_LAUNCH_CHECK();
   }
   return 0;
@@ -607,7 +672,7 @@ static int launch_h2(const ConvArgsH &a, hipStream_t st) {
   PH_LAUNCH_CHECK();
   if (args.ksplit > 1) {
     const int64_t total = a.n_out * a.cout;
-    hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, args);
+    hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, args);
     PH_LAUNCH_CHECK();
   }
   return 0;
@@ -632,6 +697,16 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.in_split = (const _Float16 *)d->in_split;
   a.w_split = (const _Float16 *)d->w_split;
   a.cpad = (d->cin + 31) / 32 * 32;
+  a.out_split = (_Float16 *)d->out_split;
+  a.osp_scale = d->osp_scale;
+  a.osp_shift = d->osp_shift;
+  a.osp_has = (d->osp_scale || d->osp_shift || d->osp_act != PH_ACT_NONE) ? 1 : 0;
+  a.osp_neg = d->osp_act == PH_ACT_RELU ? 0.f : (d->osp_act == PH_ACT_LEAKY ? d->epi_slope : 1.f);
+  if (d->out_split) {
+    PH_REQUIRE(pre, "conv_fwd(f16x3): out_split needs mma_mode 2");
+    PH_REQUIRE(d->cout % 32 == 0 && (((uintptr_t)d->out_split) & 15) == 0, "conv_fwd(f16x3): out_split needs cout %% 32 == 0");
+  }
+  PH_REQUIRE(d->out || d->out_split, "conv_fwd(f16x3): no output buffer");
   a.in = d->in;
   a.w_hi = (const _Float16 *)d->w_f16_hi;
   a.w_lo = (const _Float16 *)d->w_f16_lo;

@@ -50,10 +50,16 @@ class ResidualBlock(nn.Module):
             ME.MinkowskiConvolution(inc, outc, kernel_size=1, dilation=1, stride=stride, dimension=D))
         self.relu = ME.MinkowskiReLU(inplace=True)
 
-    def forward(self, x: ME.SparseTensor) -> ME.SparseTensor:
+    def next_prologue(self):
+        """What this block's first convolution applies to its input: lets the producer of that input emit the
+        pre-split operand in its own epilogue (fused.conv emit_next)."""
+        return (self.net[0], ACT_RELU)
+
+    def forward(self, x: ME.SparseTensor, emit_next=None) -> ME.SparseTensor:
         skip = x if len(self.downsample) == 0 else fused.conv(x, self.downsample[0])
-        y = fused.conv(x, self.net[2], pro_bn=self.net[0], pro_act=ACT_RELU, epi_bn=self.net[3], epi_act=ACT_RELU)
-        return fused.conv(y, self.net[5], residual=skip.F, res_act=ACT_RELU)
+        y = fused.conv(x, self.net[2], pro_bn=self.net[0], pro_act=ACT_RELU, epi_bn=self.net[3], epi_act=ACT_RELU,
+                       emit_next=(None, ACT_NONE))
+        return fused.conv(y, self.net[5], residual=skip.F, res_act=ACT_RELU, emit_next=emit_next)
 
 
 class BasicConvolutionBlock(nn.Module):
@@ -68,9 +74,10 @@ class BasicConvolutionBlock(nn.Module):
             ME.MinkowskiLeakyReLU(inplace=True),
         )
 
-    def forward(self, x, post_bn=None, post_act=ACT_NONE):
+    def forward(self, x, post_bn=None, post_act=ACT_NONE, emit_next=None):
         return fused.conv(x, self.net[0], epi_bn=self.net[1], epi_act=ACT_LEAKY,
-                          slope=self.net[2].module.negative_slope, epi2_bn=post_bn, res_act=post_act)
+                          slope=self.net[2].module.negative_slope, epi2_bn=post_bn, res_act=post_act,
+                          emit_next=emit_next)
 
 
 class BasicGenerativeDeconvolutionBlock(nn.Module):
@@ -90,21 +97,43 @@ class BasicGenerativeDeconvolutionBlock(nn.Module):
                           slope=self.net[2].module.negative_slope, out_key=out_key, nbr=nbr)
 
 
-def run_sequential(seq: nn.Sequential, x):
+def first_prologue(seq: nn.Sequential):
+    """(bn, act) the first convolution of `seq` applies to its input, or None when unknown: a ResidualBlock reads
+    ReLU(BN0(x)), a BasicConvolutionBlock reads x as it is."""
+    for m in seq:
+        if isinstance(m, (nn.Identity, SpatialDropout)):
+            continue
+        if isinstance(m, ResidualBlock):
+            return m.next_prologue()
+        if isinstance(m, BasicConvolutionBlock):
+            return (None, ACT_NONE)
+        return None
+    return None
+
+
+def run_sequential(seq: nn.Sequential, x, emit_last=None):
     """Run a reference-shaped nn.Sequential, folding `BasicConvolutionBlock, BN, ReLU` triples and
-    skipping identities / dropouts."""
-    mods = list(seq)
+    skipping identities / dropouts.  `emit_last` = prologue of whatever convolution reads the result
+    (fused.conv emit_next), when the caller knows it."""
+    mods = [m for m in seq if not isinstance(m, (nn.Identity, SpatialDropout))]
+
+    def emit_for(j):
+        """prologue of the module that will read the output of the step ending before index j"""
+        if j >= len(mods):
+            return emit_last
+        return mods[j].next_prologue() if isinstance(mods[j], ResidualBlock) else None
+
     i = 0
     while i < len(mods):
         m = mods[i]
         if isinstance(m, BasicConvolutionBlock) and i + 2 < len(mods) and \
                 isinstance(mods[i + 1], ME.MinkowskiBatchNorm) and isinstance(mods[i + 2], ME.MinkowskiReLU):
-            x = m(x, post_bn=mods[i + 1], post_act=ACT_RELU)
+            x = m(x, post_bn=mods[i + 1], post_act=ACT_RELU, emit_next=emit_for(i + 3))
             i += 3
             continue
-        if isinstance(m, (nn.Identity, SpatialDropout)):
-            i += 1
-            continue
-        x = m(x)
+        if isinstance(m, (ResidualBlock, BasicConvolutionBlock)):
+            x = m(x, emit_next=emit_for(i + 1))
+        else:
+            x = m(x)
         i += 1
     return x

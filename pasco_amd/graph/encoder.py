@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from .. import me as ME
 from . import fused
-from .blocks import BasicConvolutionBlock, ResidualBlock, SpatialDropout, run_sequential
+from .blocks import BasicConvolutionBlock, ResidualBlock, SpatialDropout, first_prologue, run_sequential
 
 
 class Encoder3DSepV2(nn.Module):
@@ -35,8 +35,10 @@ class Encoder3DSepV2(nn.Module):
 
     def forward(self, x: ME.SparseTensor):
         assert not self.training, "inference only"
-        s1 = run_sequential(self.s1, fused.conv(x, self.enc_in_feats))
-        s2 = run_sequential(self.s1s2, s1)
-        s4 = run_sequential(self.s2s4, s2)
+        # each stage's last launch also writes the next stage's first operand (fused.conv emit_next)
+        s1 = run_sequential(self.s1, fused.conv(x, self.enc_in_feats, emit_next=first_prologue(self.s1)),
+                            emit_last=first_prologue(self.s1s2))
+        s2 = run_sequential(self.s1s2, s1, emit_last=first_prologue(self.s2s4))
+        s4 = run_sequential(self.s2s4, s2, emit_last=first_prologue(self.s4s8))
         s8 = run_sequential(self.s4s8, s4)
         return [s1, s2, s4, s8]

@@ -51,8 +51,7 @@ def split_input(x: SparseTensor, be, ps, pb, pro_act, slope):
     """Pre-split rows of act(x.F * ps + pb), cached on the SparseTensor (several consumers of one tensor with the
     same prologue - e.g. the per-subnet heads - split it once)."""
     F = x.F if x.F.is_contiguous() else x.F.contiguous()
-    key = (F.data_ptr(), F._version, None if ps is None else ps.data_ptr(), None if pb is None else pb.data_ptr(),
-           pro_act, float(slope))
+    key = _split_key(F, ps, pb, pro_act, slope)
     cache = x.__dict__.setdefault("_ph_in_split", {})
     hit = cache.get(key)
     if hit is None:
@@ -173,13 +172,21 @@ def fold_bn(bn) -> Tuple[torch.Tensor, torch.Tensor]:
     return scale, shift
 
 
+def _split_key(F, ps, pb, pro_act, slope):
+    return (F.data_ptr(), F._version, None if ps is None else ps.data_ptr(), None if pb is None else pb.data_ptr(),
+            pro_act, float(slope) if pro_act == ACT_LEAKY else 0.0)
+
+
 def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NONE, epi_bn=None,
          epi_act: int = ACT_NONE, epi2_bn=None, residual: Optional[torch.Tensor] = None,
-         res_act: int = ACT_NONE, slope: float = 0.01, out_key=None, nbr=None) -> SparseTensor:
+         res_act: int = ACT_NONE, slope: float = 0.01, out_key=None, nbr=None, emit_next=None) -> SparseTensor:
     """One fused launch of a Minkowski-style convolution module on `x`.
 
     out = act_res( act_epi(BN_epi(conv(act_pro(BN_pro(x))) + bias)) -> BN_epi2 -> (+ residual) )
-    """
+
+    `emit_next` = (bn | None, act): the caller knows the next convolution reads act(BN(out)); the launch then also
+    writes that convolution's pre-split operand (no separate ph_split_rows pass) and leaves it in the returned
+    tensor's operand cache, where the next `conv` call finds it."""
     mgr = x.coordinate_manager
     if out_key is None:
         out_key, nbr = mod._maps(x)
@@ -198,12 +205,23 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
         split = split_weight(mod, be)
         if _PRESPLIT and n_out > 0:
             in_split = split_input(x, be, ps, pb, pro_act, slope)
+    emit = None
+    if emit_next is not None and in_split is not None and mod.out_channels % 32 == 0:
+        nbn, nact = emit_next
+        ns, nb = fold_bn(nbn) if nbn is not None else (None, None)
+        emit = (ns, nb, nact)
     out = be.conv_fwd(
         x.F if x.F.is_contiguous() else x.F.contiguous(), mod.kernel.detach(), nbr, n_out, bias=bias,
         pro_scale=ps, pro_shift=pb, pro_act=pro_act, epi_scale=es, epi_shift=eb, epi_act=epi_act,
         epi2_scale=e2s, epi2_shift=e2b, residual=residual, res_act=res_act, slope=slope, split=split,
-        in_split=in_split)
-    return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
+        in_split=in_split, emit_split=emit)
+    if emit is None:
+        return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
+    out, out_split = out
+    y = SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
+    # key it the way the next conv's split_input will look it up (a leaky prologue would use this launch's slope)
+    y.__dict__.setdefault("_ph_in_split", {})[_split_key(y.F, emit[0], emit[1], emit[2], slope)] = out_split
+    return y
 
 
 __all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "linear_rows", "split_rows_2d", "batched_rows_matmul", "linear_bn_act", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]

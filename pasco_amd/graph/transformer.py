@@ -48,8 +48,25 @@ class PositionEmbeddingSineSparse(nn.Module):
         self.temperature = temperature
         self.scale = 2 * math.pi if scale is None else scale
 
-    def forward(self, coords):
-        return sine_position_encoding(coords, self.num_pos_feats, self.temperature, self.scale)
+    def dim_t(self, device) -> torch.Tensor:
+        hit = self.__dict__.get("_dim_t")
+        if hit is None or hit.device != device:
+            i = torch.arange(self.num_pos_feats, dtype=torch.float32, device=device)
+            hit = (self.temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / self.num_pos_feats)).contiguous()
+            self.__dict__["_dim_t"] = hit
+        return hit
+
+    def forward(self, coords, coff: int = 0):
+        """coords [N, >=3] integer rows with x,y,z from column `coff`.  On a device with a backend: one kernel
+        (ph_sine_pe); otherwise the torch formula."""
+        if coords.dtype == torch.int32 and coords.is_contiguous() and (coords.is_cuda or _has_checker()):
+            return backend_for(coords.device).sine_pe(coords, self.dim_t(coords.device), self.scale, coff)
+        return sine_position_encoding(coords[:, coff:coff + 3], self.num_pos_feats, self.temperature, self.scale)
+
+
+def _has_checker() -> bool:
+    from ..me import backend
+    return backend._checker_backend is not None
 
 
 def _xavier(module):
@@ -259,7 +276,7 @@ class TransformerPredictorV2(nn.Module):
             f, c = xs[s]
             srcs.append(f)
             src_Cs.append(c)
-            pos.append(self.pe_layer(c.reshape(-1, 4)[:, 1:]).reshape(B, -1, D))
+            pos.append(self.pe_layer(c.reshape(-1, 4), coff=1).reshape(B, -1, D))
         voxel_coord = xs[1][1]
         x1 = xs[1][0]
         voxel_feat = linear_rows(x1.reshape(-1, x1.shape[-1]), self.mask_feat_proj.weight, self.mask_feat_proj.bias,

@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("mma_mode", _i32), ("w_unscale", C.c_float), ("w_f16_hi", _vp), ("w_f16_lo", _vp),
         ("splitk_ws", _vp), ("splitk_ws_bytes", _i64), ("status", _vp),
         ("in_split", _vp), ("w_split", _vp),
+        ("out_split", _vp), ("osp_scale", _vp), ("osp_shift", _vp), ("osp_act", _i32), ("reserved2", _i32),
     ]
 
 
@@ -63,6 +64,7 @@ _SIGNATURES = {
     "to_dense": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp],
     "to_sparse_coords": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "dense_gather": [_vp, _i32, _vp, _vp, _i64, _vp, _vp],
+    "sine_pe": [_vp, _i64, _i32, _i32, _i32, _vp, C.c_float, _vp, _vp],
     "attn_workspace_bytes": [_i64, _i32, _i32, _i32, _i32],
     "attn_mask_pack": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
     "bits_orpool": [_vp, _vp, _i32, _i64, _vp, _vp],
@@ -231,7 +233,11 @@ class CBackend:
                  *, wshape=None, bias=None, pro_scale=None, pro_shift=None, pro_act=ACT_NONE, epi_scale=None,
                  epi_shift=None, epi_act=ACT_NONE, slope=0.01, residual=None, res_act=ACT_NONE,
                  epi2_scale=None, epi2_shift=None, split=None, in_split: Optional[torch.Tensor] = None,
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 emit_split=None, want_out: bool = True,
+                 out: Optional[torch.Tensor] = None):
+        """... `emit_split` = (scale | None, shift | None, act) (mode 2, cout % 32 == 0): also write the split operand
+        of act(out * scale + shift) for the next convolution and return (out, out_split); `want_out=False` then
+        skips the fp32 result (returns (None, out_split))."""
         self._chk(x, torch.float32, "in")
         if weight is None:     # pre-split operands only (mode 2): the fp32 kernel is not read, `wshape` = (kvol, cin, cout)
             if wshape is None or split is None or len(split) != 2 or self.device_type != "cuda":
@@ -249,11 +255,23 @@ class CBackend:
             self._chk(nbr, torch.int32, "nbr")
             if tuple(nbr.shape) != (kvol, n_out):
                 raise ValueError(f"conv: nbr shape {tuple(nbr.shape)} != {(kvol, n_out)}")
-        if out is None:
+        emit = emit_split is not None and split is not None and len(split) == 2 and cout % 32 == 0
+        if emit_split is not None and not emit:
+            raise ValueError("conv: emit_split needs a mode-2 split and cout % 32 == 0")
+        if out is None and (want_out or not emit):
             out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
+        out_split = torch.empty((n_out, cout // 32, 2, 32), dtype=torch.float16, device=x.device) if emit else None
         if n_out == 0:
-            return out
+            return (out, out_split) if emit else out
         d = ConvDesc()
+        if emit:
+            osc, osh, oact = emit_split
+            for name, t in (("osp_scale", osc), ("osp_shift", osh)):
+                if t is not None:
+                    self._chk(t, torch.float32, name)
+                    if t.numel() != cout:
+                        raise ValueError(f"conv: {name} has {t.numel()} entries, expected {cout}")
+            d.out_split, d.osp_scale, d.osp_shift, d.osp_act = _ptr(out_split), _ptr(osc), _ptr(osh), int(oact)
         d.in_, d.weight, d.nbr, d.out = _ptr(x), _ptr(weight), _ptr(nbr), _ptr(out)
         d.n_in, d.n_out, d.cin, d.cout, d.kvol = x.shape[0], n_out, cin, cout, kvol
         d.pro_act, d.epi_act, d.res_act, d.epi_slope = pro_act, epi_act, res_act, float(slope)
@@ -296,7 +314,7 @@ class CBackend:
                 d.splitk_ws, d.splitk_ws_bytes = _ptr(sk), sk.numel()
         rc = self.fn["conv_fwd"](C.byref(d), self.stream(x.device))
         self._check(rc, "conv_fwd")
-        return out
+        return (out, out_split) if emit else out
 
     def status_word(self, device) -> torch.Tensor:
         """Device word the split-precision kernels OR their range flag into (one per device)."""
@@ -499,6 +517,18 @@ class CBackend:
         out = torch.empty((b, 4), dtype=torch.int32, device=bits.device)
         rc = self.fn["bits_or_reduce"](_ptr(bits), n, b, _ptr(out), self.stream(bits.device))
         self._check(rc, "bits_or_reduce")
+        return out
+
+    def sine_pe(self, coords: torch.Tensor, dim_t: torch.Tensor, scale: float, coff: int = 0) -> torch.Tensor:
+        """coords int32 [N, cstride] (x,y,z from column `coff`) -> [N, 3*f] sine position encoding."""
+        self._chk(coords, torch.int32, "coords")
+        self._chk(dim_t, torch.float32, "dim_t")
+        n, cstride = coords.shape
+        f = dim_t.numel()
+        out = torch.empty((n, 3 * f), dtype=torch.float32, device=coords.device)
+        rc = self.fn["sine_pe"](_ptr(coords), n, cstride, coff, f, _ptr(dim_t), float(scale), _ptr(out),
+                                self.stream(coords.device))
+        self._check(rc, "sine_pe")
         return out
 
     def attn_supported(self, qn: int, dh: int) -> bool:

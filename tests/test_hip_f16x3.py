@@ -105,3 +105,30 @@ def test_split_conv_mode2_fullgrid_splitk(hip, oracle):
     exp = oracle.conv_fwd(x, w, nbr_o, m, bias=b, epi_act=1)
     got = hip.conv_fwd(x.cuda(), w.cuda(), nbr_h, m, bias=b.cuda(), epi_act=1, split=hip.split_weight_rows(w.cuda())).cpu()
     assert torch.allclose(got, exp, rtol=1e-4, atol=2e-4), float((got - exp).abs().max())
+
+
+@pytest.mark.parametrize("cout,n,ksplit_shape", [(64, 20000, False), (128, 9000, False), (256, 1500, True)])
+def test_conv_emits_next_operand(hip, oracle, cout, n, ksplit_shape):
+    """mode 2 with out_split: the second output is bit-identical to ph_split_rows of the fp32 output with the
+    next layer's prologue, for the direct epilogue and for the split-K epilogue; out may be skipped."""
+    coords = scene_coords(51, n)
+    tk_h, tv_h, c_h, _, _ = unique_map(hip, coords.cuda())
+    nbr_h = hip.nbr_build(c_h, tk_h, tv_h, kernel_offsets(3, 1))
+    m = c_h.shape[0]
+    g = torch.Generator().manual_seed(52)
+    cin = 64
+    x = torch.randn(m, cin, generator=g).cuda()
+    w = (torch.randn(27, cin, cout, generator=g) / 30).cuda()
+    res = torch.randn(m, cout, generator=g).cuda()
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.3).cuda()
+    split = hip.split_weight_rows(w)
+    for emit in ((None, None, 0), (sc, sh, 1), (sc, None, 2)):
+        out, osp = hip.conv_fwd(x, w, nbr_h, m, split=split, residual=res, res_act=1, slope=0.2, emit_split=emit)
+        plain = hip.conv_fwd(x, w, nbr_h, m, split=split, residual=res, res_act=1, slope=0.2)
+        assert torch.equal(out, plain)
+        exp = hip.split_rows(out, pro_scale=emit[0], pro_shift=emit[1], pro_act=emit[2], slope=0.2)
+        assert torch.equal(osp.view(torch.int16), exp.view(torch.int16))
+        none_out, osp2 = hip.conv_fwd(x, w, nbr_h, m, split=split, residual=res, res_act=1, slope=0.2, emit_split=emit,
+                                      want_out=False)
+        assert none_out is None and torch.equal(osp2.view(torch.int16), exp.view(torch.int16))
+    hip.check_status(x.device)

@@ -225,3 +225,17 @@ def test_rows_and_dense_exact(hip, oracle):
     assert torch.equal(ch.cpu(), co) and torch.equal(fh.cpu(), fo)
     assert co.shape[0] == int((f != 0).any(dim=1).sum())
 
+
+
+def test_sine_pe_matches_oracle_and_torch(hip, oracle):
+    from pasco_amd.graph.transformer import PositionEmbeddingSineSparse, sine_position_encoding
+    g = torch.Generator().manual_seed(90)
+    c4 = torch.randint(-40, 300, (7001, 4), generator=g, dtype=torch.int32)
+    c4[:50, 1:] = 0
+    pe = PositionEmbeddingSineSparse(128, normalize=True)
+    exp = oracle.sine_pe(c4, pe.dim_t(torch.device("cpu")), pe.scale, coff=1)
+    got = pe(c4.cuda(), coff=1)
+    assert got.shape == (7001, 384)
+    assert torch.allclose(got.cpu(), exp, atol=2e-6, rtol=0)
+    ref = sine_position_encoding(c4.cuda()[:, 1:], 128)
+    assert torch.allclose(got, ref, atol=2e-6, rtol=0)

@@ -44,6 +44,15 @@ tp.compute_mask_bits = timed("    attn_mask", tp.compute_mask_bits)
 for i, l in enumerate(tp.transformer_cross_attention_layers):
     l.forward = timed(f"    xattn{i}", l.forward)
 tp.pred_heads = timed("    pred_heads", tp.pred_heads)
+tp.pe_layer.forward = timed("    pos_enc", tp.pe_layer.forward)
+for i, l in enumerate(tp.transformer_self_attention_layers):
+    l.forward = timed("    self_attn", l.forward)
+for i, l in enumerate(tp.transformer_ffn_layers):
+    l.forward = timed("    ffn", l.forward)
+T.linear_rows = timed("    linear_rows(all)", T.linear_rows)
+D.batch_sparse_tensor = timed("  batch_sparse_tensor", D.batch_sparse_tensor)
+net.feat._mlp = timed("  point_mlp", net.feat._mlp)
+U.merge_subnet_inputs = timed("  merge_subnet_inputs", U.merge_subnet_inputs)
 with torch.no_grad():
     for _ in range(2):
         bench.run_scene(net, scene, tk)
