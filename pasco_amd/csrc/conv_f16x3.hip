@@ -329,7 +329,10 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
 // time in VALU converting every row up to 27 times, profiles/README.md "SQ counters, split kernel").
 // A row of a tile = KC/32 groups of [32 hi | 32 lo] f16 (+8 pad): LD = 2*KC + 8.
 // ------------------------------------------------------------------------------------------------------
-template <int BM, int KC, int WM, int WN, int TM, int TN>
+// EMIT = the launch also writes the next convolution's operand (out_split).  A separate instantiation: the
+// emission code raises the kernel's register budget (one wave of occupancy less), which launches that do not
+// emit should not pay for.
+template <int BM, int KC, int WM, int WN, int TM, int TN, bool EMIT>
 __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
   constexpr int BN = WN * TN * 32;
   constexpr int LD = 2 * KC + 8;
@@ -506,46 +509,91 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int col = n0 + (wn * TN + j) * 32 + 8 * g + 4 * h;
-      if (col >= cout) continue;          // cout % 4 == 0: a run is entirely inside or outside
-      float bias[4], es[4], eb[4], es2[4], eb2[4];
+    for (int m = 0; m < 2; ++m) {       // pairs of 4-channel runs: g = 2m, 2m + 1
+      const int cbase = n0 + (wn * TN + j) * 32 + 16 * m;
+      if (cbase >= cout) continue;      // uniform over the wave (cout % 4 == 0; with out_split cout % 32 == 0)
+      float bias[2][4], es[2][4], eb[2][4], es2[2][4], eb2[2][4];
+      bool cok[2];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        bias[q] = a.bias ? a.bias[col + q] : 0.f;
-        es[q] = a.epi_scale ? a.epi_scale[col + q] : 1.f;
-        eb[q] = a.epi_shift ? a.epi_shift[col + q] : 0.f;
-        es2[q] = a.epi2_scale ? a.epi2_scale[col + q] : 1.f;
-        eb2[q] = a.epi2_shift ? a.epi2_shift[col + q] : 0.f;
+      for (int u = 0; u < 2; ++u) {
+        const int col = cbase + 8 * u + 4 * h;
+        cok[u] = col < cout;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = cok[u] ? col + q : 0;
+          bias[u][q] = a.bias ? a.bias[c] : 0.f;
+          es[u][q] = a.epi_scale ? a.epi_scale[c] : 1.f;
+          eb[u][q] = a.epi_shift ? a.epi_shift[c] : 0.f;
+          es2[u][q] = a.epi2_scale ? a.epi2_scale[c] : 1.f;
+          eb2[u][q] = a.epi2_shift ? a.epi2_shift[c] : 0.f;
+        }
+      }
+      // operand emission: after a half-wave exchange this lane owns 8 consecutive channels cbase + 8h .. + 7
+      float sc[8], sh[8];
+      if (EMIT) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          sc[q] = a.osp_scale ? a.osp_scale[cbase + 8 * h + q] : 1.f;
+          sh[q] = a.osp_shift ? a.osp_shift[cbase + 8 * h + q] : 0.f;
+        }
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int64_t row = m0 + (wm * TM + i) * 32 + l31;
-        if (row >= a.n_out) continue;
-        float v[4];
+        const bool rok = row < a.n_out;
+        float v[2][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = h_act((acc[i][j][4 * g + q] * a.w_unscale + bias[q]) * es[q] + eb[q], a.epi_neg);
-        if (a.has_tail) {
-          float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (a.residual) rs = *reinterpret_cast<const float4 *>(a.residual + row * cout + col);
-          const float r4[4] = {rs.x, rs.y, rs.z, rs.w};
+        for (int u = 0; u < 2; ++u) {
+          const int g = 2 * m + u;
+          const int col = cbase + 8 * u + 4 * h;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = h_act(v[q] * es2[q] + eb2[q] + r4[q], a.res_neg);
+          for (int q = 0; q < 4; ++q)
+            v[u][q] = h_act((acc[i][j][4 * g + q] * a.w_unscale + bias[u][q]) * es[u][q] + eb[u][q], a.epi_neg);
+          if (a.has_tail) {
+            float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.residual && rok && cok[u]) rs = *reinterpret_cast<const float4 *>(a.residual + row * cout + col);
+            const float r4[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[u][q] = h_act(v[u][q] * es2[u][q] + eb2[u][q] + r4[q], a.res_neg);
+          }
+          if ((!EMIT || a.out) && rok && cok[u])
+            *reinterpret_cast<float4 *>(a.out + row * cout + col) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
         }
-        if (a.out) *reinterpret_cast<float4 *>(a.out + row * cout + col) = make_float4(v[0], v[1], v[2], v[3]);
-        if (a.out_split) {
-          float sc[4], sh[4];
+        if (EMIT) {
+          // lanes l and l ^ 32 hold the same row: h = 0 keeps run u = 0 and takes the partner's u = 0 (channels
+          // +4..7); h = 1 takes the partner's u = 1 (channels +8..11) and keeps its own u = 1
+          float w8[8];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            sc[q] = a.osp_scale ? a.osp_scale[col + q] : 1.f;
-            sh[q] = a.osp_shift ? a.osp_shift[col + q] : 0.f;
+            const float send = h ? v[0][q] : v[1][q];
+            const float recv = __shfl_xor(send, 32);
+            w8[q] = h ? recv : v[0][q];
+            w8[4 + q] = h ? v[1][q] : recv;
           }
-          omax = fmaxf(omax, emit_split4(v, sc, sh, a.osp_has, a.osp_neg,
-                                         a.out_split + (row * (cout >> 5) + (col >> 5)) * 64 + (col & 31)));
+          if (rok) {
+            f16x8 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              float t = w8[q];
+              if (a.osp_has) {   // separate multiply and add, like ph_split_rows and the C restatement
+#pragma clang fp contract(off)
+                const float mm = t * sc[q];
+                t = h_act(mm + sh[q], a.osp_neg);
+              }
+              omax = fmaxf(omax, fabsf(t));
+              const _Float16 th = (_Float16)t;
+              hi[q] = th;
+              lo[q] = (_Float16)(t - (float)th);
+            }
+            const int col8 = cbase + 8 * h;
+            _Float16 *dst = a.out_split + (row * (cout >> 5) + (col8 >> 5)) * 64 + (col8 & 31);
+            *reinterpret_cast<f16x8 *>(dst) = hi;
+            *reinterpret_cast<f16x8 *>(dst + 32) = lo;
+          }
         }
       }
     }
-  if (a.out_split && a.status != nullptr && !(omax <= 65504.f)) atomicOr(a.status, 1);
+  if (EMIT && a.status != nullptr && !(omax <= 65504.f)) atomicOr(a.status, 1);
 }
 
 // fp32 rows -> [hi x32 | lo x32] groups; one thread per 8 channels.  Channels >= c (pad to 32) are zero.
@@ -668,7 +716,10 @@ static int launch_h2(const ConvArgsH &a, hipStream_t st) {
   args.n_col_tiles = (a.cout + BN - 1) / BN;
   const int ntiles = args.n_row_tiles * args.n_col_tiles;
   const int grid = ((ntiles + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_conv_h2<BM, KC, WM, WN, TM, TN>), dim3(grid, args.ksplit), dim3(HV_THREADS), 0, st, args);
+  if (args.out_split != nullptr && args.ksplit == 1)
+    hipLaunchKernelGGL((k_conv_h2<BM, KC, WM, WN, TM, TN, true>), dim3(grid, 1), dim3(HV_THREADS), 0, st, args);
+  else
+    hipLaunchKernelGGL((k_conv_h2<BM, KC, WM, WN, TM, TN, false>), dim3(grid, args.ksplit), dim3(HV_THREADS), 0, st, args);
   PH_LAUNCH_CHECK();
   if (args.ksplit > 1) {
     const int64_t total = a.n_out * a.cout;

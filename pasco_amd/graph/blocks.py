@@ -58,7 +58,7 @@ class ResidualBlock(nn.Module):
     def forward(self, x: ME.SparseTensor, emit_next=None) -> ME.SparseTensor:
         skip = x if len(self.downsample) == 0 else fused.conv(x, self.downsample[0])
         y = fused.conv(x, self.net[2], pro_bn=self.net[0], pro_act=ACT_RELU, epi_bn=self.net[3], epi_act=ACT_RELU,
-                       emit_next=(None, ACT_NONE))
+                       emit_next=(None, ACT_NONE), split_only=True)   # y has one reader: never stored as fp32
         return fused.conv(y, self.net[5], residual=skip.F, res_act=ACT_RELU, emit_next=emit_next)
 
 

@@ -172,6 +172,17 @@ def fold_bn(bn) -> Tuple[torch.Tensor, torch.Tensor]:
     return scale, shift
 
 
+class SplitRows:
+    """Rows that exist only as the pre-split operand of the next convolution (their fp32 values were never
+    written): what `conv(..., split_only=True)` returns inside a block whose intermediate has one reader."""
+
+    def __init__(self, split: torch.Tensor, channels: int, coordinate_map_key, coordinate_manager):
+        self.split = split
+        self.channels = channels
+        self.coordinate_map_key = coordinate_map_key
+        self.coordinate_manager = coordinate_manager
+
+
 def _split_key(F, ps, pb, pro_act, slope):
     return (F.data_ptr(), F._version, None if ps is None else ps.data_ptr(), None if pb is None else pb.data_ptr(),
             pro_act, float(slope) if pro_act == ACT_LEAKY else 0.0)
@@ -179,14 +190,17 @@ def _split_key(F, ps, pb, pro_act, slope):
 
 def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NONE, epi_bn=None,
          epi_act: int = ACT_NONE, epi2_bn=None, residual: Optional[torch.Tensor] = None,
-         res_act: int = ACT_NONE, slope: float = 0.01, out_key=None, nbr=None, emit_next=None) -> SparseTensor:
+         res_act: int = ACT_NONE, slope: float = 0.01, out_key=None, nbr=None, emit_next=None,
+         split_only: bool = False):
     """One fused launch of a Minkowski-style convolution module on `x`.
 
     out = act_res( act_epi(BN_epi(conv(act_pro(BN_pro(x))) + bias)) -> BN_epi2 -> (+ residual) )
 
     `emit_next` = (bn | None, act): the caller knows the next convolution reads act(BN(out)); the launch then also
     writes that convolution's pre-split operand (no separate ph_split_rows pass) and leaves it in the returned
-    tensor's operand cache, where the next `conv` call finds it."""
+    tensor's operand cache, where the next `conv` call finds it.  With `split_only` (the result has exactly that one
+    reader) the fp32 result is not written at all and a `SplitRows` is returned - when the split path does not
+    apply, a normal SparseTensor comes back.  `x` may itself be a `SplitRows`."""
     mgr = x.coordinate_manager
     if out_key is None:
         out_key, nbr = mod._maps(x)
@@ -201,23 +215,35 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     bias = mod.bias.detach().reshape(-1) if mod.bias is not None else None
     be = mgr.backend()
     split = in_split = None
-    if _CONV_PRECISION == "f16x3" and be.split_supported(mod.in_channels, mod.out_channels):
-        split = split_weight(mod, be)
-        if _PRESPLIT and n_out > 0:
-            in_split = split_input(x, be, ps, pb, pro_act, slope)
+    x_rows = None
+    if isinstance(x, SplitRows):
+        assert pro_bn is None and pro_act == ACT_NONE, "a pre-split input already carries its prologue"
+        split, in_split = split_weight(mod, be), x.split
+        xshape = (in_split.shape[0], x.channels)
+    else:
+        x_rows = x.F if x.F.is_contiguous() else x.F.contiguous()
+        xshape = None
+        if _CONV_PRECISION == "f16x3" and be.split_supported(mod.in_channels, mod.out_channels):
+            split = split_weight(mod, be)
+            if _PRESPLIT and n_out > 0:
+                in_split = split_input(x, be, ps, pb, pro_act, slope)
     emit = None
     if emit_next is not None and in_split is not None and mod.out_channels % 32 == 0:
         nbn, nact = emit_next
         ns, nb = fold_bn(nbn) if nbn is not None else (None, None)
         emit = (ns, nb, nact)
+    only = split_only and emit is not None and n_out > 0
     out = be.conv_fwd(
-        x.F if x.F.is_contiguous() else x.F.contiguous(), mod.kernel.detach(), nbr, n_out, bias=bias,
+        x_rows, mod.kernel.detach(), nbr, n_out, xshape=xshape, bias=bias,
         pro_scale=ps, pro_shift=pb, pro_act=pro_act, epi_scale=es, epi_shift=eb, epi_act=epi_act,
         epi2_scale=e2s, epi2_shift=e2b, residual=residual, res_act=res_act, slope=slope, split=split,
-        in_split=in_split, emit_split=emit)
+        in_split=in_split, emit_split=emit, want_out=not only)
     if emit is None:
         return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
     out, out_split = out
+    if only:
+        assert emit[0] is None and emit[1] is None and emit[2] == ACT_NONE, "split_only serves a plain next operand"
+        return SplitRows(out_split, mod.out_channels, out_key, mgr)
     y = SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
     # key it the way the next conv's split_input will look it up (a leaky prologue would use this launch's slope)
     y.__dict__.setdefault("_ph_in_split", {})[_split_key(y.F, emit[0], emit[1], emit[2], slope)] = out_split

@@ -25,7 +25,8 @@ class ConvProfiler:
         prof = self
 
         def conv_fwd(x, weight, nbr, n_out, **kw):
-            if not prof.enabled or x.device.type != "cuda":
+            dev = x.device if x is not None else kw["in_split"].device
+            if not prof.enabled or dev.type != "cuda":
                 return inner(x, weight, nbr, n_out, **kw)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
@@ -36,7 +37,8 @@ class ConvProfiler:
                 kvol, _, cout = kw["wshape"]
             else:
                 kvol, cout = (1 if weight.dim() == 2 else weight.shape[0]), weight.shape[-1]
-            prof.records.append(dict(e0=e0, e1=e1, nbr=nbr, n_in=x.shape[0], n_out=n_out, cin=x.shape[1],
+            n_in, cin = tuple(x.shape) if x is not None else kw["xshape"]
+            prof.records.append(dict(e0=e0, e1=e1, nbr=nbr, n_in=n_in, n_out=n_out, cin=cin,
                                      cout=cout, kvol=kvol,
                                      kernel=("k_conv_mfma" if kw.get("split") is None else
                                              ("k_conv_h2" if len(kw["split"]) == 2 else "k_conv_f16x3"))))

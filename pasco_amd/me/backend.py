@@ -229,8 +229,8 @@ class CBackend:
         return pin, pout, counts
 
     # -- convolution -------------------------------------------------------------------------------
-    def conv_fwd(self, x: torch.Tensor, weight: Optional[torch.Tensor], nbr: Optional[torch.Tensor], n_out: int,
-                 *, wshape=None, bias=None, pro_scale=None, pro_shift=None, pro_act=ACT_NONE, epi_scale=None,
+    def conv_fwd(self, x: Optional[torch.Tensor], weight: Optional[torch.Tensor], nbr: Optional[torch.Tensor],
+                 n_out: int, *, wshape=None, xshape=None, bias=None, pro_scale=None, pro_shift=None, pro_act=ACT_NONE, epi_scale=None,
                  epi_shift=None, epi_act=ACT_NONE, slope=0.01, residual=None, res_act=ACT_NONE,
                  epi2_scale=None, epi2_shift=None, split=None, in_split: Optional[torch.Tensor] = None,
                  emit_split=None, want_out: bool = True,
@@ -238,7 +238,16 @@ class CBackend:
         """... `emit_split` = (scale | None, shift | None, act) (mode 2, cout % 32 == 0): also write the split operand
         of act(out * scale + shift) for the next convolution and return (out, out_split); `want_out=False` then
         skips the fp32 result (returns (None, out_split))."""
-        self._chk(x, torch.float32, "in")
+        if x is None:          # rows that exist only as a pre-split operand (mode 2): `xshape` = (n_in, cin)
+            if xshape is None or in_split is None or split is None or len(split) != 2 or self.device_type != "cuda":
+                raise ValueError("conv: x=None needs xshape, in_split and a mode-2 split on the device backend")
+            if pro_scale is not None or pro_shift is not None or pro_act != ACT_NONE:
+                raise ValueError("conv: a pre-split input already carries its prologue")
+            x = torch.empty((xshape[0], xshape[1]), dtype=torch.float32, device="meta")   # shape carrier only
+            dev = in_split.device
+        else:
+            self._chk(x, torch.float32, "in")
+            dev = x.device
         if weight is None:     # pre-split operands only (mode 2): the fp32 kernel is not read, `wshape` = (kvol, cin, cout)
             if wshape is None or split is None or len(split) != 2 or self.device_type != "cuda":
                 raise ValueError("conv: weight=None needs wshape and a mode-2 split on the device backend")
@@ -259,8 +268,8 @@ class CBackend:
         if emit_split is not None and not emit:
             raise ValueError("conv: emit_split needs a mode-2 split and cout % 32 == 0")
         if out is None and (want_out or not emit):
-            out = torch.empty((n_out, cout), dtype=torch.float32, device=x.device)
-        out_split = torch.empty((n_out, cout // 32, 2, 32), dtype=torch.float16, device=x.device) if emit else None
+            out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+        out_split = torch.empty((n_out, cout // 32, 2, 32), dtype=torch.float16, device=dev) if emit else None
         if n_out == 0:
             return (out, out_split) if emit else out
         d = ConvDesc()
@@ -272,7 +281,7 @@ class CBackend:
                     if t.numel() != cout:
                         raise ValueError(f"conv: {name} has {t.numel()} entries, expected {cout}")
             d.out_split, d.osp_scale, d.osp_shift, d.osp_act = _ptr(out_split), _ptr(osc), _ptr(osh), int(oact)
-        d.in_, d.weight, d.nbr, d.out = _ptr(x), _ptr(weight), _ptr(nbr), _ptr(out)
+        d.in_, d.weight, d.nbr, d.out = (None if x.is_meta else _ptr(x)), _ptr(weight), _ptr(nbr), _ptr(out)
         d.n_in, d.n_out, d.cin, d.cout, d.kvol = x.shape[0], n_out, cin, cout, kvol
         d.pro_act, d.epi_act, d.res_act, d.epi_slope = pro_act, epi_act, res_act, float(slope)
         for name, t, c in (("pro_scale", pro_scale, cin), ("pro_shift", pro_shift, cin),
@@ -303,16 +312,16 @@ class CBackend:
             else:                  # (w_hi, w_lo, unscale) from split_weight_f16: mode 1, activations split in-kernel
                 w_hi, w_lo, unscale = split
                 d.mma_mode, d.w_unscale, d.w_f16_hi, d.w_f16_lo = 1, float(unscale), _ptr(w_hi), _ptr(w_lo)
-            d.status = _ptr(self.status_word(x.device))
+            d.status = _ptr(self.status_word(dev))
             if n_out * cout <= (1 << 23):          # few-row layer: offer scratch for a split over the offsets
                 need = 8 * n_out * cout * 4
-                key = ("splitk", x.device)
+                key = ("splitk", dev)
                 sk = self._ws.get(key)
                 if sk is None or sk.numel() < need:
-                    sk = torch.empty(need, dtype=torch.uint8, device=x.device)
+                    sk = torch.empty(need, dtype=torch.uint8, device=dev)
                     self._ws[key] = sk
                 d.splitk_ws, d.splitk_ws_bytes = _ptr(sk), sk.numel()
-        rc = self.fn["conv_fwd"](C.byref(d), self.stream(x.device))
+        rc = self.fn["conv_fwd"](C.byref(d), self.stream(dev))
         self._check(rc, "conv_fwd")
         return (out, out_split) if emit else out
 
