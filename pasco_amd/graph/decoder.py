@@ -136,9 +136,10 @@ class DecoderGenerativeSepConvV2(nn.Module):
         def keep_mask(i, scale, x):
             logits = sem_logits_at_scales[scale][i]
             keep = keep_override.member(scale, i, x.C) if keep_override is not None else self._occupied(logits)
-            if int(keep.sum()) == 0:  # reference fallback (decoder_v3.py:415-418)
-                keep = torch.zeros_like(keep)
-                keep[:1000] = True
+            # reference fallback (decoder_v3.py:415-418): nothing kept -> keep the first 1000 rows.  Selected on the
+            # device (no host read of the count)
+            first = torch.arange(keep.shape[0], device=keep.device) < 1000
+            keep = torch.where(keep.any(), keep, first)
             return keep & inside_bounds(x.C, min_Cs[i], max_Cs[i])
 
         pad_to = {s: None for s in xs}

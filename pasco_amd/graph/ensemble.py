@@ -39,12 +39,22 @@ def canonical_sites(size: Sequence[int], device) -> torch.Tensor:
     return torch.stack(torch.meshgrid(*ax, indexing="ij"), dim=-1).reshape(-1, 3)
 
 
+_MB_CACHE = {}
+
+
+def _min_bound(device) -> torch.Tensor:
+    key = str(device)
+    if key not in _MB_CACHE:
+        _MB_CACHE[key] = torch.tensor(MIN_BOUND, dtype=torch.float32, device=device)
+    return _MB_CACHE[key]
+
+
 def project_canonical(sites: torch.Tensor, T: torch.Tensor, resolution: float = RESOLUTION) -> torch.Tensor:
     """Voxel index -> voxel centre in metres -> T -> voxel index (round half to even), fp32 like the
     reference's `transform` (transform_utils.py:60-74).  The 4x4 product is written out with a fixed
     operation order so that CPU and GPU give bit-identical coordinates."""
     T = T.to(device=sites.device, dtype=torch.float32)
-    mb = torch.tensor(MIN_BOUND, dtype=torch.float32, device=sites.device)
+    mb = _min_bound(sites.device)
     # float64 until the cast, as in the reference (numpy grid is float64, min_bound float32 -> promoted)
     p = (sites.to(torch.float64) * resolution + resolution / 2 + mb.to(torch.float64)).to(torch.float32)
     x, y, z = p[:, 0], p[:, 1], p[:, 2]
@@ -184,14 +194,15 @@ class Ensembler(torch.nn.Module):
         query_probs.append(anchor_q)
         out = []
         coords4 = torch.cat([torch.zeros((site_coords.shape[0], 1), dtype=torch.int32, device=dev), site_coords], dim=1)
+        union_long = union_sites.long()
         for i, m in enumerate(masks):
-            nz = (m != 0).any(dim=1)                                          # ME.to_sparse keeps non-zero sites
-            c = coords4[nz].contiguous()
+            nz = be.mask_compact((m != 0).any(dim=1).contiguous()).long()     # ME.to_sparse keeps non-zero sites
+            c = coords4.index_select(0, nz)
             mgr = ME.CoordinateManager(D=3, device=dev)
             key = mgr.insert_unique(c, 1)                                     # canonical sites are unique
-            voxel_prob = ME.SparseTensor(m[nz].contiguous(), coordinate_map_key=key, coordinate_manager=mgr)
+            voxel_prob = ME.SparseTensor(m.index_select(0, nz), coordinate_map_key=key, coordinate_manager=mgr)
             if sem_rows is not None:
-                sem_f = sem_rows[i][union_sites.long()[nz]].contiguous()
+                sem_f = sem_rows[i].index_select(0, union_long.index_select(0, nz))
             else:
                 cl = c.long()
                 sem_f = ensemble_sem_prob_denses[i][:, cl[:, 1], cl[:, 2], cl[:, 3]].t().contiguous()

