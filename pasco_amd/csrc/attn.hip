@@ -16,6 +16,8 @@
 // registers directly usable as the B operand of the second product - no LDS, no barrier, no
 // cross-lane traffic for P.  Work is split over N (flash-decoding style): each wave writes a
 // partial (m, l, O) and k_attn_merge combines them.  Mask = 1 bit per (key, query), 16 B per key.
+#include <stdlib.h>
+
 #include "ph_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -32,11 +34,15 @@ struct AttnArgs {
   int B, H, Qn, Dh;
   int splits;            // waves per (b, h)
   int tiles_per_wave;    // 16-key tiles per wave
+  int qp;                // queries per partial record (64 per query block of the launch)
 };
 
+// One wave = one key range x one block of QT query tiles (blockIdx.y).  QT = 4 keeps the wave at ~150 VGPRs
+// (3 waves per SIMD; the 7-tile variant needed 356 and ran one wave per SIMD with nothing to hide latency).
 template <int QT, int DT>
-__global__ void __launch_bounds__(256, 1) k_attn_cross(AttnArgs a) {
+__global__ void __launch_bounds__(256) k_attn_cross(AttnArgs a) {
   constexpr int DH = DT * 16;
+  const int qt0 = (int)blockIdx.y * QT;   // first query tile of this block
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int64_t w = (int64_t)blockIdx.x * 4 + wave_in_block;
@@ -53,7 +59,7 @@ __global__ void __launch_bounds__(256, 1) k_attn_cross(AttnArgs a) {
   unsigned force[QT];  // query attends everywhere (no mask given, or nothing allowed anywhere)
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    const int qq = qt * 16 + qi;
+    const int qq = (qt0 + qt) * 16 + qi;
     const bool qv = qq < a.Qn;
 #pragma unroll
     for (int j = 0; j < DT; ++j) {
@@ -131,7 +137,7 @@ __global__ void __launch_bounds__(256, 1) k_attn_cross(AttnArgs a) {
         s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j][3], qreg[qt][j][3], s, 0, 0, 0);
       }
       // mask: this lane's query is qt*16 + qi; register r is key nb + 4g + r
-      const int qq = qt * 16 + qi;
+      const int qq = (qt0 + qt) * 16 + qi;
       const int wsel = qq >> 5, bsel = qq & 31;
       float sv[4];
       float tmax = -INFINITY;
@@ -171,13 +177,13 @@ __global__ void __launch_bounds__(256, 1) k_attn_cross(AttnArgs a) {
   }
 
   // ---- partial result of this wave: per query m, l (summed over the 4 key groups), O[q][d] -----------
-  float *pw = a.part + w * (int64_t)(QT * 16) * (DH + 4);
+  float *pw = a.part + w * (int64_t)a.qp * (DH + 4);
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     float lt = l[qt];
     lt += __shfl_xor(lt, 16);
     lt += __shfl_xor(lt, 32);
-    const int qq = qt * 16 + qi;
+    const int qq = (qt0 + qt) * 16 + qi;
     float *row = pw + (int64_t)qq * (DH + 4);
     if (g == 0) {
       row[DH] = m[qt];
@@ -193,7 +199,7 @@ __global__ void __launch_bounds__(256, 1) k_attn_cross(AttnArgs a) {
 template <int QT, int DT>
 __global__ void __launch_bounds__(256) k_attn_merge(AttnArgs a) {
   constexpr int DH = DT * 16;
-  constexpr int QP = QT * 16;
+  const int QP = a.qp;
   constexpr int PS = DH + 4;
   __shared__ float Ms[16];
   __shared__ float Ls[16];
@@ -329,9 +335,9 @@ extern "C" int ph_bits_or_reduce(const uint32_t *bits, int64_t n, int32_t b, uin
 }
 
 extern "C" int64_t ph_attn_workspace_bytes(int64_t n, int32_t b, int32_t h, int32_t qn, int32_t dh) {
-  // at most 2048 + b*h partial records, each as large as the kernel instantiation writes (7 or 8 query tiles,
-  // whatever qn is - sizing it by qn under-allocated for qn < 97)
-  const int64_t qp = qn <= 112 ? 112 : 128;
+  // at most 2048 + b*h partial records, each as large as the launch writes: 64 queries per query block
+  // (1 or 2 blocks), whatever qn is
+  const int64_t qp = qn <= 64 ? 64 : 128;
   return (int64_t)(2048 + (int64_t)b * h * 4) * qp * (dh + 4) * 4 + 256;
 }
 
@@ -361,15 +367,10 @@ extern "C" int ph_attn_cross_fwd(const float *q, const float *k, const float *v,
   hipStream_t st = ph_stream(stream);
   const int64_t waves = (int64_t)bh * splits;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-  if (qn <= 112) {
-    hipLaunchKernelGGL((k_attn_cross<7, 3>), dim3(grid), dim3(256), 0, st, a);
-    PH_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_attn_merge<7, 3>), dim3(bh, 7), dim3(256), 0, st, a);
-  } else {
-    hipLaunchKernelGGL((k_attn_cross<8, 3>), dim3(grid), dim3(256), 0, st, a);
-    PH_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_attn_merge<8, 3>), dim3(bh, 8), dim3(256), 0, st, a);
-  }
+  a.qp = qn <= 64 ? 64 : 128;   // 2-tile query blocks were measured slower (K / V re-read by four waves)
+  hipLaunchKernelGGL((k_attn_cross<4, 3>), dim3(grid, a.qp / 64), dim3(256), 0, st, a);
+  PH_LAUNCH_CHECK();
+  hipLaunchKernelGGL((k_attn_merge<4, 3>), dim3(bh, (qn + 15) / 16), dim3(256), 0, st, a);
   PH_LAUNCH_CHECK();
   return 0;
 }
