@@ -69,10 +69,9 @@ def project_canonical(sites: torch.Tensor, T: torch.Tensor, resolution: float = 
     return torch.round(q).to(torch.int32)
 
 
-def _lookup_rows(st: ME.SparseTensor, coords3: torch.Tensor) -> torch.Tensor:
-    """row of each (0, x, y, z) coordinate in st's coordinate map, or -1."""
-    q = torch.cat([torch.zeros((coords3.shape[0], 1), dtype=torch.int32, device=coords3.device), coords3], dim=1)
-    return st.coordinate_manager.find(st.coordinate_map_key, q.contiguous())
+def _lookup_rows(st: ME.SparseTensor, coords4: torch.Tensor) -> torch.Tensor:
+    """row of each (0, x, y, z) coordinate (int32 [N, 4], batch column 0) in st's coordinate map, or -1."""
+    return st.coordinate_manager.find(st.coordinate_map_key, coords4)
 
 
 def _gram(a: torch.Tensor, b: torch.Tensor, chunks: int = 256) -> torch.Tensor:
@@ -97,10 +96,12 @@ class Ensembler(torch.nn.Module):
         self._sites = {}
 
     def projected(self, T: torch.Tensor, device, cache: dict) -> torch.Tensor:
-        """canonical sites seen through T (shared by the semantic and the mask resampling of a scene)."""
+        """canonical sites seen through T as (0, x, y, z) rows (shared by the semantic and the mask resampling
+        of a scene)."""
         key = id(T)
         if key not in cache:
-            cache[key] = project_canonical(self.sites(device), T)
+            p = project_canonical(self.sites(device), T)
+            cache[key] = torch.cat([torch.zeros((p.shape[0], 1), dtype=torch.int32, device=p.device), p], dim=1).contiguous()
         return cache[key]
 
     def sites(self, device) -> torch.Tensor:
@@ -123,8 +124,9 @@ class Ensembler(torch.nn.Module):
             probs = F.softmax(st.F, dim=-1)
             rows = _lookup_rows(st, self.projected(Ts[i], dev, cache))
             dense_rows = backend_for(dev).gather_rows(probs.contiguous(), rows)          # [XYZ, C], -1 -> 0
-            empty = dense_rows.sum(dim=1) == 0
-            dense_rows[:, 0] = torch.where(empty, torch.ones_like(dense_rows[:, 0]), dense_rows[:, 0])
+            # the reference tests `probs.sum(channels) == 0` on the resampled grid; a covered site holds a softmax
+            # row (sum 1), so that is exactly "no source voxel"
+            dense_rows[:, 0] = torch.where(rows < 0, torch.ones_like(dense_rows[:, 0]), dense_rows[:, 0])
             outs.append(dense_rows)
         outs.append(torch.stack(outs, dim=0).mean(0))
         if cache is not None:

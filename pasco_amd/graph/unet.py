@@ -34,6 +34,28 @@ def compute_scene_size(min_coords, max_coords, scale=1):
     return (torch.ceil((max_coords - min_coords + 1) / scale) * scale).int()
 
 
+def unique_rows_sorted(rows: torch.Tensor):
+    """`torch.unique(rows, return_inverse=True, dim=0)` for integer coordinate rows [N, 3] (x,y,z) or [N, 4]
+    (b,x,y,z): same sorted unique rows and inverse, via ONE 64-bit key per row (the coordinate-map packing:
+    10 bits batch, 18 bits per axis biased by 2^17 - order preserving) and a 1-D sort instead of a row-wise
+    lexicographic sort."""
+    r = rows.to(torch.int64)
+    if r.shape[1] == 3:
+        b, xyz = None, r
+    else:
+        b, xyz = r[:, 0], r[:, 1:]
+    bias = 1 << 17
+    key = ((xyz[:, 0] + bias) << 36) | ((xyz[:, 1] + bias) << 18) | (xyz[:, 2] + bias)
+    if b is not None:
+        key = key | (b << 54)
+    uk, inv = torch.unique(key, return_inverse=True)
+    mask = (1 << 18) - 1
+    cols = [((uk >> 36) & mask) - bias, ((uk >> 18) & mask) - bias, (uk & mask) - bias]
+    if b is not None:
+        cols = [uk >> 54] + cols
+    return torch.stack(cols, dim=1).to(rows.dtype), inv
+
+
 class CylinderFeat(nn.Module):
     """Per-point MLP + max over the points of a voxel (reference unet3d_sparse_v2.py:15-86).
 
@@ -61,7 +83,7 @@ class CylinderFeat(nn.Module):
     def forward(self, pt_fea: List[torch.Tensor], xy_ind: List[torch.Tensor]):
         ind = torch.cat([F.pad(c, (1, 0), value=i) for i, c in enumerate(xy_ind)], dim=0)
         fea = torch.cat(pt_fea, dim=0)
-        unq, inv = torch.unique(ind, return_inverse=True, dim=0)
+        unq, inv = unique_rows_sorted(ind)
         h = self._mlp(fea)
         pooled = torch.full((unq.shape[0], h.shape[1]), float("-inf"), dtype=h.dtype, device=h.device)
         pooled.scatter_reduce_(0, inv[:, None].expand_as(h), h, reduce="amax", include_self=True)
@@ -77,7 +99,7 @@ def merge_subnet_inputs(in_feat: ME.SparseTensor, n_infers: int) -> ME.SparseTen
     Fi = in_feat.F
     c = Fi.shape[1]
     xyz = C[:, 1:]
-    uniq, inv = torch.unique(xyz, return_inverse=True, dim=0)      # sorted rows = lexicographic order
+    uniq, inv = unique_rows_sorted(xyz)                            # sorted rows = lexicographic order
     out = Fi.new_zeros((uniq.shape[0], n_infers * c))
     col = C[:, 0].to(torch.int64) * c
     idx = (inv[:, None] * (n_infers * c) + col[:, None] + torch.arange(c, device=Fi.device)[None, :])
@@ -193,7 +215,9 @@ class PascoNet(nn.Module):
         sem_prob_denses = self.ensembler.ensemble_sem_compl(ret["sem_logits_at_scales"], Ts, cache=cache)
         panop = self.ensembler.ensemble_panop(ret["panop_predictions"], sem_prob_denses, Ts,
                                               iou_threshold=self.iou_threshold, cache=cache)
-        ssc_confidences = [p.max(dim=0)[0] for p in sem_prob_denses]
+        # max over classes on the channels-last rows the dense views are made of (contiguous reduction)
+        X, Y, Z = self.ensembler.scene_size
+        ssc_confidences = [r.max(dim=1)[0].reshape(X, Y, Z) for r in cache["sem_rows"]]
         return ssc_confidences, sem_prob_denses, panop
 
     def step_inference(self, in_feats, in_coords, Ts, global_min_coords, global_max_coords, min_Cs, max_Cs,

@@ -239,3 +239,11 @@ def test_sine_pe_matches_oracle_and_torch(hip, oracle):
     assert torch.allclose(got.cpu(), exp, atol=2e-6, rtol=0)
     ref = sine_position_encoding(c4.cuda()[:, 1:], 128)
     assert torch.allclose(got, ref, atol=2e-6, rtol=0)
+
+
+def test_gram_batched_matches_matmul():
+    from pasco_amd.graph.ensemble import _gram
+    g = torch.Generator().manual_seed(91)
+    a, b = torch.rand(100003, 100, generator=g).cuda(), torch.rand(100003, 100, generator=g).cuda()
+    ref = (a.double().t() @ b.double()).float()
+    assert torch.allclose(_gram(a, b), ref, rtol=1e-5, atol=1e-3)
