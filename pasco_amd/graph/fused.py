@@ -69,24 +69,31 @@ def split_rows_2d(x2d: torch.Tensor):
     return backend_for(x2d.device).split_rows(x2d.contiguous())
 
 
-def linear_rows(x2d: torch.Tensor, weight: torch.Tensor, bias, cache_owner, cache_key: str,
-                min_rows: int = 16384, in_split=None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_owner, cache_key: str,
+                min_rows: int = 16384, in_split=None, residual: Optional[torch.Tensor] = None,
+                emit: bool = False, want_out: bool = True):
     """y = x @ weight.T + bias for a tall [N, cin] operand (`weight` is an nn.Linear-style [cout, cin] tensor
     or a row slice of one).  Large N on the GPU goes through the convolution kernel as an identity-map k=1
     convolution - the same split-precision MFMA GEMM with fused bias - instead of an fp32 library GEMM;
     everything else (small N, CPU checker backend, odd shapes) is torch.nn.functional.linear.
-    `residual` [N, cout] (optional) is added in the same launch (y + residual)."""
-    n, cin = x2d.shape
-    cout = weight.shape[0]
+    `residual` [N, cout] (optional) is added in the same launch (y + residual).
+    `x2d` may be None when `in_split` (its pre-split operand) is given.
+    `emit`: also return the pre-split operand of y for a following linear_rows / batched_rows_matmul -> (y, y_split);
+    y_split is None when the split path did not apply, and with `want_out=False` y is None when it did."""
+    cout, cin = weight.shape
+    n = x2d.shape[0] if x2d is not None else in_split.shape[0]
+    dev = x2d.device if x2d is not None else in_split.device
     be = None
-    if x2d.is_cuda and n >= min_rows and _CONV_PRECISION == "f16x3":
+    if dev.type == "cuda" and n >= min_rows and _CONV_PRECISION == "f16x3":
         from ..me.backend import backend_for
-        be = backend_for(x2d.device)
+        be = backend_for(dev)
         if not be.split_supported(cin, cout):
             be = None
     if be is None:
+        assert x2d is not None, "linear_rows: a pre-split operand needs the split path"
         y = torch.nn.functional.linear(x2d, weight, bias)
-        return y if residual is None else y + residual
+        y = y if residual is None else y + residual
+        return (y, None) if emit else y
     ver = (weight._version, weight.device, weight.data_ptr(), _PRESPLIT)
     hit = cache_owner.__dict__.get("_ph_lin_" + cache_key)
     if hit is None or hit[0] != ver:
@@ -94,8 +101,15 @@ def linear_rows(x2d: torch.Tensor, weight: torch.Tensor, bias, cache_owner, cach
         hit = (ver, wt, _split_of(wt, be), bias.detach().contiguous() if bias is not None else None)
         cache_owner.__dict__["_ph_lin_" + cache_key] = hit
     _, wt, split, b = hit
-    return be.conv_fwd(x2d.contiguous(), wt, None, n, bias=b, split=split, in_split=in_split if _PRESPLIT else None,
-                       residual=None if residual is None else residual.contiguous())
+    do_emit = emit and _PRESPLIT and cout % 32 == 0
+    out = be.conv_fwd(None if (x2d is None) else x2d.contiguous(), wt, None, n,
+                      xshape=(n, cin) if x2d is None else None, bias=b, split=split,
+                      in_split=in_split if _PRESPLIT else None,
+                      residual=None if residual is None else residual.contiguous(),
+                      emit_split=(None, None, ACT_NONE) if do_emit else None, want_out=want_out or not do_emit)
+    if not emit:
+        return out
+    return out if do_emit else (out, None)
 
 
 def linear_bn_act(x2d: torch.Tensor, lin: nn.Linear, *, pro_bn=None, epi_bn=None, epi_act: int = ACT_NONE,
@@ -131,24 +145,25 @@ def linear_bn_act(x2d: torch.Tensor, lin: nn.Linear, *, pro_bn=None, epi_bn=None
                        epi_act=epi_act, split=split)
 
 
-def batched_rows_matmul(x: torch.Tensor, w: torch.Tensor, x_split: torch.Tensor) -> torch.Tensor:
+def batched_rows_matmul(x: Optional[torch.Tensor], w: torch.Tensor, x_split: torch.Tensor, shape=None) -> torch.Tensor:
     """out[b] = x[b] @ w[b].T for tall x [B, P, D] and per-batch w [B, Q, D] that change every call (the mask
     logits of the query heads), on the split-precision kernel with `x_split` = split_rows(x) prepared once.
     The power-of-two weight scale is chosen on the device (no host read) and undone by the epilogue scale."""
     from ..me.backend import backend_for
-    be = backend_for(x.device)
-    B, P, D = x.shape
+    dev = x_split.device
+    be = backend_for(dev)
+    B, P, D = x.shape if x is not None else shape     # x itself is not read (only its operand split)
     Q = w.shape[1]
     w = w.detach()
     e = 13 - torch.frexp(w.abs().amax())[1]                        # device int: largest magnitude just below 2^14
     w_split = be.split_rows(torch.ldexp(w, e).reshape(B * Q, D).contiguous())
-    unscale = torch.ldexp(torch.ones(Q, device=x.device), -e).contiguous()
-    out = torch.empty((B, P, Q), dtype=torch.float32, device=x.device)
+    unscale = torch.ldexp(torch.ones(Q, device=dev), -e).contiguous()
+    out = torch.empty((B, P, Q), dtype=torch.float32, device=dev)
     xs = x_split.reshape(B, P, -1)
     ws = w_split.reshape(B, Q, -1)
     for b in range(B):
-        be.conv_fwd(x[b], None, None, P, wshape=(1, D, Q), split=(ws[b], 1.0), in_split=xs[b], epi_scale=unscale,
-                    out=out[b])
+        be.conv_fwd(None, None, None, P, xshape=(P, D), wshape=(1, D, Q), split=(ws[b], 1.0), in_split=xs[b],
+                    epi_scale=unscale, out=out[b])
     return out
 
 

@@ -96,21 +96,29 @@ class CrossAttentionLayer(nn.Module):
         self.nhead = nhead
         _xavier(self)
 
-    def forward(self, q_embed, feats, attn_mask=None, pos=None, query_pos=None, mask_bits=None):
+    def forward(self, q_embed, feats, attn_mask=None, pos=None, query_pos=None, mask_bits=None, feats_split=None,
+                feats_shape=None):
         """q_embed [B,Q,D]; feats [B,N,D] (pass pos=None when the positional term is already added).  Mask
         either as `attn_mask` bool [B,Q,N] (True = masked, shared by the heads; torch path) or as `mask_bits`
         = (bits [B,N,4], any [B,4]) for the fused HIP kernel (ph_attn_cross_fwd), which also applies the
         all-masked -> unmasked rule."""
         q = self.norm(q_embed)
-        kv = feats if pos is None else feats + pos
         mha = self.multihead_attn
         B, Q, D = q.shape
         H = self.nhead
         w, b = mha.in_proj_weight, mha.in_proj_bias
         qq = F.linear(q if query_pos is None else q + query_pos, w[:D], b[:D])
-        N = kv.shape[1]
-        kv2 = kv.reshape(B * N, D)
-        kv_split = split_rows_2d(kv2) if kv2.shape[0] >= 16384 else None     # one operand split for K and V
+        if feats is None:      # the keys / values exist only as the pre-split operand of their projections
+            assert pos is None and feats_split is not None and mask_bits is not None
+            N = feats_shape[1]
+            kv2, kv_split = None, feats_split
+        else:
+            kv = feats if pos is None else feats + pos
+            N = kv.shape[1]
+            kv2 = kv.reshape(B * N, D)
+            kv_split = feats_split
+            if kv_split is None and kv2.shape[0] >= 16384:
+                kv_split = split_rows_2d(kv2)                                     # one operand split for K and V
         kk = linear_rows(kv2, w[D:2 * D], b[D:2 * D], self, "k", in_split=kv_split).view(B, N, D)
         vv = linear_rows(kv2, w[2 * D:], b[2 * D:], self, "v", in_split=kv_split).view(B, N, D)
         qq = qq.view(B, Q, H, D // H).transpose(1, 2)
@@ -188,12 +196,12 @@ class TransformerPredictorV2(nn.Module):
         self.mask_feat_proj = nn.Linear(mask_dim, hidden_dim)
 
     # -- heads --------------------------------------------------------------------------------------
-    def pred_heads(self, output, mask_features, mask_features_split=None):
+    def pred_heads(self, output, mask_features, mask_features_split=None, shape=None):
         d = self.decoder_norm(output)
         outputs_class = self.class_embed(d)
         mask_embed = self.mask_embed(d)                                   # [B,Q,D]
-        if mask_features_split is not None and mask_embed.shape[1] % 4 == 0:
-            outputs_mask = batched_rows_matmul(mask_features, mask_embed, mask_features_split)
+        if mask_features_split is not None:
+            outputs_mask = batched_rows_matmul(mask_features, mask_embed, mask_features_split, shape=shape)
         else:
             outputs_mask = torch.matmul(mask_features, mask_embed.transpose(1, 2))   # [B,P,Q]
         return outputs_class, outputs_mask
@@ -279,27 +287,42 @@ class TransformerPredictorV2(nn.Module):
             pos.append(self.pe_layer(c.reshape(-1, 4), coff=1).reshape(B, -1, D))
         voxel_coord = xs[1][1]
         x1 = xs[1][0]
-        voxel_feat = linear_rows(x1.reshape(-1, x1.shape[-1]), self.mask_feat_proj.weight, self.mask_feat_proj.bias,
-                                 self.mask_feat_proj, "w", residual=pos[-1].reshape(-1, D)).view(B, -1, D)
+        # voxel features of the mask heads: read only as the operand of `voxel_feat @ mask_embed^T`, so with the
+        # split kernel the projection writes that operand directly (no fp32 copy, no separate split pass)
+        P = x1.shape[1]
+        heads_split = self.num_queries % 4 == 0
+        voxel_feat, vf_split = linear_rows(x1.reshape(-1, x1.shape[-1]), self.mask_feat_proj.weight,
+                                           self.mask_feat_proj.bias, self.mask_feat_proj, "w",
+                                           residual=pos[-1].reshape(-1, D), emit=True, want_out=not heads_split)
+        if not heads_split:
+            vf_split = None
+        if voxel_feat is not None:
+            voxel_feat = voxel_feat.view(B, -1, D)
+        vf_shape = (B, P, D)
         predictions_class, predictions_mask = [], []
         mask_cache = {}
-        vf_split = split_rows_2d(voxel_feat.reshape(-1, D)) if voxel_feat.shape[0] * voxel_feat.shape[1] >= 16384 else None
-        oc, om = self.pred_heads(output, voxel_feat, vf_split)
+        oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape)
         predictions_class.append(oc)
         predictions_mask.append(om)
         for i in range(self.num_layers):
             lin = self.input_projs[i]
             # input projection with the positional term added in the same launch: the layer only ever uses
             # src + pos (transformer/blocks.py:83-86, key = value = bb_feat + pos)
-            src_F = linear_rows(srcs[i].reshape(-1, srcs[i].shape[-1]), lin.weight, lin.bias, lin, "w",
-                                residual=pos[i].reshape(-1, D)).view(B, -1, D)
+            N_i, Qn = srcs[i].shape[1], om.shape[2]
+            be = backend_for(srcs[i].device)
+            fused_attn = be.attn_supported(Qn, D // self.nheads)
+            # with the fused attention kernel src + pos is read only by the K / V projections: emit it as their
+            # operand (no fp32 copy)
+            src_F, src_split = linear_rows(srcs[i].reshape(-1, srcs[i].shape[-1]), lin.weight, lin.bias, lin, "w",
+                                           residual=pos[i].reshape(-1, D), emit=True, want_out=not fused_attn)
+            if src_F is not None:
+                src_F = src_F.view(B, -1, D)
             bits, any_ = self.compute_mask_bits(om, voxel_coord, src_Cs[i], self.src_scales[i], min_Cs, max_Cs,
                                                 cache=mask_cache)
-            N_i, Qn = src_F.shape[1], om.shape[2]
-            be = backend_for(src_F.device)
-            if be.attn_supported(Qn, D // self.nheads):
+            if fused_attn:
                 output = self.transformer_cross_attention_layers[i](output, src_F, pos=None, query_pos=query_embed,
-                                                                    mask_bits=(bits, any_))
+                                                                    mask_bits=(bits, any_), feats_split=src_split,
+                                                                    feats_shape=(B, N_i, D))
             else:   # shapes outside the fused kernel: torch attention with the materialised bool mask
                 q_idx = torch.arange(Qn, device=bits.device)
                 allow = (bits[:, :, (q_idx >> 5).long()] >> (q_idx & 31).to(torch.int32)) & 1      # [B,N,Q]
@@ -309,7 +332,7 @@ class TransformerPredictorV2(nn.Module):
                                                                     pos=None, query_pos=query_embed)
             output = self.transformer_self_attention_layers[i](output, query_pos=query_embed)
             output = self.transformer_ffn_layers[i](output)
-            oc, om = self.pred_heads(output, voxel_feat, vf_split)
+            oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape)
             predictions_class.append(oc)
             predictions_mask.append(om)
         panop_predictions = []
