@@ -189,9 +189,12 @@ int PH_FN(maxpool_fwd)(const float *in, int32_t c, const int32_t *nbr, int32_t k
  *   c = float(coord); c = c / (c + 1e-6f) * scale;  ang_i = c / dim_t[i]  (dim_t [f], given by the caller)
  *   out[row, a*f + p]       = sin(ang_{2p})      p < f/2
  *   out[row, a*f + f/2 + p] = cos(ang_{2p+1})
- * f even. */
+ * f even.  `table` (optional, [tab_n, f] fp32 = this same function evaluated on the coordinate values
+ * tab_lo .. tab_lo + tab_n - 1, one axis) turns the evaluation into a lookup for coordinates inside the table
+ * range (the encoding of an axis depends on that axis' integer value only); values outside are computed. */
 int PH_FN(sine_pe)(const int32_t *coords, int64_t n, int32_t cstride, int32_t coff, int32_t f,
-                   const float *dim_t, float scale, float *out, ph_stream_t stream);
+                   const float *dim_t, float scale, const float *table, int32_t tab_lo, int32_t tab_n,
+                   float *out, ph_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pruning / row movement (ME.MinkowskiPruning decoder_v3.py:159,421,427,432,496-497,

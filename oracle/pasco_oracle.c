@@ -565,7 +565,7 @@ int pho_bits_or_reduce(const uint32_t *bits, int64_t n, int32_t b, uint32_t *any
 /* sine position encoding (include/pasco_hip.h ph_sine_pe; reference: PositionEmbeddingSineSparse with
  * normalize=True as used by transformer_predictor_v2.py:93-95) */
 int pho_sine_pe(const int32_t *coords, int64_t n, int32_t cstride, int32_t coff, int32_t f, const float *dim_t,
-                float scale, float *out, ph_stream_t stream) {
+                float scale, const float *table, int32_t tab_lo, int32_t tab_n, float *out, ph_stream_t stream) {
   (void)stream;
   if (n < 0 || f <= 0 || f % 2 != 0 || cstride < 3 || coff < 0 || coff + 3 > cstride) return fail("sine_pe: bad shape");
   if (n == 0) return 0;
@@ -574,9 +574,14 @@ int pho_sine_pe(const int32_t *coords, int64_t n, int32_t cstride, int32_t coff,
 #pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < n; ++r) {
     for (int a = 0; a < 3; ++a) {
-      float c = (float)coords[r * cstride + coff + a];
-      c = c / (c + 1e-6f) * scale;
+      const int ci = coords[r * cstride + coff + a];
       float *o = out + r * 3 * f + a * f;
+      if (table && ci >= tab_lo && ci - tab_lo < tab_n) {   /* lookup: same values by construction */
+        memcpy(o, table + (int64_t)(ci - tab_lo) * f, sizeof(float) * (size_t)f);
+        continue;
+      }
+      float c = (float)ci;
+      c = c / (c + 1e-6f) * scale;
       for (int p = 0; p < half; ++p) {
         o[p] = sinf(c / dim_t[2 * p]);
         o[half + p] = cosf(c / dim_t[2 * p + 1]);

@@ -218,7 +218,9 @@ extern "C" int ph_dense_gather(const float *dense, int32_t c, const int32_t *h_d
 // ---- sine position encoding -----------------------------------------------------------------------
 // one thread per output element; consecutive threads write consecutive columns of a row
 __global__ void __launch_bounds__(256) k_sine_pe(const int32_t *__restrict__ coords, int64_t n, int cstride, int coff, int f,
-                                                  const float *__restrict__ dim_t, float scale, float *__restrict__ out) {
+                                                  const float *__restrict__ dim_t, float scale,
+                                                  const float *__restrict__ table, int tab_lo, int tab_n,
+                                                  float *__restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int w = 3 * f;
   if (t >= n * w) return;
@@ -227,21 +229,29 @@ __global__ void __launch_bounds__(256) k_sine_pe(const int32_t *__restrict__ coo
   const int axis = col / f;
   const int j = col - axis * f;
   const int half = f >> 1;
-  float c = (float)coords[row * cstride + coff + axis];
-  c = c / (c + 1e-6f) * scale;
+  const int ci = coords[row * cstride + coff + axis];
+  const unsigned ti = (unsigned)(ci - tab_lo);
   float v;
-  if (j < half) v = sinf(c / dim_t[2 * j]);
-  else v = cosf(c / dim_t[2 * (j - half) + 1]);
+  if (table != nullptr && ti < (unsigned)tab_n) {
+    v = table[(int64_t)ti * f + j];
+  } else {
+    float c = (float)ci;
+    c = c / (c + 1e-6f) * scale;
+    if (j < half) v = sinf(c / dim_t[2 * j]);
+    else v = cosf(c / dim_t[2 * (j - half) + 1]);
+  }
   out[t] = v;
 }
 
 extern "C" int ph_sine_pe(const int32_t *coords, int64_t n, int32_t cstride, int32_t coff, int32_t f,
-                          const float *dim_t, float scale, float *out, ph_stream_t stream) {
+                          const float *dim_t, float scale, const float *table, int32_t tab_lo, int32_t tab_n,
+                          float *out, ph_stream_t stream) {
   PH_REQUIRE(n >= 0 && f > 0 && f % 2 == 0 && cstride >= 3 && coff >= 0 && coff + 3 <= cstride, "sine_pe: bad shape");
+  PH_REQUIRE(table == nullptr || tab_n > 0, "sine_pe: empty table");
   if (n == 0) return 0;
   PH_REQUIRE(coords && dim_t && out, "sine_pe: null buffer");
   hipLaunchKernelGGL(k_sine_pe, dim3(nblk(n * 3 * f, 256)), dim3(256), 0, ph_stream(stream), coords, n, cstride, coff, f,
-                     dim_t, scale, out);
+                     dim_t, scale, table, tab_lo, tab_n, out);
   PH_LAUNCH_CHECK();
   return 0;
 }

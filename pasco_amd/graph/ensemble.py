@@ -164,10 +164,11 @@ class Ensembler(torch.nn.Module):
             occupied = (rows >= 0) if occupied is None else (occupied | (rows >= 0))
             query_probs.append(F.softmax(panop_predictions[i]["query_logits"], dim=-1))
         union_sites = be.mask_compact(occupied.contiguous())                # canonical site ids, lexicographic
-        site_coords = sites[union_sites.long()]                             # [U, 3]
+        union_long = union_sites.long()
+        site_coords = sites.index_select(0, union_long)                     # [U, 3]
         masks = []                                                          # per subnet [U, Q] (0 where absent)
         for i in range(n_sub):
-            r = rows_per_subnet[i][union_sites.long()].contiguous()
+            r = rows_per_subnet[i].index_select(0, union_long)
             masks.append(be.gather_rows(probs_per_subnet[i].contiguous(), r))
         anchor_q = query_probs[0].clone()
         anchor_m = masks[0].clone()
@@ -188,15 +189,14 @@ class Ensembler(torch.nn.Module):
                 r.data_ptr() != d.data_ptr() for r, d in zip(sem_rows, ensemble_sem_prob_denses))):
             sem_rows = None                      # denses did not come from this cache's ensemble_sem_compl
         if sem_rows is not None:                 # rows of the same tensors, channels last: contiguous reads
-            ens_class = sem_rows[-1][union_sites.long()].argmax(dim=1)
+            ens_class = sem_rows[-1].index_select(0, union_long).argmax(dim=1)
         else:
-            ens_class = ensemble_sem_prob_denses[-1].argmax(0).reshape(-1)[union_sites.long()]
+            ens_class = ensemble_sem_prob_denses[-1].argmax(0).reshape(-1)[union_long]
         anchor_m = anchor_m * (ens_class != 0).float()[:, None]
         masks.append(anchor_m)
         query_probs.append(anchor_q)
         out = []
         coords4 = torch.cat([torch.zeros((site_coords.shape[0], 1), dtype=torch.int32, device=dev), site_coords], dim=1)
-        union_long = union_sites.long()
         for i, m in enumerate(masks):
             nz = be.mask_compact((m != 0).any(dim=1).contiguous()).long()     # ME.to_sparse keeps non-zero sites
             c = coords4.index_select(0, nz)

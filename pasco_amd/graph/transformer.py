@@ -41,6 +41,8 @@ def sine_position_encoding(coords: torch.Tensor, num_pos_feats: int, temperature
 
 
 class PositionEmbeddingSineSparse(nn.Module):
+    TABLE_LO, TABLE_HI = -1024, 4096     # coordinate values served by lookup (others are evaluated)
+
     def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
         super().__init__()
         assert normalize, "the served configuration uses normalize=True"
@@ -60,7 +62,13 @@ class PositionEmbeddingSineSparse(nn.Module):
         """coords [N, >=3] integer rows with x,y,z from column `coff`.  On a device with a backend: one kernel
         (ph_sine_pe); otherwise the torch formula."""
         if coords.dtype == torch.int32 and coords.is_contiguous() and (coords.is_cuda or _has_checker()):
-            return backend_for(coords.device).sine_pe(coords, self.dim_t(coords.device), self.scale, coff)
+            be = backend_for(coords.device)
+            dim_t = self.dim_t(coords.device)
+            tab = self.__dict__.get("_table")
+            if tab is None or tab.device != coords.device:      # one axis, values -1024 .. 4095: 2.6 MB, built once
+                tab = be.sine_pe_table(dim_t, self.scale, self.TABLE_LO, self.TABLE_HI)
+                self.__dict__["_table"] = tab
+            return be.sine_pe(coords, dim_t, self.scale, coff, table=tab, tab_lo=self.TABLE_LO)
         return sine_position_encoding(coords[:, coff:coff + 3], self.num_pos_feats, self.temperature, self.scale)
 
 

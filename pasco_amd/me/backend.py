@@ -64,7 +64,7 @@ _SIGNATURES = {
     "to_dense": [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp, _vp],
     "to_sparse_coords": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "dense_gather": [_vp, _i32, _vp, _vp, _i64, _vp, _vp],
-    "sine_pe": [_vp, _i64, _i32, _i32, _i32, _vp, C.c_float, _vp, _vp],
+    "sine_pe": [_vp, _i64, _i32, _i32, _i32, _vp, C.c_float, _vp, _i32, _i32, _vp, _vp],
     "attn_workspace_bytes": [_i64, _i32, _i32, _i32, _i32],
     "attn_mask_pack": [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
     "bits_orpool": [_vp, _vp, _i32, _i64, _vp, _vp],
@@ -528,17 +528,32 @@ class CBackend:
         self._check(rc, "bits_or_reduce")
         return out
 
-    def sine_pe(self, coords: torch.Tensor, dim_t: torch.Tensor, scale: float, coff: int = 0) -> torch.Tensor:
-        """coords int32 [N, cstride] (x,y,z from column `coff`) -> [N, 3*f] sine position encoding."""
+    def sine_pe(self, coords: torch.Tensor, dim_t: torch.Tensor, scale: float, coff: int = 0,
+                table: Optional[torch.Tensor] = None, tab_lo: int = 0) -> torch.Tensor:
+        """coords int32 [N, cstride] (x,y,z from column `coff`) -> [N, 3*f] sine position encoding.
+        `table` [T, f] = `sine_pe_table(...)`: lookup for coordinate values tab_lo .. tab_lo + T - 1."""
         self._chk(coords, torch.int32, "coords")
         self._chk(dim_t, torch.float32, "dim_t")
         n, cstride = coords.shape
         f = dim_t.numel()
+        tab_n = 0
+        if table is not None:
+            self._chk(table, torch.float32, "table")
+            if table.dim() != 2 or table.shape[1] != f:
+                raise ValueError("sine_pe: table must be [T, f]")
+            tab_n = table.shape[0]
         out = torch.empty((n, 3 * f), dtype=torch.float32, device=coords.device)
-        rc = self.fn["sine_pe"](_ptr(coords), n, cstride, coff, f, _ptr(dim_t), float(scale), _ptr(out),
-                                self.stream(coords.device))
+        rc = self.fn["sine_pe"](_ptr(coords), n, cstride, coff, f, _ptr(dim_t), float(scale), _ptr(table), int(tab_lo),
+                                tab_n, _ptr(out), self.stream(coords.device))
         self._check(rc, "sine_pe")
         return out
+
+    def sine_pe_table(self, dim_t: torch.Tensor, scale: float, lo: int, hi: int) -> torch.Tensor:
+        """[hi - lo, f] encodings of one axis for the integer values lo .. hi - 1 (evaluated by the same entry
+        point, so a lookup returns exactly what the evaluation would)."""
+        v = torch.arange(lo, hi, dtype=torch.int32, device=dim_t.device)
+        c = torch.stack([v, v, v], dim=1).contiguous()
+        return self.sine_pe(c, dim_t, scale)[:, : dim_t.numel()].contiguous()
 
     def attn_supported(self, qn: int, dh: int) -> bool:
         return qn <= 128 and (dh == 48 or self.device_type == "cpu")

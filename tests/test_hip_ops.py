@@ -232,6 +232,8 @@ def test_sine_pe_matches_oracle_and_torch(hip, oracle):
     g = torch.Generator().manual_seed(90)
     c4 = torch.randint(-40, 300, (7001, 4), generator=g, dtype=torch.int32)
     c4[:50, 1:] = 0
+    c4[50:60, 1] = 5000          # outside the lookup table of the module: evaluated in the kernel
+    c4[60:70, 3] = -2000
     pe = PositionEmbeddingSineSparse(128, normalize=True)
     exp = oracle.sine_pe(c4, pe.dim_t(torch.device("cpu")), pe.scale, coff=1)
     got = pe(c4.cuda(), coff=1)
@@ -239,6 +241,9 @@ def test_sine_pe_matches_oracle_and_torch(hip, oracle):
     assert torch.allclose(got.cpu(), exp, atol=2e-6, rtol=0)
     ref = sine_position_encoding(c4.cuda()[:, 1:], 128)
     assert torch.allclose(got, ref, atol=2e-6, rtol=0)
+    # lookup and evaluation are the same numbers
+    direct = hip.sine_pe(c4.cuda(), pe.dim_t(torch.device("cuda", 0)), pe.scale, coff=1)
+    assert torch.equal(got, direct)
 
 
 def test_gram_batched_matches_matmul():

@@ -20,7 +20,9 @@ with torch.no_grad():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         if which == "ensemble":
             net.ensemble(ret, scene.Ts)
+        elif which == "unet":
+            net(x, scene.global_min_Cs, scene.global_max_Cs, scene.min_Cs, scene.max_Cs, keep_override=tk)
         else:
             net.prepare_input(scene.in_feats, scene.in_coords)
         torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=int(sys.argv[2]) if len(sys.argv) > 2 else 45, max_name_column_width=60))
