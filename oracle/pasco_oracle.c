@@ -283,18 +283,59 @@ int pho_split_rows(const float *in, int64_t n, int32_t c, const float *pro_scale
 
 /* a2-a5: per output row, per kernel offset, row-vector x W[k] accumulate (fp32, like upstream's
  * CPU gather -> SGEMM -> scatter-add). Rows are processed in blocks so W[k] stays cache resident. */
+/* rows of a split operand (ph_split_rows layout) back to fp32: hi + lo */
+static float *unsplit_rows(const void *split, int64_t n, int c, float scale) {
+  const int cpad = (c + 31) / 32 * 32;
+  const uint16_t *sp = (const uint16_t *)split;
+  float *x = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1) * c);
+  if (!x) return NULL;
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < n; ++r) {
+    const uint16_t *row = sp + r * 2 * cpad;
+    for (int ch = 0; ch < c; ++ch)
+      x[r * c + ch] = (f16_bits_to_f32(row[(ch >> 5) * 64 + (ch & 31)]) +
+                       f16_bits_to_f32(row[(ch >> 5) * 64 + 32 + (ch & 31)])) * scale;
+  }
+  return x;
+}
+
 int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   (void)stream;
   if (!d) return fail("conv_fwd: null desc");
   if (d->cin <= 0 || d->cout <= 0 || d->kvol < 1 || d->kvol > 4096) return fail("conv_fwd: bad shape");
   if (d->n_out == 0) return 0;
-  /* mma_mode only selects how the device forms the products; the restatement is plain fp32 either way */
+  /* mma_mode 0 / 1: plain fp32 on in / weight (how the device forms the products does not change the values
+   * beyond rounding).  mma_mode 2 follows the device's data flow (include/pasco_hip.h): the operands are
+   * in_split / w_split, read back as hi + lo, with the prologue already inside in_split; in / weight may be NULL. */
   if (!d->nbr && !(d->kvol == 1 && d->n_in == d->n_out)) return fail("conv_fwd: identity map needs kvol == 1");
   const int cin = d->cin, cout = d->cout;
   const int64_t n_out = d->n_out;
+  float *in_tmp = NULL, *w_tmp = NULL, *out_tmp = NULL;
+  const float *in = d->in, *weight = d->weight;
+  int has_pro = d->pro_scale || d->pro_shift || d->pro_act != PH_ACT_NONE;
+  if (d->mma_mode == 2 && d->in_split) {
+    in = in_tmp = unsplit_rows(d->in_split, d->n_in, cin, 1.f);
+    has_pro = 0;
+  }
+  if (!in) return fail("conv_fwd: null input");
+  if (d->mma_mode == 2 && d->w_split) {
+    /* w_split rows are [kvol * cout][cin] of weight * 2^e; back to [kvol][cin][cout] * 2^-e */
+    float *rows = unsplit_rows(d->w_split, (int64_t)d->kvol * cout, cin, d->w_unscale);
+    w_tmp = (float *)malloc(sizeof(float) * (size_t)d->kvol * cin * cout);
+    for (int64_t k = 0; k < d->kvol; ++k)
+      for (int n = 0; n < cout; ++n)
+        for (int c = 0; c < cin; ++c) w_tmp[(k * cin + c) * cout + n] = rows[(k * cout + n) * cin + c];
+    free(rows);
+    weight = w_tmp;
+  }
+  if (!weight) { free(in_tmp); return fail("conv_fwd: null weight"); }
+  float *outp = d->out;
+  if (!outp) {
+    if (!d->out_split) { free(in_tmp); free(w_tmp); return fail("conv_fwd: no output buffer"); }
+    outp = out_tmp = (float *)malloc(sizeof(float) * (size_t)n_out * cout);
+  }
   enum { RB = 32 };
   const int64_t nblocks = (n_out + RB - 1) / RB;
-  const int has_pro = d->pro_scale || d->pro_shift || d->pro_act != PH_ACT_NONE;
 #pragma omp parallel
   {
     float *acc = (float *)malloc(sizeof(float) * RB * cout);
@@ -305,12 +346,12 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
       const int rows = (int)((n_out - o0) < RB ? (n_out - o0) : RB);
       memset(acc, 0, sizeof(float) * RB * cout);
       for (int k = 0; k < d->kvol; ++k) {
-        const float *wk = d->weight + (int64_t)k * cin * cout;
+        const float *wk = weight + (int64_t)k * cin * cout;
         for (int r = 0; r < rows; ++r) {
           const int64_t o = o0 + r;
           const int idx = d->nbr ? d->nbr[(int64_t)k * n_out + o] : (int)o;
           if (idx < 0) continue;
-          const float *src = d->in + (int64_t)idx * cin;
+          const float *src = in + (int64_t)idx * cin;
           const float *a = src;
           if (has_pro) {
             for (int c = 0; c < cin; ++c) {
@@ -338,19 +379,23 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
             if (d->residual) v += d->residual[o * cout + n];
             v = act_apply(v, d->res_act, d->epi_slope);
           }
-          d->out[o * cout + n] = v;
+          outp[o * cout + n] = v;
         }
       }
     }
     free(acc);
     free(arow);
   }
+  int rc = 0;
   if (d->out_split) {   /* second output of mma_mode 2: the next convolution's operand */
-    if (!d->out || d->cout % 32 != 0) return fail("conv_fwd: out_split needs out and cout % 32 == 0");
-    return pho_split_rows(d->out, d->n_out, d->cout, d->osp_scale, d->osp_shift, d->osp_act, d->epi_slope,
-                          d->out_split, d->status, stream);
+    if (d->cout % 32 != 0) rc = fail("conv_fwd: out_split needs cout % 32 == 0");
+    else rc = pho_split_rows(outp, d->n_out, d->cout, d->osp_scale, d->osp_shift, d->osp_act, d->epi_slope,
+                             d->out_split, d->status, stream);
   }
-  return 0;
+  free(in_tmp);
+  free(w_tmp);
+  free(out_tmp);
+  return rc;
 }
 
 /* a10 */

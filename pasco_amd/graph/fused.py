@@ -14,6 +14,17 @@ from ..me.modules import MinkowskiBatchNorm, _ConvBase
 
 _CONV_PRECISION = "f16x3"
 _PRESPLIT = True     # f16x3 operands pre-split once per tensor (mma_mode 2) instead of per gather (mode 1)
+MIN_ROWS_LINEAR = 16384    # tall-operand threshold above which linear layers run on the convolution kernel
+
+
+def _kernel_device(device) -> bool:
+    """True where the convolution kernel can take linear layers: a GPU, or (tests) a CPU checker backend that
+    has been allowed to take split-operand descriptors."""
+    if device.type == "cuda":
+        return True
+    from ..me import backend
+    cb = backend._checker_backend
+    return cb is not None and cb.checker_split
 
 
 def set_conv_precision(mode: str) -> None:
@@ -63,14 +74,14 @@ def split_input(x: SparseTensor, be, ps, pb, pro_act, slope):
 def split_rows_2d(x2d: torch.Tensor):
     """Pre-split operand of a tall [N, cin] matrix for several `linear_rows` calls on it (None when the split
     path does not apply)."""
-    if not (x2d.is_cuda and _CONV_PRECISION == "f16x3" and _PRESPLIT and x2d.shape[1] % 8 == 0):
+    if not (_kernel_device(x2d.device) and _CONV_PRECISION == "f16x3" and _PRESPLIT and x2d.shape[1] % 8 == 0):
         return None
     from ..me.backend import backend_for
     return backend_for(x2d.device).split_rows(x2d.contiguous())
 
 
 def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_owner, cache_key: str,
-                min_rows: int = 16384, in_split=None, residual: Optional[torch.Tensor] = None,
+                min_rows: Optional[int] = None, in_split=None, residual: Optional[torch.Tensor] = None,
                 emit: bool = False, want_out: bool = True):
     """y = x @ weight.T + bias for a tall [N, cin] operand (`weight` is an nn.Linear-style [cout, cin] tensor
     or a row slice of one).  Large N on the GPU goes through the convolution kernel as an identity-map k=1
@@ -84,7 +95,8 @@ def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_o
     n = x2d.shape[0] if x2d is not None else in_split.shape[0]
     dev = x2d.device if x2d is not None else in_split.device
     be = None
-    if dev.type == "cuda" and n >= min_rows and _CONV_PRECISION == "f16x3":
+    min_rows = MIN_ROWS_LINEAR if min_rows is None else min_rows
+    if _kernel_device(dev) and n >= min_rows and _CONV_PRECISION == "f16x3":
         from ..me.backend import backend_for
         be = backend_for(dev)
         if not be.split_supported(cin, cout):
@@ -113,14 +125,15 @@ def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_o
 
 
 def linear_bn_act(x2d: torch.Tensor, lin: nn.Linear, *, pro_bn=None, epi_bn=None, epi_act: int = ACT_NONE,
-                  min_rows: int = 16384) -> torch.Tensor:
+                  min_rows: Optional[int] = None) -> torch.Tensor:
     """act(BN_epi(Linear(BN_pro(x)))) for a tall [N, cin] operand as ONE launch of the convolution kernel
     (identity map, eval BatchNorm folded into the gather prologue / store epilogue) - the point MLP of
     CylinderFeat (unet3d_sparse_v2.py:27-43) without separate normalisation / activation passes.
     Small N, CPU tensors: plain torch modules."""
     n, cin = x2d.shape
     cout = lin.out_features
-    if not (x2d.is_cuda and n >= min_rows):
+    min_rows = MIN_ROWS_LINEAR if min_rows is None else min_rows
+    if not (_kernel_device(x2d.device) and n >= min_rows):
         y = x2d if pro_bn is None else pro_bn(x2d)
         y = lin(y)
         y = y if epi_bn is None else epi_bn(y)

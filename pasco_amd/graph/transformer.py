@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from .. import me as ME
 from ..me.backend import backend_for
+from . import fused as fused_mod
 from .fused import batched_rows_matmul, linear_rows, split_rows_2d
 
 
@@ -125,7 +126,7 @@ class CrossAttentionLayer(nn.Module):
             N = kv.shape[1]
             kv2 = kv.reshape(B * N, D)
             kv_split = feats_split
-            if kv_split is None and kv2.shape[0] >= 16384:
+            if kv_split is None and kv2.shape[0] >= fused_mod.MIN_ROWS_LINEAR:
                 kv_split = split_rows_2d(kv2)                                     # one operand split for K and V
         kk = linear_rows(kv2, w[D:2 * D], b[D:2 * D], self, "k", in_split=kv_split).view(B, N, D)
         vv = linear_rows(kv2, w[2 * D:], b[2 * D:], self, "v", in_split=kv_split).view(B, N, D)

@@ -111,6 +111,9 @@ class CBackend:
         if v != 1:
             raise RuntimeError(f"{path}: ABI version {v}, expected 1")
         self._ws: Dict[torch.device, torch.Tensor] = {}
+        # tests may let a CPU checker library take the split-operand (mode 2) descriptors as well, so that the
+        # host-side plumbing of that path (operand emission, split-only tensors) is exercised without a GPU
+        self.checker_split = False
 
     # -- helpers -----------------------------------------------------------------------------------
     def has(self, name: str) -> bool:
@@ -239,7 +242,7 @@ class CBackend:
         of act(out * scale + shift) for the next convolution and return (out, out_split); `want_out=False` then
         skips the fp32 result (returns (None, out_split))."""
         if x is None:          # rows that exist only as a pre-split operand (mode 2): `xshape` = (n_in, cin)
-            if xshape is None or in_split is None or split is None or len(split) != 2 or self.device_type != "cuda":
+            if xshape is None or in_split is None or split is None or len(split) != 2 or not self.split_capable():
                 raise ValueError("conv: x=None needs xshape, in_split and a mode-2 split on the device backend")
             if pro_scale is not None or pro_shift is not None or pro_act != ACT_NONE:
                 raise ValueError("conv: a pre-split input already carries its prologue")
@@ -249,7 +252,7 @@ class CBackend:
             self._chk(x, torch.float32, "in")
             dev = x.device
         if weight is None:     # pre-split operands only (mode 2): the fp32 kernel is not read, `wshape` = (kvol, cin, cout)
-            if wshape is None or split is None or len(split) != 2 or self.device_type != "cuda":
+            if wshape is None or split is None or len(split) != 2 or not self.split_capable():
                 raise ValueError("conv: weight=None needs wshape and a mode-2 split on the device backend")
             kvol, cin, cout = wshape
         else:
@@ -398,8 +401,11 @@ class CBackend:
         rows = torch.ldexp(w, torch.tensor(e, device=w.device)).transpose(1, 2).contiguous().view(k * cout, cin)
         return self.split_rows(rows), float(2.0 ** (-e))
 
+    def split_capable(self) -> bool:
+        return self.device_type == "cuda" or self.checker_split
+
     def split_supported(self, cin: int, cout: int) -> bool:
-        return self.device_type == "cuda" and cin % 8 == 0 and cout % 4 == 0
+        return self.split_capable() and cin % 8 == 0 and cout % 4 == 0
 
     def maxpool_fwd(self, x: torch.Tensor, nbr: torch.Tensor) -> torch.Tensor:
         self._chk(x, torch.float32, "in")

@@ -141,3 +141,9 @@ def test_config_shaped_graphs_vs_oracle(hip, oracle, cfg):
         assert torch.equal(a["voxel_logits"].C.cpu(), b["voxel_logits"].C)
         assert torch.allclose(a["voxel_logits"].F.cpu(), b["voxel_logits"].F, rtol=2e-3, atol=2e-3)
         assert torch.allclose(a["query_logits"].cpu(), b["query_logits"], rtol=2e-3, atol=2e-3)
+
+
+def test_graft_entry_smoke(hip):
+    """The driver's smoke(): one small MIMO-2 scene, HIP vs oracle."""
+    import __graft_entry__ as g
+    g.smoke()
