@@ -203,11 +203,16 @@ def main():
         prof.enabled = not args.no_profile
         barrier()
         t0 = time.perf_counter()
+        marks = [t0]
         for _ in range(args.steps):
             out, panop = run_scene(net, scene, teacher, window)
+            marks.append(time.perf_counter())      # host-side enqueue clock of each step (diagnostic, stderr only)
         barrier()
         elapsed = time.perf_counter() - t0
         prof.enabled = False
+        if rank == 0:
+            per = [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])]
+            print(f"[bench] per-step host ms: {per}", file=sys.stderr, flush=True)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)

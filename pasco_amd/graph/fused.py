@@ -124,22 +124,28 @@ def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_o
     return out if do_emit else (out, None)
 
 
-def linear_bn_act(x2d: torch.Tensor, lin: nn.Linear, *, pro_bn=None, epi_bn=None, epi_act: int = ACT_NONE,
-                  min_rows: Optional[int] = None) -> torch.Tensor:
+def linear_bn_act(x2d: Optional[torch.Tensor], lin: nn.Linear, *, pro_bn=None, epi_bn=None, epi_act: int = ACT_NONE,
+                  min_rows: Optional[int] = None, in_split=None, emit: bool = False):
     """act(BN_epi(Linear(BN_pro(x)))) for a tall [N, cin] operand as ONE launch of the convolution kernel
     (identity map, eval BatchNorm folded into the gather prologue / store epilogue) - the point MLP of
     CylinderFeat (unet3d_sparse_v2.py:27-43) without separate normalisation / activation passes.
-    Small N, CPU tensors: plain torch modules."""
-    n, cin = x2d.shape
-    cout = lin.out_features
+    Small N, CPU tensors: plain torch modules.
+    `emit`: the result is read only by the next layer of the chain -> return (None, operand) with the result stored
+    only as that layer's pre-split operand ((y, None) when the split path does not apply); `in_split` = such an
+    operand from the previous layer (then `x2d` is None)."""
+    cin, cout = lin.in_features, lin.out_features
+    n = x2d.shape[0] if x2d is not None else in_split.shape[0]
+    dev = x2d.device if x2d is not None else in_split.device
     min_rows = MIN_ROWS_LINEAR if min_rows is None else min_rows
-    if not (_kernel_device(x2d.device) and n >= min_rows):
+    if not (_kernel_device(dev) and n >= min_rows):
+        assert x2d is not None
         y = x2d if pro_bn is None else pro_bn(x2d)
         y = lin(y)
         y = y if epi_bn is None else epi_bn(y)
-        return torch.relu(y) if epi_act == ACT_RELU else y
+        y = torch.relu(y) if epi_act == ACT_RELU else y
+        return (y, None) if emit else y
     from ..me.backend import backend_for
-    be = backend_for(x2d.device)
+    be = backend_for(dev)
     ps = pb = es = eb = None
     if pro_bn is not None:
         ps, pb = fold_bn(pro_bn)
@@ -154,8 +160,15 @@ def linear_bn_act(x2d: torch.Tensor, lin: nn.Linear, *, pro_bn=None, epi_bn=None
         hit = (ver, wt, split, lin.bias.detach().contiguous() if lin.bias is not None else None)
         lin.__dict__["_ph_lin_w"] = hit
     _, wt, split, b = hit
-    return be.conv_fwd(x2d.contiguous(), wt, None, n, bias=b, pro_scale=ps, pro_shift=pb, epi_scale=es, epi_shift=eb,
-                       epi_act=epi_act, split=split)
+    do_emit = emit and split is not None and _PRESPLIT and cout % 32 == 0
+    assert x2d is not None or (split is not None and _PRESPLIT), "a pre-split operand needs the split path"
+    out = be.conv_fwd(None if x2d is None else x2d.contiguous(), wt, None, n, xshape=(n, cin) if x2d is None else None,
+                      bias=b, pro_scale=ps, pro_shift=pb, epi_scale=es, epi_shift=eb, epi_act=epi_act, split=split,
+                      in_split=in_split if (split is not None and _PRESPLIT) else None,
+                      emit_split=(None, None, ACT_NONE) if do_emit else None, want_out=not do_emit)
+    if not emit:
+        return out
+    return out if do_emit else (out, None)
 
 
 def batched_rows_matmul(x: Optional[torch.Tensor], w: torch.Tensor, x_split: torch.Tensor, shape=None) -> torch.Tensor:

@@ -75,10 +75,11 @@ class CylinderFeat(nn.Module):
         if self.training:
             return self.PPmodel(fea)
         m = self.PPmodel
-        h = fused.linear_bn_act(fea, m[1], pro_bn=m[0], epi_bn=m[2], epi_act=ACT_RELU)
-        h = fused.linear_bn_act(h, m[4], epi_bn=m[5], epi_act=ACT_RELU)
-        h = fused.linear_bn_act(h, m[7], epi_bn=m[8], epi_act=ACT_RELU)
-        return fused.linear_bn_act(h, m[10])
+        # each hidden activation has one reader (the next Linear): it is stored only as that layer's operand
+        h, hs = fused.linear_bn_act(fea, m[1], pro_bn=m[0], epi_bn=m[2], epi_act=ACT_RELU, emit=True)
+        h, hs = fused.linear_bn_act(h, m[4], epi_bn=m[5], epi_act=ACT_RELU, in_split=hs, emit=True)
+        h, hs = fused.linear_bn_act(h, m[7], epi_bn=m[8], epi_act=ACT_RELU, in_split=hs, emit=True)
+        return fused.linear_bn_act(h, m[10], in_split=hs)
 
     def forward(self, pt_fea: List[torch.Tensor], xy_ind: List[torch.Tensor]):
         ind = torch.cat([F.pad(c, (1, 0), value=i) for i, c in enumerate(xy_ind)], dim=0)
