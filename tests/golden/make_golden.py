@@ -313,9 +313,37 @@ def golden_ensemble():
     save("ensemble.npz", **arrays)
 
 
+def golden_transform_and_matching():
+    """Two leaf functions of the ensembler on their own: `transform` (transform_utils.py:60-74) on signed voxel
+    indices for three transformations, and `find_matching_indices_v2` (utils.py:153-198) on 7 queries."""
+    from pasco.models.transform_utils import generate_transformation, transform
+    from pasco.models.utils import find_matching_indices_v2
+    g = torch.Generator().manual_seed(77)
+    coords = torch.randint(-20, 300, (400, 3), generator=g)
+    arrays = {"coords": coords}
+    rots, trans = (0.0, 10.0, -20.0), ((0.0, 0.0, 0.0), (0.2, -0.2, 0.0), (-0.4, 0.2, 0.2))
+    for i, (r, t) in enumerate(zip(rots, trans)):
+        T = generate_transformation(r, np.array(t)).float()
+        arrays[f"T{i}"] = T
+        arrays[f"out{i}"] = transform(coords, T)
+    Q, U = 7, 500
+    a = torch.rand(Q, U, generator=g) * (torch.rand(Q, U, generator=g) > 0.6)
+    b = a[torch.randperm(Q, generator=g)] * 0.8 + 0.2 * torch.rand(Q, U, generator=g) * (torch.rand(Q, U, generator=g) > 0.8)
+    b[3] = 0.0                                            # an empty mask: union can be 0 against an empty anchor
+    a[5] = 0.0
+    qa, qb = torch.rand(Q, 21, generator=g), torch.rand(Q, 21, generator=g)
+    ai, bi, iou = find_matching_indices_v2(a, qa, b, qb, 0.2)
+    arrays.update(anchor=a, aux=b, a_idx=torch.as_tensor(ai), b_idx=torch.as_tensor(bi), iou=iou)
+    print("matching", list(ai), list(bi), [round(float(v), 3) for v in iou])
+    save("transform_matching.npz", **arrays)
+
+
 if __name__ == "__main__":
     if "--ensemble-only" in sys.argv:
         golden_ensemble()
+        sys.exit(0)
+    if "--leaf-only" in sys.argv:
+        golden_transform_and_matching()
         sys.exit(0)
     golden_pe()
     golden_attention_layers()
@@ -324,3 +352,4 @@ if __name__ == "__main__":
     golden_unet(2, False, "m2_light")
     golden_unet(1, True, "m1_heavy")
     golden_ensemble()
+    golden_transform_and_matching()

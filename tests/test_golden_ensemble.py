@@ -64,3 +64,17 @@ def test_ensemble_and_panoptic_match_reference_cpu(oracle_registered):
 @pytest.mark.gpu
 def test_ensemble_and_panoptic_match_reference_gpu(hip):
     run_case("cuda", rtol=1e-3, atol=1e-4)
+
+
+def test_transform_and_matching_leaves_match_reference():
+    """`project_canonical` against the reference's `transform` (bit-exact integer coordinates, three
+    transformations, signed indices) and `Ensembler.match_queries` against `find_matching_indices_v2`
+    (assignment identical, IoU to 1e-6), incl. empty masks on both sides."""
+    from pasco_amd.graph.ensemble import project_canonical
+    d = load("transform_matching.npz")
+    for i in range(3):
+        got = project_canonical(d["coords"].to(torch.int32), d[f"T{i}"])
+        assert torch.equal(got, d[f"out{i}"].to(torch.int32)), i
+    a_idx, b_idx, iou = Ensembler.match_queries(d["anchor"].t().contiguous(), d["aux"].t().contiguous(), 0.2)
+    assert torch.equal(a_idx, d["a_idx"]) and torch.equal(b_idx, d["b_idx"])
+    assert torch.allclose(iou, d["iou"], rtol=1e-6, atol=1e-6)
