@@ -792,6 +792,13 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   if (bn >= 64 && ((d->n_out + 127) / 128) * ncol < 2 * 256) bm = 64;
   if (bn == 128 && bm == 64 && ((d->n_out + 63) / 64) * ncol < 2 * 256) bm = 32;
   int kc = (d->cin % 64 == 0 && d->cin >= 256) ? 64 : 32;   // deeper stages pay only for wide layers (profiles/r1f_op_bench.json)
+  // 128-channel layers with fewer than ~1.5 waves of 128-row tiles (stride-2 levels of the pruned scene): 64-row
+  // tiles with 64-channel stages measured 304 -> 250 us (profiles/README.md, r1k sweep); env PASCO_CONVH_MID=0 disables
+  static const bool mid_on = getenv("PASCO_CONVH_MID") ? atoi(getenv("PASCO_CONVH_MID")) != 0 : true;
+  if (pre && mid_on && bn == 128 && d->cin == 128 && d->kvol > 1 && ((d->n_out + 127) / 128) * ncol < 3 * 256) {
+    if (bm == 128) bm = 64;
+    kc = 64;
+  }
   if (pre && a.cpad % 64 != 0) kc = 32;
   const char *env = getenv("PASCO_CONVH_CFG");   // tuning override: "bm,kc"
   if (env) {
