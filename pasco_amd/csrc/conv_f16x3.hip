@@ -332,122 +332,6 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
 // EMIT = the launch also writes the next convolution's operand (out_split).  A separate instantiation: the
 // emission code raises the kernel's register budget (one wave of occupancy less), which launches that do not
 // emit should not pay for.
-// Epilogue shared by the k_conv_h2 variants.  Accumulator layout (transposed block):
-// acc[i][j][4g + q] = out[row = m0 + (wm*TM+i)*32 + l31][col = n0 + (wn*TN+j)*32 + 8g + 4h + q]
-template <int TM, int TN, bool EMIT>
-__device__ __forceinline__ void h2_epilogue(const ConvArgsH &a, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm, int wn,
-                                            int l31, int h) {
-  const int cout = a.cout;
-  if (a.ksplit > 1) {   // raw partial sums; k_splitk_epilogue reduces them in a fixed order
-    float *part = a.partial + (int64_t)blockIdx.y * a.n_out * cout;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int64_t row = m0 + (wm * TM + i) * 32 + l31;
-      if (row >= a.n_out) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = n0 + (wn * TN + j) * 32 + 8 * g + 4 * h;
-          if (col >= cout) continue;
-          *reinterpret_cast<float4 *>(part + row * cout + col) =
-              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        }
-    }
-    return;
-  }
-
-  float omax = 0.f;
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {       // pairs of 4-channel runs: g = 2m, 2m + 1
-      const int cbase = n0 + (wn * TN + j) * 32 + 16 * m;
-      if (cbase >= cout) continue;      // uniform over the wave (cout % 4 == 0; with out_split cout % 32 == 0)
-      float bias[2][4], es[2][4], eb[2][4], es2[2][4], eb2[2][4];
-      bool cok[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int col = cbase + 8 * u + 4 * h;
-        cok[u] = col < cout;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c = cok[u] ? col + q : 0;
-          bias[u][q] = a.bias ? a.bias[c] : 0.f;
-          es[u][q] = a.epi_scale ? a.epi_scale[c] : 1.f;
-          eb[u][q] = a.epi_shift ? a.epi_shift[c] : 0.f;
-          es2[u][q] = a.epi2_scale ? a.epi2_scale[c] : 1.f;
-          eb2[u][q] = a.epi2_shift ? a.epi2_shift[c] : 0.f;
-        }
-      }
-      // operand emission: after a half-wave exchange this lane owns 8 consecutive channels cbase + 8h .. + 7
-      float sc[8], sh[8];
-      if (EMIT) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          sc[q] = a.osp_scale ? a.osp_scale[cbase + 8 * h + q] : 1.f;
-          sh[q] = a.osp_shift ? a.osp_shift[cbase + 8 * h + q] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int64_t row = m0 + (wm * TM + i) * 32 + l31;
-        const bool rok = row < a.n_out;
-        float v[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int g = 2 * m + u;
-          const int col = cbase + 8 * u + 4 * h;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            v[u][q] = h_act((acc[i][j][4 * g + q] * a.w_unscale + bias[u][q]) * es[u][q] + eb[u][q], a.epi_neg);
-          if (a.has_tail) {
-            float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.residual && rok && cok[u]) rs = *reinterpret_cast<const float4 *>(a.residual + row * cout + col);
-            const float r4[4] = {rs.x, rs.y, rs.z, rs.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[u][q] = h_act(v[u][q] * es2[u][q] + eb2[u][q] + r4[q], a.res_neg);
-          }
-          if ((!EMIT || a.out) && rok && cok[u])
-            *reinterpret_cast<float4 *>(a.out + row * cout + col) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
-        }
-        if (EMIT) {
-          // lanes l and l ^ 32 hold the same row: h = 0 keeps run u = 0 and takes the partner's u = 0 (channels
-          // +4..7); h = 1 takes the partner's u = 1 (channels +8..11) and keeps its own u = 1
-          float w8[8];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float send = h ? v[0][q] : v[1][q];
-            const float recv = __shfl_xor(send, 32);
-            w8[q] = h ? recv : v[0][q];
-            w8[4 + q] = h ? v[1][q] : recv;
-          }
-          if (rok) {
-            f16x8 hi, lo;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              float t = w8[q];
-              if (a.osp_has) {   // separate multiply and add, like ph_split_rows and the C restatement
-#pragma clang fp contract(off)
-                const float mm = t * sc[q];
-                t = h_act(mm + sh[q], a.osp_neg);
-              }
-              omax = fmaxf(omax, fabsf(t));
-              const _Float16 th = (_Float16)t;
-              hi[q] = th;
-              lo[q] = (_Float16)(t - (float)th);
-            }
-            const int col8 = cbase + 8 * h;
-            _Float16 *dst = a.out_split + (row * (cout >> 5) + (col8 >> 5)) * 64 + (col8 & 31);
-            *reinterpret_cast<f16x8 *>(dst) = hi;
-            *reinterpret_cast<f16x8 *>(dst + 32) = lo;
-          }
-        }
-      }
-    }
-  if (EMIT && a.status != nullptr && !(omax <= 65504.f)) atomicOr(a.status, 1);
-}
-
 template <int BM, int KC, int WM, int WN, int TM, int TN, bool EMIT>
 __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
   constexpr int BN = WN * TN * 32;
@@ -600,174 +484,116 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
     __syncthreads();
   }
 
-  h2_epilogue<TM, TN, EMIT>(a, acc, m0, n0, wm, wn, l31, h);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// k_conv_h2d: the same tile computation with the operand tiles filled by direct global -> LDS loads
-// (`global_load_lds_dwordx4`): no staging registers, no ds_write pass, two LDS buffers, ONE barrier per stage; the
-// loads of stage s + 1 are in flight while stage s is multiplied.  KC = 32: a tile row is 128 bytes = 8 chunks
-// of 16 bytes, rows are stored unpadded (the DMA writes lane-linearly) with chunk c of row r at position
-// c ^ ((r >> 1) & 7) - conflict-free for the lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS table).  The
-// swizzle is applied to the per-lane SOURCE address and to the fragment reads.  Rows without a neighbour read a
-// 128-byte zero line.
-// ------------------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(128))) const uint32_t ph_zero_line[64] = {0};
-
-template <int BM, int WM, int WN, int TM, int TN, bool EMIT>
-__global__ void __launch_bounds__(HV_THREADS) k_conv_h2d(ConvArgsH a) {
-  constexpr int KC = 32;
-  constexpr int BN = WN * TN * 32;
-  constexpr int ROW = 64;                     // f16 per tile row (32 hi | 32 lo)
-  constexpr int A_PASSES = BM / 32;           // 32 rows per pass: 8 rows per wave-instruction x 4 waves
-  constexpr int B_PASSES = (BN + 31) / 32;
-  static_assert(WM * WN == 4 && WM * TM * 32 == BM && BN % 32 == 0, "tile shape");
-
-  __shared__ __attribute__((aligned(128))) _Float16 As[2][BM * ROW];
-  __shared__ __attribute__((aligned(128))) _Float16 Bs[2][BN * ROW];
-
-  const int nwg = gridDim.x;
-  const int cpx = nwg >> 3;
-  const int bid = blockIdx.x;
-  const int tile = (bid & 7) * cpx + (bid >> 3);
-  const int ntiles = a.n_row_tiles * a.n_col_tiles;
-  if (tile >= ntiles) return;
-  const int row_tile = tile / a.n_col_tiles;
-  const int col_tile = tile - row_tile * a.n_col_tiles;
-  const int64_t m0 = (int64_t)row_tile * BM;
-  const int n0 = col_tile * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int h = lane >> 5;
-  const int l31 = lane & 31;
-
-  const int cout = a.cout;
-  const int nchunks = a.cpad / KC;
-  const int kper = (a.kvol + a.ksplit - 1) / a.ksplit;
-  const int k_begin = (int)blockIdx.y * kper;
-  const int k_end = (k_begin + kper < a.kvol) ? k_begin + kper : a.kvol;
-  const int nstages = (k_end > k_begin ? k_end - k_begin : 0) * nchunks;
-  const int l_j = tid & 7;                    // physical 16-byte chunk this lane fills
-  const int l_r = tid >> 3;                   // tile row of this lane in pass 0 (pass p: + 32 p)
-  const int c_log = l_j ^ ((l_r >> 1) & 7);   // logical chunk it must fetch (the same for every pass: 32 p >> 1 = 0 mod 8)
-  const uint32_t rs = 2u * (uint32_t)a.cpad;  // f16 per operand row
-  const _Float16 *zero = reinterpret_cast<const _Float16 *>(ph_zero_line);
-
-  f32x16 acc[TM][TN];
+  // accumulator layout (transposed block): acc[i][j][4g + q] = out[row = m0 + (wm*TM+i)*32 + l31]
+  //                                                          [col = n0 + (wn*TN+j)*32 + 8g + 4h + q]
+  if (a.ksplit > 1) {   // raw partial sums; k_splitk_epilogue reduces them in a fixed order
+    float *part = a.partial + (int64_t)blockIdx.y * a.n_out * cout;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+      const int64_t row = m0 + (wm * TM + i) * 32 + l31;
+      if (row >= a.n_out) continue;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  int idx_cur[A_PASSES], idx_nxt[A_PASSES];
-  int64_t boff[B_PASSES];
-#pragma unroll
-  for (int q = 0; q < B_PASSES; ++q) {
-    const int n = l_r + q * 32;
-    boff[q] = (n < BN && n0 + n < cout) ? (int64_t)(n0 + n) * rs + c_log * 8 : -1;
+        for (int g = 0; g < 4; ++g) {
+          const int col = n0 + (wn * TN + j) * 32 + 8 * g + 4 * h;
+          if (col >= cout) continue;
+          *reinterpret_cast<float4 *>(part + row * cout + col) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+    }
+    return;
   }
 
-  auto load_idx = [&](int k, int *dst) {
+  float omax = 0.f;
 #pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) {
-      const int64_t row = m0 + l_r + p * 32;
-      int idx = -1;
-      if (row < a.n_out) idx = a.nbr ? a.nbr[(int64_t)k * a.n_out + row] : (int)row;
-      dst[p] = idx;
-    }
-  };
-
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
-
-  // one wave-instruction = 64 lanes x 16 B = 8 tile rows, written lane-linearly from the wave's first row
-  auto issue_stage = [&](int k, int chunk, int buf) {
-    const int coff = chunk * (2 * KC) + c_log * 8;
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) {
-      const int idx = idx_cur[p];
-      const _Float16 *src = idx >= 0 ? a.in_split + (uint64_t)(uint32_t)idx * rs + coff : zero + c_log * 8;
-      _Float16 *dst = &As[buf][(wave * 8 + p * 32) * ROW];
-      __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dst, 16, 0, 0);
-    }
-    const _Float16 *wk = a.w_split + (int64_t)k * cout * rs + chunk * (2 * KC);
+    for (int m = 0; m < 2; ++m) {       // pairs of 4-channel runs: g = 2m, 2m + 1
+      const int cbase = n0 + (wn * TN + j) * 32 + 16 * m;
+      if (cbase >= cout) continue;      // uniform over the wave (cout % 4 == 0; with out_split cout % 32 == 0)
+      float bias[2][4], es[2][4], eb[2][4], es2[2][4], eb2[2][4];
+      bool cok[2];
 #pragma unroll
-    for (int q = 0; q < B_PASSES; ++q) {
-      if (wave * 8 + q * 32 >= BN) continue;          // wave-uniform
-      const _Float16 *src = boff[q] >= 0 ? wk + boff[q] : zero + c_log * 8;
-      _Float16 *dst = &Bs[buf][(wave * 8 + q * 32) * ROW];
-      __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)dst, 16, 0, 0);
-    }
-  };
-
-  // fragments of a whole stage (both 16-channel steps) are read BEFORE the next stage's DMA is issued: the
-  // compiler drains vmcnt before any LDS read that follows a global_load_lds (it cannot tell the buffers apart),
-  // so reads issued after the DMA would serialise it with this stage's MFMAs
-  f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
-  auto read_stage = [&](int buf) {
+      for (int u = 0; u < 2; ++u) {
+        const int col = cbase + 8 * u + 4 * h;
+        cok[u] = col < cout;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+        for (int q = 0; q < 4; ++q) {
+          const int c = cok[u] ? col + q : 0;
+          bias[u][q] = a.bias ? a.bias[c] : 0.f;
+          es[u][q] = a.epi_scale ? a.epi_scale[c] : 1.f;
+          eb[u][q] = a.epi_shift ? a.epi_shift[c] : 0.f;
+          es2[u][q] = a.epi2_scale ? a.epi2_scale[c] : 1.f;
+          eb2[u][q] = a.epi2_shift ? a.epi2_shift[c] : 0.f;
+        }
+      }
+      // operand emission: after a half-wave exchange this lane owns 8 consecutive channels cbase + 8h .. + 7
+      float sc[8], sh[8];
+      if (EMIT) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          sc[q] = a.osp_scale ? a.osp_scale[cbase + 8 * h + q] : 1.f;
+          sh[q] = a.osp_shift ? a.osp_shift[cbase + 8 * h + q] : 0.f;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int R = (wm * TM + i) * 32 + l31;
-        const int sw = (R >> 1) & 7;
-        ah[ks][i] = *reinterpret_cast<const f16x8 *>(&As[buf][R * ROW + (((ks * 2 + h) ^ sw) << 3)]);
-        al[ks][i] = *reinterpret_cast<const f16x8 *>(&As[buf][R * ROW + (((4 + ks * 2 + h) ^ sw) << 3)]);
-      }
+        const int64_t row = m0 + (wm * TM + i) * 32 + l31;
+        const bool rok = row < a.n_out;
+        float v[2][4];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int R = (wn * TN + j) * 32 + l31;
-        const int sw = (R >> 1) & 7;
-        bh[ks][j] = *reinterpret_cast<const f16x8 *>(&Bs[buf][R * ROW + (((ks * 2 + h) ^ sw) << 3)]);
-        bl[ks][j] = *reinterpret_cast<const f16x8 *>(&Bs[buf][R * ROW + (((4 + ks * 2 + h) ^ sw) << 3)]);
-      }
-    }
-  };
-  auto mma_stage = [&]() {
+        for (int u = 0; u < 2; ++u) {
+          const int g = 2 * m + u;
+          const int col = cbase + 8 * u + 4 * h;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+          for (int q = 0; q < 4; ++q)
+            v[u][q] = h_act((acc[i][j][4 * g + q] * a.w_unscale + bias[u][q]) * es[u][q] + eb[u][q], a.epi_neg);
+          if (a.has_tail) {
+            float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.residual && rok && cok[u]) rs = *reinterpret_cast<const float4 *>(a.residual + row * cout + col);
+            const float r4[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][j], al[ks][i], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[ks][j], ah[ks][i], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[ks][j], ah[ks][i], acc[i][j], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) v[u][q] = h_act(v[u][q] * es2[u][q] + eb2[u][q] + r4[q], a.res_neg);
+          }
+          if ((!EMIT || a.out) && rok && cok[u])
+            *reinterpret_cast<float4 *>(a.out + row * cout + col) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
         }
-  };
-
-  int kl = k_begin, cl = 0;    // loader position = the next stage to request
-  // the neighbour rows of the next offset are ordinary loads: they are consumed (and the following ones requested)
-  // AFTER the MFMAs of a stage, because the compiler drains vmcnt - i.e. also the DMA just issued - at their use
-  auto advance = [&]() {
-    if (++cl == nchunks) {
-      cl = 0;
-      ++kl;
+        if (EMIT) {
+          // lanes l and l ^ 32 hold the same row: h = 0 keeps run u = 0 and takes the partner's u = 0 (channels
+          // +4..7); h = 1 takes the partner's u = 1 (channels +8..11) and keeps its own u = 1
+          float w8[8];
 #pragma unroll
-      for (int p = 0; p < A_PASSES; ++p) idx_cur[p] = idx_nxt[p];
-      if (kl + 1 < k_end) load_idx(kl + 1, idx_nxt);
+          for (int q = 0; q < 4; ++q) {
+            const float send = h ? v[0][q] : v[1][q];
+            const float recv = __shfl_xor(send, 32);
+            w8[q] = h ? recv : v[0][q];
+            w8[4 + q] = h ? v[1][q] : recv;
+          }
+          if (rok) {
+            f16x8 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              float t = w8[q];
+              if (a.osp_has) {   // separate multiply and add, like ph_split_rows and the C restatement
+#pragma clang fp contract(off)
+                const float mm = t * sc[q];
+                t = h_act(mm + sh[q], a.osp_neg);
+              }
+              omax = fmaxf(omax, fabsf(t));
+              const _Float16 th = (_Float16)t;
+              hi[q] = th;
+              lo[q] = (_Float16)(t - (float)th);
+            }
+            const int col8 = cbase + 8 * h;
+            _Float16 *dst = a.out_split + (row * (cout >> 5) + (col8 >> 5)) * 64 + (col8 & 31);
+            *reinterpret_cast<f16x8 *>(dst) = hi;
+            *reinterpret_cast<f16x8 *>(dst + 32) = lo;
+          }
+        }
+      }
     }
-  };
-  if (nstages > 0) {
-    load_idx(k_begin, idx_cur);
-    if (k_begin + 1 < k_end) load_idx(k_begin + 1, idx_nxt);
-    issue_stage(kl, cl, 0);
-    advance();
-  }
-  for (int s = 0; s < nstages; ++s) {
-    __syncthreads();           // stage s has landed (the compiler drains vmcnt before the barrier); buffer (s+1)&1 is free
-    read_stage(s & 1);
-    if (s + 1 < nstages) issue_stage(kl, cl, (s + 1) & 1);
-    mma_stage();
-    if (s + 1 < nstages) advance();
-  }
-
-  h2_epilogue<TM, TN, EMIT>(a, acc, m0, n0, wm, wn, l31, h);
+  if (EMIT && a.status != nullptr && !(omax <= 65504.f)) atomicOr(a.status, 1);
 }
 
 // fp32 rows -> [hi x32 | lo x32] groups; one thread per 8 channels.  Channels >= c (pad to 32) are zero.
@@ -890,45 +716,10 @@ static int launch_h2(const ConvArgsH &a, hipStream_t st) {
   args.n_col_tiles = (a.cout + BN - 1) / BN;
   const int ntiles = args.n_row_tiles * args.n_col_tiles;
   const int grid = ((ntiles + 7) / 8) * 8;
-  static const bool dma_on = getenv("PASCO_CONVH_DMA") ? atoi(getenv("PASCO_CONVH_DMA")) != 0 : false;
-  const bool emit = args.out_split != nullptr && args.ksplit == 1;
-  if constexpr (KC == 32) {
-    if (dma_on) {
-      if (emit) hipLaunchKernelGGL((k_conv_h2d<BM, WM, WN, TM, TN, true>), dim3(grid, 1), dim3(HV_THREADS), 0, st, args);
-      else hipLaunchKernelGGL((k_conv_h2d<BM, WM, WN, TM, TN, false>), dim3(grid, args.ksplit), dim3(HV_THREADS), 0, st, args);
-      PH_LAUNCH_CHECK();
-      if (args.ksplit > 1) {
-        const int64_t total = a.n_out * a.cout;
-        hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, args);
-        PH_LAUNCH_CHECK();
-      }
-      return 0;
-    }
-  }
-  if (emit)
+  if (args.out_split != nullptr && args.ksplit == 1)
     hipLaunchKernelGGL((k_conv_h2<BM, KC, WM, WN, TM, TN, true>), dim3(grid, 1), dim3(HV_THREADS), 0, st, args);
   else
     hipLaunchKernelGGL((k_conv_h2<BM, KC, WM, WN, TM, TN, false>), dim3(grid, args.ksplit), dim3(HV_THREADS), 0, st, args);
-  PH_LAUNCH_CHECK();
-  if (args.ksplit > 1) {
-    const int64_t total = a.n_out * a.cout;
-    hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, args);
-    PH_LAUNCH_CHECK();
-  }
-  return 0;
-}
-
-template <int BM, int WM, int WN, int TM, int TN>
-static int launch_h2d(const ConvArgsH &a, hipStream_t st) {
-  constexpr int BN = WN * TN * 32;
-  ConvArgsH args = a;
-  args.n_row_tiles = (int)((a.n_out + BM - 1) / BM);
-  args.n_col_tiles = (a.cout + BN - 1) / BN;
-  const int ntiles = args.n_row_tiles * args.n_col_tiles;
-  const int grid = ((ntiles + 7) / 8) * 8;
-  const bool emit = args.out_split != nullptr && args.ksplit == 1;
-  if (emit) hipLaunchKernelGGL((k_conv_h2d<BM, WM, WN, TM, TN, true>), dim3(grid, 1), dim3(HV_THREADS), 0, st, args);
-  else hipLaunchKernelGGL((k_conv_h2d<BM, WM, WN, TM, TN, false>), dim3(grid, args.ksplit), dim3(HV_THREADS), 0, st, args);
   PH_LAUNCH_CHECK();
   if (args.ksplit > 1) {
     const int64_t total = a.n_out * a.cout;
@@ -1009,13 +800,11 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
     kc = 64;
   }
   if (pre && a.cpad % 64 != 0) kc = 32;
-  static const int dma_mode = getenv("PASCO_CONVH_DMA") ? atoi(getenv("PASCO_CONVH_DMA")) : 0;
-  if (pre && dma_mode == 2) kc = 32;             // experiment: every layer on the 32-channel DMA kernel
   const char *env = getenv("PASCO_CONVH_CFG");   // tuning override: "bm,kc"
   if (env) {
     int em = 0, ek = 0;
     if (sscanf(env, "%d,%d", &em, &ek) >= 1) {
-      if (em == 128 || (em == 64 && bn >= 64) || (em == 32 && bn == 128) || (em == 256 && bn >= 64 && pre && dma_mode)) bm = em;
+      if (em == 128 || (em == 64 && bn >= 64) || (em == 32 && bn == 128)) bm = em;
       if (ek == 32 || (ek == 64 && (!pre || a.cpad % 64 == 0))) kc = ek;
     }
   }
@@ -1046,10 +835,6 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   if (bm == BM_) {                                                                                        \
     if (pre) return kc == 64 ? launch_h2<BM_, 64, WM_, WN_, TM_, TN_>(a, st) : launch_h2<BM_, 32, WM_, WN_, TM_, TN_>(a, st); \
     return kc == 64 ? launch_h<BM_, 64, WM_, WN_, TM_, TN_>(a, st) : launch_h<BM_, 32, WM_, WN_, TM_, TN_>(a, st);            \
-  }
-  if (pre && bm == 256 && kc == 32) {          // experiment: 256-row tiles on the DMA kernel
-    if (bn == 64) return launch_h2d<256, 4, 1, 2, 2>(a, st);
-    if (bn == 128) return launch_h2d<256, 2, 2, 4, 2>(a, st);
   }
   if (bn == 32) {
     PH_H_CASE(128, 4, 1, 1, 1);
