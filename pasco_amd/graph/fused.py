@@ -1,6 +1,13 @@
-"""Fused launch helpers: eval-mode BatchNorm folded to per-channel (scale, shift) and handed to the
-conv kernel as gather prologue / store epilogue, so the sparse blocks of PaSCo need no separate
-elementwise passes."""
+"""Fused launch helpers around `ph_conv_fwd`.
+
+* eval-mode BatchNorm folded to per-channel (scale, shift) and handed to the conv kernel as gather prologue /
+  store epilogue, so the sparse blocks of PaSCo need no separate elementwise passes (SURVEY.md 8(a) a6,
+  section 9 items 6-7);
+* the split-precision operand plumbing (include/pasco_hip.h, mma_mode 2): weights split once per module,
+  activations split once per tensor (`split_input`) or written in operand form by the launch that produces them
+  (`conv(..., emit_next=...)`, `SplitRows` for tensors that exist only in that form);
+* tall linear layers (`linear_rows`, `linear_bn_act`, `batched_rows_matmul`) as identity-map convolutions on the
+  same kernel."""
 from __future__ import annotations
 
 from typing import Optional, Tuple

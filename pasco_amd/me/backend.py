@@ -238,7 +238,13 @@ class CBackend:
                  epi2_scale=None, epi2_shift=None, split=None, in_split: Optional[torch.Tensor] = None,
                  emit_split=None, want_out: bool = True,
                  out: Optional[torch.Tensor] = None):
-        """... `emit_split` = (scale | None, shift | None, act) (mode 2, cout % 32 == 0): also write the split operand
+        """out = epilogue(sum_k gather(prologue(x))[k] @ W[k]) - one `ph_conv_fwd` launch (include/pasco_hip.h).
+
+        `split` selects the split-precision products: (w_hi, w_lo, unscale) from `split_weight_f16` = mode 1
+        (activations split inside the kernel), (w_split, unscale) from `split_weight_rows` = mode 2 (both operands
+        pre-split; `in_split` = `split_rows(x, prologue)` or computed here).  In mode 2 `x` / `weight` may be None
+        (`xshape` = (n_in, cin) / `wshape` = (kvol, cin, cout)) when only the operands exist.
+        `emit_split` = (scale | None, shift | None, act) (mode 2, cout % 32 == 0): also write the split operand
         of act(out * scale + shift) for the next convolution and return (out, out_split); `want_out=False` then
         skips the fp32 result (returns (None, out_split))."""
         if x is None:          # rows that exist only as a pre-split operand (mode 2): `xshape` = (n_in, cin)
