@@ -178,19 +178,31 @@ def linear_bn_act(x2d: Optional[torch.Tensor], lin: nn.Linear, *, pro_bn=None, e
     return out if do_emit else (out, None)
 
 
-def batched_rows_matmul(x: Optional[torch.Tensor], w: torch.Tensor, x_split: torch.Tensor, shape=None) -> torch.Tensor:
-    """out[b] = x[b] @ w[b].T for tall x [B, P, D] and per-batch w [B, Q, D] that change every call (the mask
-    logits of the query heads), on the split-precision kernel with `x_split` = split_rows(x) prepared once.
-    The power-of-two weight scale is chosen on the device (no host read) and undone by the epilogue scale."""
+def prepare_batched_weights(w: torch.Tensor):
+    """Operand form of per-batch weights w [B, Q, D] that change every call (the mask-embedding of the query
+    heads): (w_split [B*Q, D/32, 2, 32], unscale [Q]).  The power-of-two scale is chosen on the device (no host
+    read) and undone by the epilogue scale; launch-only, so it can sit inside a captured graph."""
+    from ..me.backend import backend_for
+    be = backend_for(w.device)
+    B, Q, D = w.shape
+    w = w.detach()
+    e = 13 - torch.frexp(w.abs().amax())[1]                        # device int: largest magnitude just below 2^14
+    w_split = be.split_rows(torch.ldexp(w, e).reshape(B * Q, D).contiguous())
+    unscale = torch.ldexp(torch.ones(Q, device=w.device), -e).contiguous()
+    return w_split, unscale
+
+
+def batched_rows_matmul(x: Optional[torch.Tensor], w: Optional[torch.Tensor], x_split: torch.Tensor, shape=None,
+                        prepared=None) -> torch.Tensor:
+    """out[b] = x[b] @ w[b].T for tall x [B, P, D] and per-batch w [B, Q, D] (the mask logits of the query heads),
+    on the split-precision kernel with `x_split` = split_rows(x) prepared once.  `prepared` =
+    prepare_batched_weights(w) when the caller already has it."""
     from ..me.backend import backend_for
     dev = x_split.device
     be = backend_for(dev)
     B, P, D = x.shape if x is not None else shape     # x itself is not read (only its operand split)
-    Q = w.shape[1]
-    w = w.detach()
-    e = 13 - torch.frexp(w.abs().amax())[1]                        # device int: largest magnitude just below 2^14
-    w_split = be.split_rows(torch.ldexp(w, e).reshape(B * Q, D).contiguous())
-    unscale = torch.ldexp(torch.ones(Q, device=dev), -e).contiguous()
+    w_split, unscale = prepared if prepared is not None else prepare_batched_weights(w)
+    Q = unscale.numel()
     out = torch.empty((B, P, Q), dtype=torch.float32, device=dev)
     xs = x_split.reshape(B, P, -1)
     ws = w_split.reshape(B, Q, -1)
@@ -298,4 +310,4 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     return y
 
 
-__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "linear_rows", "split_rows_2d", "batched_rows_matmul", "linear_bn_act", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]
+__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "linear_rows", "split_rows_2d", "batched_rows_matmul", "prepare_batched_weights", "linear_bn_act", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]

@@ -17,6 +17,7 @@ keep-mask stays sparse and level voxels look their parent block up in its hash m
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -26,7 +27,7 @@ import torch.nn.functional as F
 from .. import me as ME
 from ..me.backend import backend_for
 from . import fused as fused_mod
-from .fused import batched_rows_matmul, linear_rows, split_rows_2d
+from .fused import batched_rows_matmul, linear_rows, prepare_batched_weights, split_rows_2d
 
 
 def sine_position_encoding(coords: torch.Tensor, num_pos_feats: int, temperature: float = 10000.0,
@@ -205,15 +206,72 @@ class TransformerPredictorV2(nn.Module):
         self.mask_feat_proj = nn.Linear(mask_dim, hidden_dim)
 
     # -- heads --------------------------------------------------------------------------------------
-    def pred_heads(self, output, mask_features, mask_features_split=None, shape=None):
+    def heads_query_side(self, output, want_operand: bool):
+        """The part of `pred_heads` that only touches the [B, Q, D] queries: class logits, mask embedding and -
+        for the split kernel - the mask embedding in operand form."""
         d = self.decoder_norm(output)
         outputs_class = self.class_embed(d)
         mask_embed = self.mask_embed(d)                                   # [B,Q,D]
+        prepared = prepare_batched_weights(mask_embed) if want_operand else None
+        return outputs_class, mask_embed, prepared
+
+    def pred_heads(self, output, mask_features, mask_features_split=None, shape=None, query_side=None):
+        outputs_class, mask_embed, prepared = query_side if query_side is not None else \
+            self.heads_query_side(output, mask_features_split is not None)
         if mask_features_split is not None:
-            outputs_mask = batched_rows_matmul(mask_features, mask_embed, mask_features_split, shape=shape)
+            outputs_mask = batched_rows_matmul(mask_features, mask_embed, mask_features_split, shape=shape,
+                                               prepared=prepared)
         else:
             outputs_mask = torch.matmul(mask_features, mask_embed.transpose(1, 2))   # [B,P,Q]
         return outputs_class, outputs_mask
+
+    # -- fixed-shape query-side ops as one replayed graph -------------------------------------------------------
+    def _query_step(self, layer: int, output, query_embed, want_operand: bool):
+        """self-attention + FFN of decoder layer `layer` (layer < 0: none) followed by the query side of the heads.
+        Everything here has the static shape [B, Q, D] and launches ~40 tiny kernels: on the GPU it is captured
+        once per (layer, shape) into a hipGraph and replayed (`PASCO_QUERY_GRAPH=0` or any capture failure ->
+        eager)."""
+        if layer >= 0:
+            output = self.transformer_self_attention_layers[layer](output, query_pos=query_embed)
+            output = self.transformer_ffn_layers[layer](output)
+        return (output,) + tuple(self.heads_query_side(output, want_operand))
+
+    def query_step(self, layer: int, output, query_embed, want_operand: bool):
+        if not output.is_cuda or self.training or os.environ.get("PASCO_QUERY_GRAPH", "1") == "0" or \
+                self.__dict__.get("_qgraph_broken", False):
+            return self._query_step(layer, output, query_embed, want_operand)
+        graphs = self.__dict__.setdefault("_qgraphs", {})
+        vers = tuple(p._version for p in self.parameters())
+        key = (layer, tuple(output.shape), output.device, want_operand, query_embed.data_ptr())
+        hit = graphs.get(key)
+        if hit is None or hit["vers"] != vers:
+            try:
+                hit = self._capture_query_step(layer, output, query_embed, want_operand)
+                hit["vers"] = vers
+                graphs[key] = hit
+            except Exception as exc:       # capture is an optimisation: never let it take the step down
+                self.__dict__["_qgraph_broken"] = True
+                import warnings
+                warnings.warn(f"pasco_amd: query-side graph capture failed ({type(exc).__name__}: {exc}); running eagerly")
+                return self._query_step(layer, output, query_embed, want_operand)
+        hit["x"].copy_(output)
+        hit["graph"].replay()
+        out, oc, me, prepared = hit["outs"]
+        # the class logits are kept by the caller across replays -> private copy; the rest is consumed before the next replay
+        return out, oc.clone(), me, prepared
+
+    def _capture_query_step(self, layer, output, query_embed, want_operand):
+        x = output.detach().clone()
+        side = torch.cuda.Stream(device=output.device)
+        side.wait_stream(torch.cuda.current_stream(output.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):             # warm-up outside the capture: library handles, workspaces, autotuning
+                self._query_step(layer, x, query_embed, want_operand)
+        torch.cuda.current_stream(output.device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(g):
+            outs = self._query_step(layer, x, query_embed, want_operand)
+        return {"graph": g, "x": x, "outs": outs}
 
     # -- attention mask -----------------------------------------------------------------------------
     def compute_mask_bits(self, outputs_mask, voxel_coord, src_C, src_scale, min_Cs, max_Cs, cache=None):
@@ -310,7 +368,8 @@ class TransformerPredictorV2(nn.Module):
         vf_shape = (B, P, D)
         predictions_class, predictions_mask = [], []
         mask_cache = {}
-        oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape)
+        output, *qs = self.query_step(-1, output.contiguous(), query_embed, vf_split is not None)
+        oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape, query_side=qs)
         predictions_class.append(oc)
         predictions_mask.append(om)
         for i in range(self.num_layers):
@@ -339,9 +398,8 @@ class TransformerPredictorV2(nn.Module):
                 attn_mask = attn_mask & ~attn_mask.all(dim=-1, keepdim=True)   # all-masked -> unmasked
                 output = self.transformer_cross_attention_layers[i](output, src_F, attn_mask=attn_mask,
                                                                     pos=None, query_pos=query_embed)
-            output = self.transformer_self_attention_layers[i](output, query_pos=query_embed)
-            output = self.transformer_ffn_layers[i](output)
-            oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape)
+            output, *qs = self.query_step(i, output.contiguous(), query_embed, vf_split is not None)
+            oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape, query_side=qs)
             predictions_class.append(oc)
             predictions_mask.append(om)
         panop_predictions = []
