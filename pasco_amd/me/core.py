@@ -180,10 +180,17 @@ class CoordinateManager:
         """-> (out_key, keep_rows int32)."""
         m = self._maps[in_key]
         assert mask.shape[0] == m.n, f"mask has {mask.shape[0]} rows, map has {m.n}"
+        # pruning several tensors of one map with the SAME mask tensor (features and their logits) is one map
+        # event: the second call reuses the first one's rows and key (the mask tensor is kept alive by the entry)
+        last = self.__dict__.get("_last_prune")
+        if last is not None and last[0] == in_key and last[1] is mask and last[2] == mask._version:
+            return last[3], last[4]
         be = self.backend()
         keep = be.mask_compact(mask.contiguous())
         coords = be.gather_rows(m.coords, keep)
-        return self.insert_unique(coords, in_key.tensor_stride), keep
+        out_key = self.insert_unique(coords, in_key.tensor_stride)
+        self.__dict__["_last_prune"] = (in_key, mask, mask._version, out_key, keep)
+        return out_key, keep
 
     def union(self, key_a: CoordinateMapKey, key_b: CoordinateMapKey):
         """-> (out_key, rows_a2out, rows_b2out): lhs rows first, then unseen rhs rows."""

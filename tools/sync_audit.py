@@ -20,11 +20,18 @@ with torch.no_grad():
     def hook(message, category, filename, lineno, file=None, line=None):
         if "synchroniz" not in str(message):
             return
-        for fr in reversed(traceback.extract_stack()[:-1]):
-            if fr.filename.startswith(root) and "sync_audit" not in fr.filename:
-                counts[f"{os.path.relpath(fr.filename, root)}:{fr.lineno} {fr.line.strip()[:90]}"] += 1
-                return
-        counts["<outside repo>"] += 1
+        frames = [fr for fr in reversed(traceback.extract_stack()[:-1])
+                  if fr.filename.startswith(root) and "sync_audit" not in fr.filename]
+        if not frames:
+            counts["<outside repo>"] += 1
+            return
+        # innermost repo frame, plus (for the generic backend / coordinate-map helpers) the first caller outside them
+        label = f"{os.path.relpath(frames[0].filename, root)}:{frames[0].lineno}"
+        for fr in frames[1:]:
+            if "/me/" not in fr.filename:
+                label += f"  <- {os.path.relpath(fr.filename, root)}:{fr.lineno} {fr.line.strip()[:70]}"
+                break
+        counts[label] += 1
 
     warnings.showwarning = hook
     warnings.simplefilter("always")
