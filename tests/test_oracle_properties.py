@@ -93,3 +93,25 @@ def test_oracle_split_rows_matches_numpy_float16(oracle):
     rec = hi.astype(np.float64) + lo.astype(np.float64)
     err = np.abs(rec - x.astype(np.float64))
     assert np.all(err <= np.maximum(np.abs(x) * 2.0 ** -21, 2.0 ** -25))
+
+
+def test_prune_same_mask_is_one_map_event(oracle_registered):
+    """Two prunes of one map with the SAME mask tensor share rows and key; a changed mask (new tensor or in-place
+    edit) is a new event."""
+    import pasco_amd.me as ME
+    g = torch.Generator().manual_seed(3)
+    c = torch.unique(torch.randint(0, 12, (300, 4), generator=g, dtype=torch.int32), dim=0)
+    c[:, 0] = 0
+    c = torch.unique(c, dim=0).contiguous()
+    x = ME.SparseTensor(torch.randn(c.shape[0], 5, generator=g), c)
+    y = ME.SparseTensor(torch.randn(c.shape[0], 3, generator=g), coordinate_map_key=x.coordinate_map_key,
+                        coordinate_manager=x.coordinate_manager)
+    keep = torch.rand(c.shape[0], generator=g) > 0.4
+    prune = ME.MinkowskiPruning()
+    px, py = prune(x, keep), prune(y, keep)
+    assert px.coordinate_map_key == py.coordinate_map_key
+    assert torch.equal(px.C, c[keep]) and torch.equal(px.F, x.F[keep]) and torch.equal(py.F, y.F[keep])
+    keep[0] = not bool(keep[0])                                   # in-place edit: version changes
+    pz = prune(x, keep)
+    assert torch.equal(pz.C, c[keep]) and torch.equal(pz.F, x.F[keep])
+    assert pz.coordinate_map_key != px.coordinate_map_key
