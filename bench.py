@@ -239,7 +239,7 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
         res = {
-            "metric": "scenes/sec (256x256x32, ~10% occ) PaSCo MIMO-3",
+            "metric": f"scenes/sec (256x256x32, ~10% occ) PaSCo MIMO-{args.n_infers}",
             "value": round(value, 4), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
