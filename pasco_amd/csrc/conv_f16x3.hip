@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
   constexpr int SPR = KC / 4;                 // 16-byte slots per tile row (hi + lo)
   constexpr int RPP = HV_THREADS / SPR;       // tile rows filled per pass
   constexpr int A_PASSES = BM / RPP;
-  constexpr int B_PASSES = (BN + RPP - 1) / RPP;
+  constexpr int B_PASSES = BN / RPP;
   static_assert(WM * WN == 4 && WM * TM * 32 == BM, "tile shape");
   static_assert(BM % RPP == 0, "loader shape");
 
@@ -384,12 +384,15 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
 
   f16x8 ra[A_PASSES], rb[B_PASSES];
   int idx_cur[A_PASSES], idx_nxt[A_PASSES];
-  // weight rows of this thread: (n0 + l_r + q * RPP); -1 when outside cout
+  // weight rows of this thread: n0 + l_r + q * RPP, clamped to the last output channel - columns >= cout of the
+  // tile are never stored, so they may multiply any finite row and the loads need no predicate
+  static_assert(BN % RPP == 0, "weight loader shape");
   int64_t boff[B_PASSES];
 #pragma unroll
   for (int q = 0; q < B_PASSES; ++q) {
-    const int n = l_r + q * RPP;
-    boff[q] = (n < BN && n0 + n < cout) ? (int64_t)(n0 + n) * rs + l_j * 8 : -1;
+    int n = n0 + l_r + q * RPP;
+    n = n < cout ? n : cout - 1;
+    boff[q] = (int64_t)n * rs + l_j * 8;
   }
 
   auto load_idx = [&](int k, int *dst) {
@@ -413,11 +416,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
     }
     const _Float16 *wk = a.w_split + (int64_t)k * cout * rs + chunk * (2 * KC);
 #pragma unroll
-    for (int q = 0; q < B_PASSES; ++q) {
-      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (boff[q] >= 0) v = *reinterpret_cast<const f16x8 *>(wk + boff[q]);
-      rb[q] = v;
-    }
+    for (int q = 0; q < B_PASSES; ++q) rb[q] = *reinterpret_cast<const f16x8 *>(wk + boff[q]);
   };
 
   auto store_stage = [&]() {
@@ -425,10 +424,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
     for (int p = 0; p < A_PASSES; ++p)
       *reinterpret_cast<f16x8 *>(&As[(l_r + p * RPP) * LD + l_j * 8]) = ra[p];
 #pragma unroll
-    for (int q = 0; q < B_PASSES; ++q) {
-      const int n = l_r + q * RPP;
-      if (n < BN) *reinterpret_cast<f16x8 *>(&Bs[n * LD + l_j * 8]) = rb[q];
-    }
+    for (int q = 0; q < B_PASSES; ++q) *reinterpret_cast<f16x8 *>(&Bs[(l_r + q * RPP) * LD + l_j * 8]) = rb[q];
   };
 
   auto compute_stage = [&]() {
