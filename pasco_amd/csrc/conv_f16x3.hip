@@ -329,6 +329,8 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
 // time in VALU converting every row up to 27 times, profiles/README.md "SQ counters, split kernel").
 // A row of a tile = KC/32 groups of [32 hi | 32 lo] f16 (+8 pad): LD = 2*KC + 8.
 // ------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(128))) const uint32_t ph_zero_line[64] = {0};   // 256 zero bytes for absent neighbours
+
 // EMIT = the launch also writes the next convolution's operand (out_split).  A separate instantiation: the
 // emission code raises the kernel's register budget (one wave of occupancy less), which launches that do not
 // emit should not pay for.
@@ -384,6 +386,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
 
   f16x8 ra[A_PASSES], rb[B_PASSES];
   int idx_cur[A_PASSES], idx_nxt[A_PASSES];
+  const _Float16 *zero_row = reinterpret_cast<const _Float16 *>(ph_zero_line);
   // weight rows of this thread: n0 + l_r + q * RPP, clamped to the last output channel - columns >= cout of the
   // tile are never stored, so they may multiply any finite row and the loads need no predicate
   static_assert(BN % RPP == 0, "weight loader shape");
@@ -409,10 +412,10 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
     const int coff = chunk * (2 * KC) + l_j * 8;
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
+      // rows without a neighbour read a zero line instead of being predicated off (no exec juggling per load)
       const int idx = idx_cur[p];
-      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (idx >= 0) v = *reinterpret_cast<const f16x8 *>(a.in_split + (uint64_t)(uint32_t)idx * rs + coff);
-      ra[p] = v;
+      const _Float16 *src = idx >= 0 ? a.in_split + (uint64_t)(uint32_t)idx * rs + coff : zero_row + l_j * 8;
+      ra[p] = *reinterpret_cast<const f16x8 *>(src);
     }
     const _Float16 *wk = a.w_split + (int64_t)k * cout * rs + chunk * (2 * KC);
 #pragma unroll
