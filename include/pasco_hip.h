@@ -136,7 +136,11 @@ typedef struct ph_conv_desc {
   float epi_slope;        /* negative slope for PH_ACT_LEAKY (pro and epi) */
   const float *residual;  /* [n_out, cout] added after epi_act */
   int32_t res_act;        /* activation after the second affine / residual add */
-  int32_t reserved;
+  int32_t split_exp2;     /* modes 1 / 2: the activation operand stands for x * 2^split_exp2 (mode 1 scales the gathered
+                             rows before splitting them; mode 2: in_split was made with this exp2; out_split is emitted
+                             with it).  The caller folds 2^-split_exp2 into w_unscale.  Keeps the lo halves of small
+                             activations out of the f16 subnormal range: |x| * 2^split_exp2 in [2^-3, 65504] has the full
+                             22-bit operand; the range flag fires above 65504 * 2^-split_exp2 */
   const float *epi2_scale; /* [cout] second per-channel affine, applied after epi_act */
   const float *epi2_shift; /* [cout] */
   /* matrix-core mode: 0 = fp32 MFMA (exact fp32, default); 1 = opt-in split precision: the product is
@@ -153,14 +157,14 @@ typedef struct ph_conv_desc {
   int32_t *status;        /* optional device word; mode 1 ORs bit 0 into it when a gathered activation
                              exceeds the f16 range (|x| > 65504) - the caller must then redo the layer in mode 0 */
   /* mode 2 = mode 1 with BOTH operands pre-split by ph_split_rows (the gather becomes a 16-byte copy: no
-   * per-gather conversion).  in_split = ph_split_rows(in [n_in, cin], pro_*) - the prologue is applied there
+   * per-gather conversion).  in_split = ph_split_rows(in [n_in, cin], pro_*, split_exp2) - the prologue is applied there
    * and NOT again by the device; w_split = ph_split_rows of the [kvol*cout, cin] rows of (weight * 2^e)
    * transposed to [kvol, cout, cin]; w_unscale = 2^-e.  `in` / `weight` / w_f16_* are not read by the device
    * library in mode 2 (the checker build reads in / weight / pro_*).  The range flag is raised by ph_split_rows. */
   const void *in_split;
   const void *w_split;
   /* mode 2, optional second output (cout % 32 == 0): out_split = ph_split_rows(out, osp_scale, osp_shift,
-   * osp_act, epi_slope) - the operand of the NEXT convolution, with that convolution's prologue already applied -
+   * osp_act, epi_slope, split_exp2) - the operand of the NEXT convolution, with that convolution's prologue already applied -
    * written by the same launch.  With out_split given, `out` may be NULL (fp32 result not needed). */
   void *out_split;
   const float *osp_scale; /* [cout] */
@@ -171,12 +175,20 @@ typedef struct ph_conv_desc {
 
 int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);
 
-/* Operand preparation for mma_mode 2.  x = act(in * pro_scale + pro_shift) (any of them NULL / PH_ACT_NONE),
- * hi = f16(x) (round to nearest even), lo = f16(x - hi); out_split is f16 [n][cpad/32][2][32] with
- * cpad = c rounded up to 32: group g holds channels 32g..32g+31 as 32 hi values then 32 lo values; channels
- * >= c are zero.  c % 8 == 0.  ORs bit 0 into *status (optional) when some |x| > 65504 or is NaN. */
+/* Diagnostics for the parity tests: which kernel instantiation the LAST conv_fwd of the calling thread launched.
+ * h_out8 (HOST array of 8 ints) = { mma_mode, tile rows, tile channels, input channels per stage, splits over the
+ * kernel offsets, 1 if the launch wrote out_split, kernel id (0 k_conv_mfma, 1 k_conv_f16x3, 2 k_conv_h2,
+ * 3 k_conv_rl = row-list k = 2 kernel), waves per workgroup }; all -1 / 0 before the first launch.  The checker build reports
+ * kernel id -1.  (No upstream counterpart: ME picks its kernel inside ConvolutionForwardKernelGPU.) */
+int PH_FN(conv_last_config)(int32_t *h_out8);
+
+/* Operand preparation for mma_mode 2.  x = act(in * pro_scale + pro_shift) * 2^exp2 (any of them NULL /
+ * PH_ACT_NONE; the power of two is exact), hi = f16(x) (round to nearest even), lo = f16(x - hi); out_split is
+ * f16 [n][cpad/32][2][32] with cpad = c rounded up to 32: group g holds channels 32g..32g+31 as 32 hi values then
+ * 32 lo values; channels >= c are zero.  c % 8 == 0.  ORs bit 0 into *status (optional) when some |x| > 65504 or
+ * is NaN.  exp2: activations use the convolution's split_exp2, pre-scaled weights 0. */
 int PH_FN(split_rows)(const float *in, int64_t n, int32_t c, const float *pro_scale, const float *pro_shift,
-                      int32_t pro_act, float slope, void *out_split, int32_t *status, ph_stream_t stream);
+                      int32_t pro_act, float slope, int32_t exp2, void *out_split, int32_t *status, ph_stream_t stream);
 
 /* Local max pooling over a neighbour table (MinkowskiMaxPooling,
  * transformer_predictor_v2.py:100-102,234-236).  Rows without any neighbour give 0. */

@@ -50,6 +50,13 @@ static int fail(const char *fmt, ...) {
 }
 
 int pho_abi_version(void) { return PH_ABI_VERSION; }
+
+/* the restatement has one formulation per operator: nothing to report (kernel id -1) */
+int pho_conv_last_config(int32_t *h_out8) {
+  if (!h_out8) return 1;
+  for (int i = 0; i < 8; ++i) h_out8[i] = (i == 6) ? -1 : 0;
+  return 0;
+}
 const char *pho_last_error(void) { return g_err; }
 int64_t pho_workspace_bytes(int64_t n) { return 9 * (n < 0 ? 0 : n) + 4096; }
 
@@ -249,8 +256,9 @@ static float f16_bits_to_f32(uint16_t h) {
 }
 
 int pho_split_rows(const float *in, int64_t n, int32_t c, const float *pro_scale, const float *pro_shift,
-                   int32_t pro_act, float slope, void *out_split, int32_t *status, ph_stream_t stream) {
+                   int32_t pro_act, float slope, int32_t exp2, void *out_split, int32_t *status, ph_stream_t stream) {
   (void)stream;
+  const float pow2 = ldexpf(1.f, exp2);
   if (n < 0 || c <= 0 || c % 8 != 0) return fail("split_rows: needs c % 8 == 0");
   if (n == 0) return 0;
   if (!in || !out_split) return fail("split_rows: null buffer");
@@ -269,6 +277,7 @@ int pho_split_rows(const float *in, int64_t n, int32_t c, const float *pro_scale
           v = v * (pro_scale ? pro_scale[ch] : 1.f) + (pro_shift ? pro_shift[ch] : 0.f);
           v = act_apply(v, pro_act, slope);
         }
+        v *= pow2;
         if (!(fabsf(v) <= 65504.f)) bad = 1;
         hi = f32_to_f16_bits(v);
         lo = f32_to_f16_bits(v - f16_bits_to_f32(hi));
@@ -314,7 +323,7 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   const float *in = d->in, *weight = d->weight;
   int has_pro = d->pro_scale || d->pro_shift || d->pro_act != PH_ACT_NONE;
   if (d->mma_mode == 2 && d->in_split) {
-    in = in_tmp = unsplit_rows(d->in_split, d->n_in, cin, 1.f);
+    in = in_tmp = unsplit_rows(d->in_split, d->n_in, cin, 1.f);   /* = x * 2^split_exp2; w_unscale undoes it */
     has_pro = 0;
   }
   if (!in) return fail("conv_fwd: null input");
@@ -390,7 +399,7 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   if (d->out_split) {   /* second output of mma_mode 2: the next convolution's operand */
     if (d->cout % 32 != 0) rc = fail("conv_fwd: out_split needs cout % 32 == 0");
     else rc = pho_split_rows(outp, d->n_out, d->cout, d->osp_scale, d->osp_shift, d->osp_act, d->epi_slope,
-                             d->out_split, d->status, stream);
+                             d->split_exp2, d->out_split, d->status, stream);
   }
   free(in_tmp);
   free(w_tmp);

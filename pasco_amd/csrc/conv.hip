@@ -42,11 +42,19 @@ struct ConvArgs {
   int n_row_tiles, n_col_tiles;
 };
 
-// activations are evaluated branch-free as max(v,0) + neg*min(v,0): neg = 1 (none), 0 (ReLU), slope (leaky)
+// activations: neg = 1 (none), 0 (ReLU), slope (leaky); NaN-preserving select (ph_common.h)
 __device__ __forceinline__ float act_neg_of(int act, float slope) {
   return act == PH_ACT_RELU ? 0.f : (act == PH_ACT_LEAKY ? slope : 1.f);
 }
-__device__ __forceinline__ float act_apply(float v, float neg) { return fmaxf(v, 0.f) + neg * fminf(v, 0.f); }
+__device__ __forceinline__ float act_apply(float v, float neg) { return ph_act(v, neg); }
+
+thread_local ph_conv_cfg_rec ph_last_cfg = {{-1, 0, 0, 0, 0, 0, -1, 0}};
+
+extern "C" int ph_conv_last_config(int32_t *h_out8) {
+  PH_REQUIRE(h_out8 != nullptr, "conv_last_config: null buffer");
+  for (int i = 0; i < 8; ++i) h_out8[i] = ph_last_cfg.v[i];
+  return 0;
+}
 
 // Tile = BM output rows x BN output channels, BKC input channels per LDS stage.
 // WM x WN waves (4 in total), each TM x TN MFMA tiles of 32x32:  BM = WM*TM*32, BN = WN*TN*32.
@@ -312,6 +320,7 @@ static int launch_conv(const ConvArgs &a, hipStream_t st) {
   else
     hipLaunchKernelGGL((k_conv_mfma<BM, BKC, WM, WN, TM, TN, false, false>), dim3(grid), dim3(CV_THREADS), 0, st, args);
   PH_LAUNCH_CHECK();
+  ph_record_cfg(0, BM, BN, BKC, 1, 0, 0, 4);
   return 0;
 }
 
@@ -326,7 +335,7 @@ static int pick_cfg(const ConvArgs &a, int *bm) {
   const int64_t ncol = (a.cout + bn - 1) / bn;
   int m = bn == 32 ? 128 : 64;
   if (bn == 128 && ((a.n_out + 63) / 64) * ncol < 2 * 256) m = 32;
-  const char *env = getenv("PASCO_CONV_CFG");
+  static const char *env = getenv("PASCO_CONV_CFG");   // tuning override, read once
   if (env) {
     const int em = atoi(env);
     if (em == 128 || (em == 64 && bn >= 64) || (em == 32 && bn == 128)) m = em;

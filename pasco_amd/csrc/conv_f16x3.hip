@@ -25,7 +25,9 @@ constexpr int HV_THREADS = 256;
 // KC input channels per stage (32 or 64); LDS rows hold KC + 8 f16 (80 / 144 bytes: 16-byte aligned and
 // conflict-free for the b128 fragment reads)
 
-__device__ __forceinline__ float h_act(float v, float neg) { return fmaxf(v, 0.f) + neg * fminf(v, 0.f); }
+__device__ __forceinline__ float h_act(float v, float neg) { return ph_act(v, neg); }
+// range flag of a value about to become an f16 operand: true for |t| > 65504 AND for NaN
+__device__ __forceinline__ bool h_out_of_range(float t) { return !(fabsf(t) <= 65504.f); }
 
 struct ConvArgsH {
   const float *in;
@@ -51,13 +53,14 @@ struct ConvArgsH {
   const float *osp_scale, *osp_shift;
   float osp_neg;
   int osp_has;
+  float act_pow2;             // 2^split_exp2: scale of the activation operand (mode 1 gather, emitted out_split)
 };
 
 // hi / lo halves of four values -> the [hi x32 | lo x32] group layout (dst points at the run's hi slot)
-__device__ __forceinline__ float emit_split4(const float v[4], const float *sc, const float *sh, int has, float neg,
-                                             _Float16 *dst) {
+__device__ __forceinline__ bool emit_split4(const float v[4], const float *sc, const float *sh, int has, float neg,
+                                            float pow2, _Float16 *dst) {
   f16x4 hi, lo;
-  float xmax = 0.f;
+  bool bad = false;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float t = v[q];
@@ -66,14 +69,15 @@ __device__ __forceinline__ float emit_split4(const float v[4], const float *sc, 
       const float m = t * (sc ? sc[q] : 1.f);
       t = h_act(m + (sh ? sh[q] : 0.f), neg);
     }
-    xmax = fmaxf(xmax, fabsf(t));
+    t *= pow2;
+    bad |= h_out_of_range(t);
     const _Float16 th = (_Float16)t;
     hi[q] = th;
     lo[q] = (_Float16)(t - (float)th);
   }
   *reinterpret_cast<f16x4 *>(dst) = hi;
   *reinterpret_cast<f16x4 *>(dst + 32) = lo;
-  return xmax;
+  return bad;
 }
 
 
@@ -133,7 +137,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
 
   float4 ra[A_PASSES];
   f16x8 rbh[B_SLOTS], rbl[B_SLOTS];
-  float xmax = 0.f;   // largest |activation| this thread converted to f16
+  bool xbad = false;  // this thread converted an activation outside the f16 range (or a NaN)
   int idx_cur[A_PASSES], idx_nxt[A_PASSES];
   int cur_c0 = 0;
 
@@ -196,7 +200,8 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
         float x = v[j];
         if (a.has_pro) x = h_act(x * ps[j] + pb[j], a.pro_neg);
         if (!ok || cbase + j >= cin) x = 0.f;
-        xmax = fmaxf(xmax, fabsf(x));
+        x *= a.act_pow2;
+        xbad |= h_out_of_range(x);
         const _Float16 xh = (_Float16)x;
         hi[j] = xh;
         lo[j] = (_Float16)(x - (float)xh);
@@ -275,7 +280,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
     __syncthreads();
   }
 
-  if (a.status != nullptr && !(xmax <= 65504.f)) atomicOr(a.status, 1);   // also catches NaN
+  if (a.status != nullptr && xbad) atomicOr(a.status, 1);
 
   if (a.ksplit > 1) {   // raw partial sums; k_splitk_epilogue reduces them in a fixed order
     float *part = a.partial + (int64_t)blockIdx.y * a.n_out * cout;
@@ -504,7 +509,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
     return;
   }
 
-  float omax = 0.f;
+  bool obad = false;
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -579,7 +584,8 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
                 const float mm = t * sc[q];
                 t = h_act(mm + sh[q], a.osp_neg);
               }
-              omax = fmaxf(omax, fabsf(t));
+              t *= a.act_pow2;
+              obad |= h_out_of_range(t);
               const _Float16 th = (_Float16)t;
               hi[q] = th;
               lo[q] = (_Float16)(t - (float)th);
@@ -592,13 +598,13 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
         }
       }
     }
-  if (EMIT && a.status != nullptr && !(omax <= 65504.f)) atomicOr(a.status, 1);
+  if (EMIT && a.status != nullptr && obad) atomicOr(a.status, 1);
 }
 
 // fp32 rows -> [hi x32 | lo x32] groups; one thread per 8 channels.  Channels >= c (pad to 32) are zero.
 __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ in, int64_t n, int c, int cpad,
                                                      const float *__restrict__ ps, const float *__restrict__ pb,
-                                                     int has_pro, float neg, _Float16 *__restrict__ out,
+                                                     int has_pro, float neg, float pow2, _Float16 *__restrict__ out,
                                                      int32_t *status) {
   const int segs = cpad >> 3;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -610,7 +616,7 @@ __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ in
     const float4 v0 = *reinterpret_cast<const float4 *>(in + row * c + c0);
     const float4 v1 = *reinterpret_cast<const float4 *>(in + row * c + c0 + 4);
     float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    float xmax = 0.f;
+    bool bad = false;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = x[j];
@@ -619,12 +625,13 @@ __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ in
         const float m = v * (ps ? ps[c0 + j] : 1.f);
         v = h_act(m + (pb ? pb[c0 + j] : 0.f), neg);
       }
-      xmax = fmaxf(xmax, fabsf(v));
+      v *= pow2;
+      bad |= h_out_of_range(v);
       const _Float16 vh = (_Float16)v;
       hi[j] = vh;
       lo[j] = (_Float16)(v - (float)vh);
     }
-    if (status != nullptr && !(xmax <= 65504.f)) atomicOr(status, 1);   // also catches NaN
+    if (status != nullptr && bad) atomicOr(status, 1);   // |v| > 65504 or NaN
   }
   _Float16 *dst = out + (row * (cpad >> 5) + (c0 >> 5)) * 64 + (c0 & 31);
   *reinterpret_cast<f16x8 *>(dst) = hi;
@@ -632,8 +639,10 @@ __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ in
 }
 
 extern "C" int ph_split_rows(const float *in, int64_t n, int32_t c, const float *pro_scale, const float *pro_shift,
-                             int32_t pro_act, float slope, void *out_split, int32_t *status, ph_stream_t stream) {
+                             int32_t pro_act, float slope, int32_t exp2, void *out_split, int32_t *status,
+                             ph_stream_t stream) {
   PH_REQUIRE(n >= 0 && c > 0 && c % 8 == 0, "split_rows: needs c %% 8 == 0 (c=%d)", c);
+  PH_REQUIRE(exp2 >= -16 && exp2 <= 16, "split_rows: exp2 out of range (%d)", exp2);
   if (n == 0) return 0;
   PH_REQUIRE(in && out_split, "split_rows: null buffer");
   PH_REQUIRE((((uintptr_t)in | (uintptr_t)out_split) & 15) == 0, "split_rows: 16-byte alignment");
@@ -642,7 +651,7 @@ extern "C" int ph_split_rows(const float *in, int64_t n, int32_t c, const float 
   const float neg = pro_act == PH_ACT_RELU ? 0.f : (pro_act == PH_ACT_LEAKY ? slope : 1.f);
   const int has_pro = (pro_scale || pro_shift || pro_act != PH_ACT_NONE) ? 1 : 0;
   hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ph_stream(stream), in, n, c, cpad,
-                     pro_scale, pro_shift, has_pro, neg, (_Float16 *)out_split, status);
+                     pro_scale, pro_shift, has_pro, neg, ldexpf(1.f, exp2), (_Float16 *)out_split, status);
   PH_LAUNCH_CHECK();
   return 0;
 }
@@ -683,9 +692,9 @@ __global__ void __launch_bounds__(256) k_splitk_epilogue(ConvArgsH a) {
       sc[q] = a.osp_scale ? a.osp_scale[col + q] : 1.f;
       sh[q] = a.osp_shift ? a.osp_shift[col + q] : 0.f;
     }
-    const float omax = emit_split4(v, sc, sh, a.osp_has, a.osp_neg,
-                                   a.out_split + (row * (a.cout >> 5) + (col >> 5)) * 64 + (col & 31));
-    if (a.status != nullptr && !(omax <= 65504.f)) atomicOr(a.status, 1);
+    const bool obad = emit_split4(v, sc, sh, a.osp_has, a.osp_neg, a.act_pow2,
+                                  a.out_split + (row * (a.cout >> 5) + (col >> 5)) * 64 + (col & 31));
+    if (a.status != nullptr && obad) atomicOr(a.status, 1);
   }
 }
 
@@ -704,6 +713,7 @@ static int launch_h(const ConvArgsH &a, hipStream_t st) {
     hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, args);
     PH_LAUNCH_CHECK();
   }
+  ph_record_cfg(1, BM, BN, KC, args.ksplit, 0, 1, 4);
   return 0;
 }
 
@@ -725,7 +735,32 @@ static int launch_h2(const ConvArgsH &a, hipStream_t st) {
     hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, args);
     PH_LAUNCH_CHECK();
   }
+  ph_record_cfg(2, BM, BN, KC, args.ksplit, (args.out_split != nullptr && args.ksplit == 1) ? 1 : 0, 2, 4);
   return 0;
+}
+
+// Tuning overrides (development only), read ONCE when the library first launches a split convolution:
+//   PASCO_CONVH_MID=0      disable the 64-row / 64-channel-stage choice for thin 128-channel layers
+//   PASCO_CONVH_CFG=bm,kc  force tile height / stage depth where the shape allows it
+//   PASCO_CONVH_KSPLIT=n   force the split over the kernel offsets
+struct ConvHKnobs {
+  bool mid_on = true;
+  bool has_cfg = false;
+  int cfg_bm = 0, cfg_kc = 0;
+  bool has_ksplit = false;
+  int ksplit = 0;
+  ConvHKnobs() {
+    if (const char *e = getenv("PASCO_CONVH_MID")) mid_on = atoi(e) != 0;
+    if (const char *e = getenv("PASCO_CONVH_CFG")) has_cfg = sscanf(e, "%d,%d", &cfg_bm, &cfg_kc) >= 1;
+    if (const char *e = getenv("PASCO_CONVH_KSPLIT")) {
+      has_ksplit = true;
+      ksplit = atoi(e);
+    }
+  }
+};
+static const ConvHKnobs &convh_knobs() {
+  static const ConvHKnobs k;
+  return k;
 }
 
 // called from ph_conv_fwd (conv.hip) when desc->mma_mode is 1 or 2
@@ -752,6 +787,8 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.osp_shift = d->osp_shift;
   a.osp_has = (d->osp_scale || d->osp_shift || d->osp_act != PH_ACT_NONE) ? 1 : 0;
   a.osp_neg = d->osp_act == PH_ACT_RELU ? 0.f : (d->osp_act == PH_ACT_LEAKY ? d->epi_slope : 1.f);
+  PH_REQUIRE(d->split_exp2 >= -16 && d->split_exp2 <= 16, "conv_fwd(f16x3): split_exp2 out of range (%d)", d->split_exp2);
+  a.act_pow2 = ldexpf(1.f, d->split_exp2);
   if (d->out_split) {
     PH_REQUIRE(pre, "conv_fwd(f16x3): out_split needs mma_mode 2");
     PH_REQUIRE(d->cout % 32 == 0 && (((uintptr_t)d->out_split) & 15) == 0, "conv_fwd(f16x3): out_split needs cout %% 32 == 0");
@@ -793,19 +830,17 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   int kc = (d->cin % 64 == 0 && d->cin >= 256) ? 64 : 32;   // deeper stages pay only for wide layers (profiles/r1f_op_bench.json)
   // 128-channel layers with fewer than ~1.5 waves of 128-row tiles (stride-2 levels of the pruned scene): 64-row
   // tiles with 64-channel stages measured 304 -> 250 us (profiles/README.md, r1k sweep); env PASCO_CONVH_MID=0 disables
-  static const bool mid_on = getenv("PASCO_CONVH_MID") ? atoi(getenv("PASCO_CONVH_MID")) != 0 : true;
-  if (pre && mid_on && bn == 128 && d->cin == 128 && d->kvol > 1 && ((d->n_out + 127) / 128) * ncol < 3 * 256) {
+  const ConvHKnobs &knobs = convh_knobs();
+  if (pre && knobs.mid_on && bn == 128 && d->cin == 128 && d->kvol > 1 && ((d->n_out + 127) / 128) * ncol < 3 * 256) {
     if (bm == 128) bm = 64;
     kc = 64;
   }
   if (pre && a.cpad % 64 != 0) kc = 32;
-  const char *env = getenv("PASCO_CONVH_CFG");   // tuning override: "bm,kc"
+  const bool env = knobs.has_cfg;
   if (env) {
-    int em = 0, ek = 0;
-    if (sscanf(env, "%d,%d", &em, &ek) >= 1) {
-      if (em == 128 || (em == 64 && bn >= 64) || (em == 32 && bn == 128)) bm = em;
-      if (ek == 32 || (ek == 64 && (!pre || a.cpad % 64 == 0))) kc = ek;
-    }
+    const int em = knobs.cfg_bm, ek = knobs.cfg_kc;
+    if (em == 128 || (em == 64 && bn >= 64) || (em == 32 && bn == 128)) bm = em;
+    if (ek == 32 || (ek == 64 && (!pre || a.cpad % 64 == 0))) kc = ek;
   }
   // Few-row layers (dense bottleneck: 245 offsets on 6.7 k rows; stride-4/8 layers): every workgroup streams
   // the whole W[k] slab sequence from L2, so small row tiles multiply the weight traffic.  Keep the tall
@@ -814,12 +849,12 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.ksplit = 1;
   a.partial = nullptr;
   {
-    const char *se = getenv("PASCO_CONVH_KSPLIT");
+    const bool se = knobs.has_ksplit;
     const int64_t t128 = ((d->n_out + 127) / 128) * ncol;
     int want = (int)(2048 / (t128 > 0 ? t128 : 1));
     if (want > 8) want = 8;
     if (want > d->kvol / 4) want = d->kvol / 4;
-    if (se) want = atoi(se);
+    if (se) want = knobs.ksplit;
     const bool room = d->splitk_ws != nullptr && d->splitk_ws_bytes >= (int64_t)want * d->n_out * d->cout * 4;
     if (bn == 128 && t128 < 2 * 256 && want >= 2 && room && !env) {
       bm = 128;

@@ -66,6 +66,24 @@ __device__ __forceinline__ int ph_find(const uint64_t *__restrict__ tkeys,
 
 static inline hipStream_t ph_stream(ph_stream_t s) { return (hipStream_t)s; }
 
+// ---- fused activations ---------------------------------------------------------------------------
+// neg = 1 (none), 0 (ReLU), slope (leaky).  Selects instead of max / min arithmetic: NaN stays NaN (the torch
+// graph of the reference propagates it; fmaxf(v, 0) + neg * fminf(v, 0) turns it into 0), -inf under ReLU is +0
+// (not 0 * inf), and every finite value gets exactly what the C restatement in oracle/ computes.
+__device__ __forceinline__ float ph_act(float v, float neg) {
+  const float n = neg * v;
+  return (v > 0.f || v != v) ? v : (neg == 0.f ? 0.f : n);
+}
+
+// ---- which convolution kernel the last ph_conv_fwd of this thread launched (ph_conv_last_config) --
+struct ph_conv_cfg_rec {
+  int32_t v[8];   // mma_mode, bm, bn, kc, ksplit, emit, kernel id (0 k_conv_mfma, 1 k_conv_f16x3, 2 k_conv_h2, ...), waves
+};
+extern thread_local ph_conv_cfg_rec ph_last_cfg;
+static inline void ph_record_cfg(int mode, int bm, int bn, int kc, int ksplit, int emit, int kid, int waves) {
+  ph_last_cfg = ph_conv_cfg_rec{{mode, bm, bn, kc, ksplit, emit, kid, waves}};
+}
+
 static inline int ph_is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // ---- stable compaction primitive (coords.hip) --------------------------------------------------

@@ -187,7 +187,7 @@ def prepare_batched_weights(w: torch.Tensor):
     B, Q, D = w.shape
     w = w.detach()
     e = 13 - torch.frexp(w.abs().amax())[1]                        # device int: largest magnitude just below 2^14
-    w_split = be.split_rows(torch.ldexp(w, e).reshape(B * Q, D).contiguous())
+    w_split = be.split_rows(torch.ldexp(w, e).reshape(B * Q, D).contiguous(), exp2=0)
     unscale = torch.ldexp(torch.ones(Q, device=w.device), -e).contiguous()
     return w_split, unscale
 

@@ -19,6 +19,11 @@ HIP_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpascohip.so")
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 MAX_KVOL = 64
+# Activation operands of the split-precision convolutions stand for x * 2^SPLIT_ACT_EXP2 (include/pasco_hip.h
+# `split_exp2`): an f16 lo half is normal only while |x| * 2^e >= 2^-3, so unscaled activations below 0.125 lost
+# operand bits (absolute floor 2^-25).  With e = 5 the full 22-bit operand covers |x| in [2^-8, 2047] and the range
+# flag fires above 2047.
+SPLIT_ACT_EXP2 = 5
 
 _vp = C.c_void_p
 _i64 = C.c_int64
@@ -35,7 +40,7 @@ class ConvDesc(C.Structure):
         ("pro_scale", _vp), ("pro_shift", _vp), ("bias", _vp),
         ("epi_scale", _vp), ("epi_shift", _vp),
         ("epi_act", _i32), ("epi_slope", C.c_float),
-        ("residual", _vp), ("res_act", _i32), ("reserved", _i32),
+        ("residual", _vp), ("res_act", _i32), ("split_exp2", _i32),
         ("epi2_scale", _vp), ("epi2_shift", _vp),
         ("mma_mode", _i32), ("w_unscale", C.c_float), ("w_f16_hi", _vp), ("w_f16_lo", _vp),
         ("splitk_ws", _vp), ("splitk_ws_bytes", _i64), ("status", _vp),
@@ -56,7 +61,8 @@ _SIGNATURES = {
     "nbr_build": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "kmap_compact": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
     "conv_fwd": [C.POINTER(ConvDesc), _vp],
-    "split_rows": [_vp, _i64, _i32, _vp, _vp, _i32, C.c_float, _vp, _vp, _vp],
+    "conv_last_config": [_vp],
+    "split_rows": [_vp, _i64, _i32, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp, _vp],
     "maxpool_fwd": [_vp, _i32, _vp, _i32, _i64, _vp, _vp],
     "mask_compact": [_vp, _i64, _vp, _vp, _vp, _i64, _vp],
     "gather_rows": [_vp, _i32, _vp, _i64, _vp, _vp],
@@ -317,10 +323,12 @@ class CBackend:
                     raise ValueError("conv: in_split does not match the input rows")
                 if w_split.numel() != kvol * cout * 2 * cpad:
                     raise ValueError("conv: w_split does not match the kernel")
-                d.mma_mode, d.w_unscale, d.in_split, d.w_split = 2, float(unscale), _ptr(in_split), _ptr(w_split)
+                d.mma_mode, d.in_split, d.w_split = 2, _ptr(in_split), _ptr(w_split)
             else:                  # (w_hi, w_lo, unscale) from split_weight_f16: mode 1, activations split in-kernel
                 w_hi, w_lo, unscale = split
-                d.mma_mode, d.w_unscale, d.w_f16_hi, d.w_f16_lo = 1, float(unscale), _ptr(w_hi), _ptr(w_lo)
+                d.mma_mode, d.w_f16_hi, d.w_f16_lo = 1, _ptr(w_hi), _ptr(w_lo)
+            d.split_exp2 = SPLIT_ACT_EXP2
+            d.w_unscale = float(unscale) * 2.0 ** (-SPLIT_ACT_EXP2)
             d.status = _ptr(self.status_word(dev))
             if n_out * cout <= (1 << 23):          # few-row layer: offer scratch for a split over the offsets
                 need = 8 * n_out * cout * 4
@@ -333,6 +341,15 @@ class CBackend:
         rc = self.fn["conv_fwd"](C.byref(d), self.stream(dev))
         self._check(rc, "conv_fwd")
         return (out, out_split) if emit else out
+
+    def conv_last_config(self) -> dict:
+        """Which kernel instantiation the last `conv_fwd` of this thread launched (include/pasco_hip.h
+        ph_conv_last_config): the parity tests assert that the instantiations the benchmark runs are the ones they
+        compared with the oracle."""
+        buf = (_i32 * 8)()
+        self._check(self.fn["conv_last_config"](C.cast(buf, _vp)), "conv_last_config")
+        names = ("mma_mode", "bm", "bn", "kc", "ksplit", "emit", "kernel", "waves")
+        return dict(zip(names, [int(v) for v in buf]))
 
     def status_word(self, device) -> torch.Tensor:
         """Device word the split-precision kernels OR their range flag into (one per device)."""
@@ -372,9 +389,11 @@ class CBackend:
         return hi.contiguous(), lo.contiguous(), float(2.0 ** (-e))
 
     def split_rows(self, x: torch.Tensor, *, pro_scale=None, pro_shift=None, pro_act=ACT_NONE, slope=0.01,
-                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """fp32 rows [n, c] -> f16 [n, cpad/32, 2, 32] (hi | lo groups) of act(x * scale + shift): the operand
-        layout of mma_mode 2 (include/pasco_hip.h ph_split_rows)."""
+                   out: Optional[torch.Tensor] = None, exp2: Optional[int] = None) -> torch.Tensor:
+        """fp32 rows [n, c] -> f16 [n, cpad/32, 2, 32] (hi | lo groups) of act(x * scale + shift) * 2^exp2: the
+        operand layout of mma_mode 2 (include/pasco_hip.h ph_split_rows).  exp2 defaults to SPLIT_ACT_EXP2 (an
+        activation operand, what `conv_fwd` expects as `in_split`); pre-scaled weights pass 0."""
+        exp2 = SPLIT_ACT_EXP2 if exp2 is None else int(exp2)
         self._chk(x, torch.float32, "in")
         n, c = x.shape
         if c % 8 != 0:
@@ -387,7 +406,7 @@ class CBackend:
                 self._chk(t, torch.float32, name)
                 if t.numel() != c:
                     raise ValueError(f"split_rows: {name} has {t.numel()} entries, expected {c}")
-        rc = self.fn["split_rows"](_ptr(x), n, c, _ptr(pro_scale), _ptr(pro_shift), pro_act, float(slope), _ptr(out),
+        rc = self.fn["split_rows"](_ptr(x), n, c, _ptr(pro_scale), _ptr(pro_shift), pro_act, float(slope), exp2, _ptr(out),
                                    _ptr(self.status_word(x.device)), self.stream(x.device))
         self._check(rc, "split_rows")
         return out
@@ -405,7 +424,7 @@ class CBackend:
             e = 0 if wmax == 0.0 else 13 - int(torch.frexp(torch.tensor(wmax))[1])
         k, cin, cout = w.shape
         rows = torch.ldexp(w, torch.tensor(e, device=w.device)).transpose(1, 2).contiguous().view(k * cout, cin)
-        return self.split_rows(rows), float(2.0 ** (-e))
+        return self.split_rows(rows, exp2=0), float(2.0 ** (-e))
 
     def split_capable(self) -> bool:
         return self.device_type == "cuda" or self.checker_split

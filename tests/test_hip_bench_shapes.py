@@ -1,0 +1,102 @@
+"""Parity of the convolution kernel instantiations THE BENCHMARK RUNS, at the benchmark's shapes.
+
+The op-level parity tests use maps of <= 30 k rows, which select the small-tile instantiations; the
+benchmark step (S10 scene, MIMO M=3) runs the tall tiles, the emitting epilogues, the split over the kernel
+offsets and the row-list kernels on maps of 53 k - 683 k rows.  Here ONE benchmark step runs with every
+`conv_fwd` launch checked in place:
+
+  (a) against the CPU oracle fed the fp32 operands, on >= 2000 sampled output rows
+      (the sub-problem of those rows: their neighbour columns, the input rows they touch);
+  (b) against an fp64 gather-matmul of the same rows on the GPU;
+  (c) the first launch of every (instantiation, layer shape) with fp32 operands bit-for-bit against the
+      in-kernel-split variant (mma_mode 1), which forms the same hi / lo products from the fp32 rows;
+  (d) an emitted next-layer operand against `ph_split_rows` of the fp32 result (full tensor, bit exact) or,
+      when the fp32 result was not written, against the fp64 reference at the operand's 22-bit resolution.
+
+`ph_conv_last_config` names the instantiation each launch ran; the test fails unless every instantiation the
+step used was checked, and writes the table to gpurun_out/ (copied to profiles/ by the round's profile run).
+The second test compares the whole S10 MIMO-3 graph on the default split-precision path with the same graph on
+the exact fp32 MFMA.  Reference layers: mink.py:625-638 (ResidualBlock convs), decoder_v3.py:267-282
+(completion heads), layers.py:646-726 (dense bottleneck), transformer_predictor_v2.py:143,150 (projections)."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+from tests.launch_checker import LaunchChecker
+
+
+@pytest.fixture(scope="module")
+def s10_net(hip):
+    import bench
+    from pasco_amd.graph.synth import TeacherKeep, make_scene
+    dev = torch.device("cuda", 0)
+    net = bench.build_net(3, 283, dev)
+    scene = make_scene(seed=0, n_infers=3, in_channels=283).to(dev)
+    return net, scene, TeacherKeep(scene, dev)
+
+
+def test_every_bench_instantiation_vs_oracle_and_fp64(hip, oracle, s10_net):
+    import bench
+    net, scene, teacher = s10_net
+    chk = LaunchChecker(hip, oracle)
+    with torch.no_grad():
+        bench.run_scene(net, scene, teacher)                  # warm-up: kernel maps, operand caches
+        chk.install()
+        try:
+            bench.run_scene(net, scene, teacher)
+        finally:
+            chk.remove()
+    table = []
+    for key, (launches, checked, worst, m1) in sorted(chk.seen.items()):
+        kid, bm, bn, kc, waves, ks, em = key
+        table.append(dict(kernel={0: "k_conv_mfma", 1: "k_conv_f16x3", 2: "k_conv_h2", 3: "k_conv_rl"}.get(kid, str(kid)),
+                          bm=bm, bn=bn, kc=kc, waves=waves, ksplit=ks, emit=em, launches_per_step=launches,
+                          checked=checked, worst_err_of_mean_abs=worst, bit_equal_mode1_shapes=sorted(m1)))
+        print(table[-1])
+        assert checked == launches
+    assert len(table) >= 5, "the S10 step should exercise several instantiations"
+    total = sum(t["launches_per_step"] for t in table)
+    assert total >= 90, f"only {total} convolution launches seen"
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "bench_instantiations_checked.json"), "w") as f:
+            json.dump(table, f, indent=1)
+
+
+def test_s10_mimo3_split_path_vs_exact_fp32(hip, s10_net):
+    """Whole graph at the benchmark size: default split-precision products vs every product on the exact fp32 MFMA."""
+    from pasco_amd.graph import fused
+    net, scene, teacher = s10_net
+
+    def run():
+        with torch.no_grad():
+            x = net.prepare_input(scene.in_feats, scene.in_coords)
+            return net(x, scene.global_min_Cs, scene.global_max_Cs, scene.min_Cs, scene.max_Cs, keep_override=teacher)
+
+    got = run()
+    fused.set_conv_precision("f32")
+    try:
+        exp = run()
+    finally:
+        fused.set_conv_precision("f16x3")
+
+    def close(a, b, what):
+        scale = float(b.abs().mean())
+        err = float((a - b).abs().max())
+        assert err <= 1e-3 * scale, f"{what}: max error {err:.3e} vs mean |y| {scale:.3e}"
+
+    for s in exp["sem_logits_at_scales"]:
+        for i, (a, b) in enumerate(zip(got["sem_logits_at_scales"][s], exp["sem_logits_at_scales"][s])):
+            assert torch.equal(a.C, b.C)
+            close(a.F, b.F, f"sem logits scale {s} subnet {i}")
+    for i, (a, b) in enumerate(zip(got["panop_predictions"], exp["panop_predictions"])):
+        assert torch.equal(a["voxel_logits"].C, b["voxel_logits"].C)
+        close(a["voxel_logits"].F, b["voxel_logits"].F, f"voxel logits subnet {i}")
+        close(a["query_logits"], b["query_logits"], f"query logits subnet {i}")

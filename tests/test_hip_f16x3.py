@@ -78,9 +78,10 @@ def test_split_rows_bit_exact(hip, oracle, n, c):
     if n > 3:
         x[1, 1], x[2, 2], x[3, 3] = 65504.0, -6.1e-5, 5.9e-8          # largest finite, near-subnormal, tiny
     ps, pb = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
-    for kw in ({}, dict(pro_scale=ps, pro_shift=pb, pro_act=2, slope=0.1)):
-        if kw:
-            x = x.clamp(-3.0e4, 3.0e4)
+    for kw in (dict(exp2=0), dict(pro_scale=ps, pro_shift=pb, pro_act=2, slope=0.1, exp2=0),
+               dict(pro_scale=ps, pro_shift=pb, pro_act=1)):          # last: an activation operand (x * 2^5)
+        if len(kw) > 1:
+            x = x.clamp(-3.0e4, 3.0e4) if "exp2" in kw else x.clamp(-1.0e3, 1.0e3)
         exp = oracle.split_rows(x, **kw)
         kw_h = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
         got = hip.split_rows(x.cuda(), **kw_h).cpu()

@@ -79,8 +79,15 @@ def test_oracle_split_rows_matches_numpy_float16(oracle):
     specials = np.array([0.0, -0.0, 65504.0, 65519.9, 6.1035156e-05, 6.0975552e-05, 5.9604645e-08, 2.9802322e-08,
                          2.9802326e-08, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, -(1.0 + 2.0 ** -11), 1e-10], np.float32)
     x[0, :specials.size] = specials
-    got = oracle.split_rows(torch.from_numpy(x)).numpy()                   # [n, 2, 2, 32] f16
+    got = oracle.split_rows(torch.from_numpy(x), exp2=0).numpy()           # [n, 2, 2, 32] f16
     assert got.shape == (n, 2, 2, 32)
+    # an activation operand (exp2 = 5) is the split of x * 32: small values keep their lo half
+    xs = np.clip(x, -2000, 2000)
+    got5 = oracle.split_rows(torch.from_numpy(xs)).numpy()
+    h5 = (xs * 32).astype(np.float16)
+    l5 = (xs * 32 - h5.astype(np.float32)).astype(np.float16)
+    assert np.array_equal(got5[:, :, 0, :].reshape(n, 64)[:, :c].view(np.int16), h5.view(np.int16))
+    assert np.array_equal(got5[:, :, 1, :].reshape(n, 64)[:, :c].view(np.int16), l5.view(np.int16))
     hi = x.astype(np.float16)
     lo = (x - hi.astype(np.float32)).astype(np.float16)
     pad = np.zeros((n, 64), np.float16)

@@ -65,3 +65,23 @@ def test_split_operand_graph_equals_fp32_graph(split_checker, heavy, n_infers, q
         assert torch.allclose(a["query_logits"], b["query_logits"], rtol=1e-3, atol=1e-3)
     for a, b in zip(got_ens[1], ref_ens[1]):             # ensembled semantic probabilities
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+
+
+def test_launch_checker_formulas_on_the_oracle(split_checker):
+    """tests/launch_checker.py (the in-place fp64 / oracle check the GPU suite wraps around every benchmark
+    launch) run against the oracle itself on a small split-operand graph: its restatement of prologue, epilogue,
+    residual tail, operand emission and operand-only inputs must agree with the library for every launch."""
+    from tests.launch_checker import LaunchChecker
+    torch.manual_seed(5)
+    net = PascoNet(n_classes=20, n_infers=2, in_channels=16, f=32, num_queries=10, heavy_decoder=False).eval()
+    scene = make_scene(6, n_infers=2, in_channels=16, grid=(32, 32, 8), occupancy=0.15)
+    split_checker.checker_split = True
+    fused.MIN_ROWS_LINEAR = 1
+    chk = LaunchChecker(split_checker, split_checker)
+    chk.install()
+    try:
+        run(net, scene)
+    finally:
+        del split_checker.conv_fwd
+    launches = sum(v[0] for v in chk.seen.values())
+    assert launches > 60 and all(v[0] == v[1] for v in chk.seen.values())
