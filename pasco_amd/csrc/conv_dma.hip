@@ -1,0 +1,294 @@
+// Sparse convolution forward, split-precision products, operands streamed global -> LDS by the LDS-DMA path
+// (`global_load_lds_dwordx4`) in a software pipeline with counted `vmcnt`:
+//
+//   * no staging registers and no ds_write pass: a gathered row chunk (128 B = [32 hi | 32 lo] f16 of one voxel)
+//     lands in LDS as 8 lanes x 16 B of one wave instruction; the weights' tile rows the same way;
+//   * two LDS stage buffers + register double-buffered MFMA fragments = three stages deep: while the matrix
+//     pipe works on stage s from registers, the fragments of stage s+1 are read from LDS and the DMA of stage
+//     s+2 (issued one step earlier) is in flight; `s_waitcnt vmcnt(L)` (L = DMA instructions per stage and
+//     thread) retires exactly the stage about to be read and leaves the younger one outstanding across the
+//     barrier (MI355X_MICROARCH.md "LDS-DMA requests stay in flight across s_barrier");
+//   * the loop holds NO other vector-memory instruction (hipcc would answer any ordinary load with vmcnt(0),
+//     cdna_hip_programming.md section 5): the neighbour indices of the tile are parked in LDS once, up front;
+//   * LDS tile rows are 128 B without padding (the DMA destination is lane-linear); the 16-byte chunk c of tile
+//     row r holds operand chunk c ^ ((r >> 1) & 7) - applied to the per-lane SOURCE address and to the fragment
+//     reads - which makes every ds_read_b128 lane group hit 16 distinct bank quads;
+//   * ONE __shared__ object (a second one makes the compiler drain vmcnt before every k-step).
+//
+// Measured motivation (tools/ubench, profiles/r2a_gather_bench.json): the bare gather of the biggest 64-channel
+// layer takes ~105 us by this path against 630 us for the whole k_conv_h2 launch whose matrix work is ~150 us:
+// the register-staged two-barrier loop serialises load, LDS store and MFMA phases instead of overlapping them.
+//
+// Same tile algebra, accumulation order and epilogue as k_conv_h2 (conv_h2_common.h): results are bit-identical.
+#include "conv_h2_common.h"
+
+constexpr int DMA_KMAX = 32;   // kernel offsets one workgroup walks (its slice of the split over the offsets)
+
+// One workgroup = 256 threads = 4 waves (WM x WN), tile BM = WM*TM*32 = 128 rows x BN = WN*TN*32 channels,
+// 32 input channels per stage.
+template <int WM, int WN, int TM, int TN, bool EMIT>
+__global__ void __launch_bounds__(HV_THREADS, 2) k_conv_dma(ConvArgsH a) {
+  constexpr int BM = WM * TM * 32;
+  constexpr int BN = WN * TN * 32;
+  static_assert(WM * WN == 4 && BM == 128, "tile shape");
+  constexpr int A_BYTES = BM * 128;
+  constexpr int B_BYTES = BN * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int A_PASSES = BM / 32;          // one pass = 32 tile rows = 4 waves x (8 rows x 128 B)
+  constexpr int B_PASSES = BN / 32;
+  constexpr int L = A_PASSES + B_PASSES;     // DMA instructions per thread and stage
+  __shared__ __attribute__((aligned(128))) char lds[2 * STAGE + DMA_KMAX * BM * 4];
+
+  const int nwg = gridDim.x;
+  const int cpx = nwg >> 3;
+  const int bid = blockIdx.x;
+  const int tile = (bid & 7) * cpx + (bid >> 3);
+  const int ntiles = a.n_row_tiles * a.n_col_tiles;
+  if (tile >= ntiles) return;
+  const int row_tile = tile / a.n_col_tiles;
+  const int col_tile = tile - row_tile * a.n_col_tiles;
+  const int64_t m0 = (int64_t)row_tile * BM;
+  const int n0 = col_tile * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int h = lane >> 5;
+  const int l31 = lane & 31;
+
+  const int cout = a.cout;
+  const int nchunks = a.cpad >> 5;
+  const int kper = (a.kvol + a.ksplit - 1) / a.ksplit;
+  const int k_begin = (int)blockIdx.y * kper;
+  const int k_end = (k_begin + kper < a.kvol) ? k_begin + kper : a.kvol;
+  const int kcount = k_end > k_begin ? k_end - k_begin : 0;
+  const int nstages = kcount * nchunks;
+  const uint32_t rsb = 4u * (uint32_t)a.cpad;   // bytes per operand row
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nstages > 0) {
+    // ---- neighbour indices of the tile -> LDS (the only ordinary loads before the epilogue) ----------------
+    // layout [offset][l_r = tile row mod 32][p = tile row / 32]: the four rows one thread feeds are one 16-byte read
+    int *idx_lds = reinterpret_cast<int *>(lds + 2 * STAGE);
+    for (int i = tid; i < kcount * BM; i += HV_THREADS) {
+      const int k = i / BM, r = i - k * BM;
+      const int64_t row = m0 + r;
+      int idx = -1;
+      if (row < a.n_out) idx = a.nbr ? a.nbr[(int64_t)(k_begin + k) * a.n_out + row] : (int)row;
+      idx_lds[k * BM + (r & 31) * 4 + (r >> 5)] = idx;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- DMA geometry of this thread: tile row l_r + 32 p, 16-byte slot l_j; source chunk swizzled ----------
+    const int l_j = tid & 7;
+    const int l_r = tid >> 3;
+    const uint32_t sj16 = (uint32_t)((l_j ^ ((l_r >> 1) & 7)) << 4);
+    const uint64_t in_base = (uint64_t)reinterpret_cast<uintptr_t>(a.in_split) + sj16;
+    const uint64_t zero_src = (uint64_t)reinterpret_cast<uintptr_t>(a.zero) + sj16;
+    const uint64_t w_base = (uint64_t)reinterpret_cast<uintptr_t>(a.w_split) + sj16;
+    uint32_t boff[B_PASSES];   // byte offset of this thread's weight rows inside one offset's [cout][rs] slab
+#pragma unroll
+    for (int q = 0; q < B_PASSES; ++q) {
+      int n = n0 + l_r + q * 32;
+      n = n < cout ? n : cout - 1;   // columns >= cout are never stored: any finite row will do
+      boff[q] = (uint32_t)n * rsb;
+    }
+    const int64_t wslab = (int64_t)cout * rsb;
+    static_assert(A_PASSES == 4, "one 16-byte index read per thread and stage");
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+    // stage s -> (offset slot, channel chunk); the tail re-loads the last stage instead of branching
+    auto stage_kc = [&](int s, int &k, uint32_t &coff) {
+      const int sc = s < nstages - 1 ? s : nstages - 1;
+      k = sc / nchunks;
+      coff = (uint32_t)(sc - k * nchunks) << 7;
+    };
+    auto load_idx = [&](int s) {
+      int k;
+      uint32_t coff;
+      stage_kc(s, k, coff);
+      return *reinterpret_cast<const i32x4 *>(idx_lds + k * BM + l_r * 4);
+    };
+    struct Src {
+      uint64_t a[A_PASSES];
+      uint64_t w;
+    };
+    auto prep = [&](int s, const i32x4 &idx, Src &src) {   // VALU only: source addresses of stage s
+      int k;
+      uint32_t coff;
+      stage_kc(s, k, coff);
+#pragma unroll
+      for (int p = 0; p < A_PASSES; ++p) {
+        const int ix = idx[p];
+        uint64_t v = in_base + (uint64_t)(uint32_t)(ix < 0 ? 0 : ix) * rsb + coff;
+        asm volatile("" : "+v"(v));            // materialise before the select: a select, not a branch per row
+        src.a[p] = ix >= 0 ? v : zero_src;
+      }
+      src.w = w_base + (uint64_t)((int64_t)(k_begin + k) * wslab) + coff;
+    };
+    auto fire = [&](const Src &src, int buf) {
+      char *abuf = lds + buf * STAGE;
+#pragma unroll
+      for (int p = 0; p < A_PASSES; ++p) {
+        char *dst = abuf + (p * 32 + wave * 8) * 128;   // wave-uniform; the DMA adds lane * 16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)src.a[p],
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < B_PASSES; ++q) {
+        char *dst = abuf + A_BYTES + (q * 32 + wave * 8) * 128;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(src.w + boff[q]),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+      }
+    };
+
+    // ---- fragment reads: lane = (tile row l31 of a 32-row block, k-half h); chunk c of row r sits at c ^ sw ---
+    const int sw = (l31 >> 1) & 7;
+    uint32_t xo[2][2];   // [ks][hi / lo] byte offset of the lane's 16-byte run inside its tile row
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int part = 0; part < 2; ++part) xo[ks][part] = (uint32_t)(((part * 4 + ks * 2 + h) ^ sw) << 4);
+    const uint32_t arow = (uint32_t)((wm * TM * 32 + l31) * 128);
+    const uint32_t brow = (uint32_t)(A_BYTES + (wn * TN * 32 + l31) * 128);
+
+    struct Frag {
+      f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+    };
+    auto readfrag = [&](int buf, Frag &f) {
+      const char *base = lds + buf * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          f.ah[ks][i] = *reinterpret_cast<const f16x8 *>(base + arow + i * 4096 + xo[ks][0]);
+          f.al[ks][i] = *reinterpret_cast<const f16x8 *>(base + arow + i * 4096 + xo[ks][1]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f.bh[ks][j] = *reinterpret_cast<const f16x8 *>(base + brow + j * 4096 + xo[ks][0]);
+          f.bl[ks][j] = *reinterpret_cast<const f16x8 *>(base + brow + j * 4096 + xo[ks][1]);
+        }
+      }
+    };
+    auto mfma = [&](const Frag &f) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            // weights first: transposed accumulator block (lane = output row); smallest terms first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[ks][j], f.al[ks][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[ks][j], f.ah[ks][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[ks][j], f.ah[ks][i], acc[i][j], 0, 0, 0);
+          }
+    };
+    // wait until at most L DMA instructions (= the younger stage) are outstanding, then rendezvous
+#define DMA_WAIT_STAGE()                                                  \
+  do {                                                                    \
+    if (L == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");          \
+    else if (L == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     \
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                 \
+    __builtin_amdgcn_s_barrier();                                         \
+  } while (0)
+#define DMA_READS_DONE()                                  \
+  do {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_s_barrier();                         \
+  } while (0)
+    static_assert(L == 5 || L == 6 || L == 8, "vmcnt immediates");
+
+    Frag f0, f1;
+    Src src;
+    i32x4 ix;
+    prep(0, load_idx(0), src);
+    fire(src, 0);
+    prep(1, load_idx(1), src);
+    fire(src, 1);
+    ix = load_idx(2);
+    DMA_WAIT_STAGE();            // stage 0 landed (stage 1 may still fly)
+    prep(2, ix, src);
+    readfrag(0, f0);
+    DMA_READS_DONE();            // every wave has its stage-0 fragments: buffer 0 is free
+    fire(src, 0);
+    ix = load_idx(3);            // index reads run one step ahead of the address arithmetic that consumes them
+    for (int s = 0; s < nstages; s += 2) {
+      // stage s from f0; fragments of stage s + 1 from buffer 1; DMA of stage s + 3 into buffer 1 afterwards
+      DMA_WAIT_STAGE();
+      prep(s + 3, ix, src);
+      readfrag(1, f1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(f0);
+      __builtin_amdgcn_sched_barrier(0);
+      DMA_READS_DONE();
+      fire(src, 1);
+      ix = load_idx(s + 4);
+      // stage s + 1 from f1; fragments of stage s + 2 from buffer 0; DMA of stage s + 4 into buffer 0 afterwards
+      DMA_WAIT_STAGE();
+      prep(s + 4, ix, src);
+      readfrag(0, f0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < nstages) mfma(f1);
+      __builtin_amdgcn_sched_barrier(0);
+      DMA_READS_DONE();
+      fire(src, 0);
+      ix = load_idx(s + 5);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail loads: nothing may land after the epilogue starts
+#undef DMA_WAIT_STAGE
+#undef DMA_READS_DONE
+  }
+
+  h2_store_tile<TM, TN, EMIT>(a, acc, m0, n0, wm, wn, h, l31);
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_dma(const ConvArgsH &a, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  ConvArgsH args = a;
+  args.n_row_tiles = (int)((a.n_out + BM - 1) / BM);
+  args.n_col_tiles = (a.cout + BN - 1) / BN;
+  const int ntiles = args.n_row_tiles * args.n_col_tiles;
+  const int grid = ((ntiles + 7) / 8) * 8;
+  const bool emit = args.out_split != nullptr && args.ksplit == 1;
+  if (emit)
+    hipLaunchKernelGGL((k_conv_dma<WM, WN, TM, TN, true>), dim3(grid, 1), dim3(HV_THREADS), 0, st, args);
+  else
+    hipLaunchKernelGGL((k_conv_dma<WM, WN, TM, TN, false>), dim3(grid, args.ksplit), dim3(HV_THREADS), 0, st, args);
+  PH_LAUNCH_CHECK();
+  if (args.ksplit > 1) {
+    if (int rc = ph_launch_splitk_epilogue(args, st)) return rc;
+  }
+  ph_record_cfg(2, BM, BN, 32, args.ksplit, emit ? 1 : 0, 4, 4);
+  return 0;
+}
+
+__device__ __attribute__((aligned(256))) const uint32_t ph_dma_zero_line[64] = {0};   // absent neighbours read this
+
+// Takes the launch when the shape fits the DMA pipeline; returns -1 when the caller should use k_conv_h2.
+// `a` arrives fully prepared (tile-independent fields, ksplit / partial chosen by the caller for 128-row tiles).
+int ph_conv_dma_try(const ConvArgsH &a_in, int bn, hipStream_t st) {
+  const int kper = (a_in.kvol + a_in.ksplit - 1) / a_in.ksplit;
+  if (kper > DMA_KMAX) return -1;
+  static const char *zero = nullptr;
+  if (zero == nullptr) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(ph_dma_zero_line)) != hipSuccess || p == nullptr) return -1;
+    zero = (const char *)p;
+  }
+  ConvArgsH a = a_in;
+  a.zero = zero;
+  if (bn == 32) return launch_dma<4, 1, 1, 1>(a, st);
+  if (bn == 64) return launch_dma<4, 1, 1, 2>(a, st);
+  return launch_dma<2, 2, 2, 2>(a, st);
+}

@@ -15,71 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "ph_common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-constexpr int HV_THREADS = 256;
-// KC input channels per stage (32 or 64); LDS rows hold KC + 8 f16 (80 / 144 bytes: 16-byte aligned and
-// conflict-free for the b128 fragment reads)
-
-__device__ __forceinline__ float h_act(float v, float neg) { return ph_act(v, neg); }
-// range flag of a value about to become an f16 operand: true for |t| > 65504 AND for NaN
-__device__ __forceinline__ bool h_out_of_range(float t) { return !(fabsf(t) <= 65504.f); }
-
-struct ConvArgsH {
-  const float *in;
-  const _Float16 *w_hi;   // [kvol][cout][cin]
-  const _Float16 *w_lo;
-  const int32_t *nbr;
-  float *out;
-  int64_t n_in, n_out;
-  int cin, cout, kvol;
-  const float *pro_scale, *pro_shift, *bias, *epi_scale, *epi_shift, *epi2_scale, *epi2_shift, *residual;
-  float pro_neg, epi_neg, res_neg, w_unscale;
-  int has_pro, has_tail;
-  int n_row_tiles, n_col_tiles;
-  int32_t *status;
-  int ksplit;       // > 1: blockIdx.y walks one slice of the kernel offsets and stores raw partial sums
-  float *partial;   // [ksplit][n_out][cout]
-  // mode 2 (both operands pre-split by ph_split_rows): rows of cpad/32 groups [hi x32 | lo x32]
-  const _Float16 *in_split;   // [n_in][cpad/32][2][32]
-  const _Float16 *w_split;    // [kvol][cout][cpad/32][2][32]
-  int cpad;
-  // optional second output: split operand of act(out * osp_scale + osp_shift) for the next convolution
-  _Float16 *out_split;        // [n_out][cout/32][2][32]  (cout % 32 == 0)
-  const float *osp_scale, *osp_shift;
-  float osp_neg;
-  int osp_has;
-  float act_pow2;             // 2^split_exp2: scale of the activation operand (mode 1 gather, emitted out_split)
-};
-
-// hi / lo halves of four values -> the [hi x32 | lo x32] group layout (dst points at the run's hi slot)
-__device__ __forceinline__ bool emit_split4(const float v[4], const float *sc, const float *sh, int has, float neg,
-                                            float pow2, _Float16 *dst) {
-  f16x4 hi, lo;
-  bool bad = false;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float t = v[q];
-    if (has) {   // separate multiply and add, like ph_split_rows and the C restatement
-#pragma clang fp contract(off)
-      const float m = t * (sc ? sc[q] : 1.f);
-      t = h_act(m + (sh ? sh[q] : 0.f), neg);
-    }
-    t *= pow2;
-    bad |= h_out_of_range(t);
-    const _Float16 th = (_Float16)t;
-    hi[q] = th;
-    lo[q] = (_Float16)(t - (float)th);
-  }
-  *reinterpret_cast<f16x4 *>(dst) = hi;
-  *reinterpret_cast<f16x4 *>(dst + 32) = lo;
-  return bad;
-}
-
+#include "conv_h2_common.h"
 
 template <int BM, int KC, int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
@@ -198,7 +134,11 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_f16x3(ConvArgsH a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x = v[j];
-        if (a.has_pro) x = h_act(x * ps[j] + pb[j], a.pro_neg);
+        if (a.has_pro) {   // separate multiply and add, like ph_split_rows (mode 2) and the C restatement
+#pragma clang fp contract(off)
+          const float m = x * ps[j];
+          x = h_act(m + pb[j], a.pro_neg);
+        }
         if (!ok || cbase + j >= cin) x = 0.f;
         x *= a.act_pow2;
         xbad |= h_out_of_range(x);
@@ -488,117 +428,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
     __syncthreads();
   }
 
-  // accumulator layout (transposed block): acc[i][j][4g + q] = out[row = m0 + (wm*TM+i)*32 + l31]
-  //                                                          [col = n0 + (wn*TN+j)*32 + 8g + 4h + q]
-  if (a.ksplit > 1) {   // raw partial sums; k_splitk_epilogue reduces them in a fixed order
-    float *part = a.partial + (int64_t)blockIdx.y * a.n_out * cout;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int64_t row = m0 + (wm * TM + i) * 32 + l31;
-      if (row >= a.n_out) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = n0 + (wn * TN + j) * 32 + 8 * g + 4 * h;
-          if (col >= cout) continue;
-          *reinterpret_cast<float4 *>(part + row * cout + col) =
-              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        }
-    }
-    return;
-  }
-
-  bool obad = false;
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {       // pairs of 4-channel runs: g = 2m, 2m + 1
-      const int cbase = n0 + (wn * TN + j) * 32 + 16 * m;
-      if (cbase >= cout) continue;      // uniform over the wave (cout % 4 == 0; with out_split cout % 32 == 0)
-      float bias[2][4], es[2][4], eb[2][4], es2[2][4], eb2[2][4];
-      bool cok[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int col = cbase + 8 * u + 4 * h;
-        cok[u] = col < cout;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c = cok[u] ? col + q : 0;
-          bias[u][q] = a.bias ? a.bias[c] : 0.f;
-          es[u][q] = a.epi_scale ? a.epi_scale[c] : 1.f;
-          eb[u][q] = a.epi_shift ? a.epi_shift[c] : 0.f;
-          es2[u][q] = a.epi2_scale ? a.epi2_scale[c] : 1.f;
-          eb2[u][q] = a.epi2_shift ? a.epi2_shift[c] : 0.f;
-        }
-      }
-      // operand emission: after a half-wave exchange this lane owns 8 consecutive channels cbase + 8h .. + 7
-      float sc[8], sh[8];
-      if (EMIT) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          sc[q] = a.osp_scale ? a.osp_scale[cbase + 8 * h + q] : 1.f;
-          sh[q] = a.osp_shift ? a.osp_shift[cbase + 8 * h + q] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int64_t row = m0 + (wm * TM + i) * 32 + l31;
-        const bool rok = row < a.n_out;
-        float v[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int g = 2 * m + u;
-          const int col = cbase + 8 * u + 4 * h;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            v[u][q] = h_act((acc[i][j][4 * g + q] * a.w_unscale + bias[u][q]) * es[u][q] + eb[u][q], a.epi_neg);
-          if (a.has_tail) {
-            float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.residual && rok && cok[u]) rs = *reinterpret_cast<const float4 *>(a.residual + row * cout + col);
-            const float r4[4] = {rs.x, rs.y, rs.z, rs.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[u][q] = h_act(v[u][q] * es2[u][q] + eb2[u][q] + r4[q], a.res_neg);
-          }
-          if ((!EMIT || a.out) && rok && cok[u])
-            *reinterpret_cast<float4 *>(a.out + row * cout + col) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
-        }
-        if (EMIT) {
-          // lanes l and l ^ 32 hold the same row: h = 0 keeps run u = 0 and takes the partner's u = 0 (channels
-          // +4..7); h = 1 takes the partner's u = 1 (channels +8..11) and keeps its own u = 1
-          float w8[8];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float send = h ? v[0][q] : v[1][q];
-            const float recv = __shfl_xor(send, 32);
-            w8[q] = h ? recv : v[0][q];
-            w8[4 + q] = h ? v[1][q] : recv;
-          }
-          if (rok) {
-            f16x8 hi, lo;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              float t = w8[q];
-              if (a.osp_has) {   // separate multiply and add, like ph_split_rows and the C restatement
-#pragma clang fp contract(off)
-                const float mm = t * sc[q];
-                t = h_act(mm + sh[q], a.osp_neg);
-              }
-              t *= a.act_pow2;
-              obad |= h_out_of_range(t);
-              const _Float16 th = (_Float16)t;
-              hi[q] = th;
-              lo[q] = (_Float16)(t - (float)th);
-            }
-            const int col8 = cbase + 8 * h;
-            _Float16 *dst = a.out_split + (row * (cout >> 5) + (col8 >> 5)) * 64 + (col8 & 31);
-            *reinterpret_cast<f16x8 *>(dst) = hi;
-            *reinterpret_cast<f16x8 *>(dst + 32) = lo;
-          }
-        }
-      }
-    }
-  if (EMIT && a.status != nullptr && obad) atomicOr(a.status, 1);
+  h2_store_tile<TM, TN, EMIT>(a, acc, m0, n0, wm, wn, h, l31);
 }
 
 // fp32 rows -> [hi x32 | lo x32] groups; one thread per 8 channels.  Channels >= c (pad to 32) are zero.
@@ -698,6 +528,13 @@ __global__ void __launch_bounds__(256) k_splitk_epilogue(ConvArgsH a) {
   }
 }
 
+int ph_launch_splitk_epilogue(const ConvArgsH &args, hipStream_t st) {
+  const int64_t total = args.n_out * args.cout;
+  hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, args);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int BM, int KC, int WM, int WN, int TM, int TN>
 static int launch_h(const ConvArgsH &a, hipStream_t st) {
   constexpr int BN = WN * TN * 32;
@@ -749,7 +586,9 @@ struct ConvHKnobs {
   int cfg_bm = 0, cfg_kc = 0;
   bool has_ksplit = false;
   int ksplit = 0;
+  bool dma_on = true;      // PASCO_CONV_DMA=0: keep every launch on the register-staged k_conv_h2 (A/B comparisons)
   ConvHKnobs() {
+    if (const char *e = getenv("PASCO_CONV_DMA")) dma_on = atoi(e) != 0;
     if (const char *e = getenv("PASCO_CONVH_MID")) mid_on = atoi(e) != 0;
     if (const char *e = getenv("PASCO_CONVH_CFG")) has_cfg = sscanf(e, "%d,%d", &cfg_bm, &cfg_kc) >= 1;
     if (const char *e = getenv("PASCO_CONVH_KSPLIT")) {
@@ -821,6 +660,7 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.has_tail = (d->residual || d->epi2_scale || d->epi2_shift || d->res_act != PH_ACT_NONE) ? 1 : 0;
   a.n_row_tiles = a.n_col_tiles = 0;
   a.status = d->status;
+  a.zero = nullptr;
   const int bn = d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128);
   const int64_t ncol = (d->cout + bn - 1) / bn;
   // tile height: the tallest tile that still gives >= 2 workgroups per CU (profiles/r1e_op_bench.json)
@@ -864,6 +704,24 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
       a.ksplit = want;
       a.partial = (float *)d->splitk_ws;
     }
+  }
+  // default for pre-split operands: the LDS-DMA pipelined kernel (conv_dma.hip; 128-row tiles, parallelism of few-row
+  // layers from the split over the offsets chosen above); it declines slices of more than 32 offsets
+  if (pre && knobs.dma_on && !env) {
+    ConvArgsH b = a;
+    if (bm != 128) {        // the choice above was made for a shorter tile: redo the split decision for 128 rows
+      const int64_t t128 = ((d->n_out + 127) / 128) * ncol;
+      int want = (int)(1024 / (t128 > 0 ? t128 : 1));
+      if (want > 8) want = 8;
+      if (want > d->kvol / 4) want = d->kvol / 4;
+      const bool room = d->splitk_ws != nullptr && d->splitk_ws_bytes >= (int64_t)want * d->n_out * d->cout * 4;
+      if (t128 < 256 && want >= 2 && room) {
+        b.ksplit = want;
+        b.partial = (float *)d->splitk_ws;
+      }
+    }
+    const int rc = ph_conv_dma_try(b, bn, st);
+    if (rc >= 0) return rc;
   }
 #define PH_H_CASE(BM_, WM_, WN_, TM_, TN_)                                                                \
   if (bm == BM_) {                                                                                        \

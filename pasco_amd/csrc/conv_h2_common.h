@@ -1,0 +1,195 @@
+// Shared pieces of the split-precision convolution kernels (conv_f16x3.hip: k_conv_f16x3 / k_conv_h2,
+// conv_dma.hip: k_conv_dma): argument block, activation / range helpers, the tile epilogue.
+#pragma once
+#include "ph_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HV_THREADS = 256;
+// KC input channels per stage (32 or 64); LDS rows hold KC + 8 f16 (80 / 144 bytes: 16-byte aligned and
+// conflict-free for the b128 fragment reads)
+
+__device__ __forceinline__ float h_act(float v, float neg) { return ph_act(v, neg); }
+// range flag of a value about to become an f16 operand: true for |t| > 65504 AND for NaN
+__device__ __forceinline__ bool h_out_of_range(float t) { return !(fabsf(t) <= 65504.f); }
+
+struct ConvArgsH {
+  const float *in;
+  const _Float16 *w_hi;   // [kvol][cout][cin]
+  const _Float16 *w_lo;
+  const int32_t *nbr;
+  float *out;
+  int64_t n_in, n_out;
+  int cin, cout, kvol;
+  const float *pro_scale, *pro_shift, *bias, *epi_scale, *epi_shift, *epi2_scale, *epi2_shift, *residual;
+  float pro_neg, epi_neg, res_neg, w_unscale;
+  int has_pro, has_tail;
+  int n_row_tiles, n_col_tiles;
+  int32_t *status;
+  int ksplit;       // > 1: blockIdx.y walks one slice of the kernel offsets and stores raw partial sums
+  float *partial;   // [ksplit][n_out][cout]
+  // mode 2 (both operands pre-split by ph_split_rows): rows of cpad/32 groups [hi x32 | lo x32]
+  const _Float16 *in_split;   // [n_in][cpad/32][2][32]
+  const _Float16 *w_split;    // [kvol][cout][cpad/32][2][32]
+  int cpad;
+  // optional second output: split operand of act(out * osp_scale + osp_shift) for the next convolution
+  _Float16 *out_split;        // [n_out][cout/32][2][32]  (cout % 32 == 0)
+  const float *osp_scale, *osp_shift;
+  float osp_neg;
+  int osp_has;
+  float act_pow2;             // 2^split_exp2: scale of the activation operand (mode 1 gather, emitted out_split)
+  const char *zero;           // k_conv_dma: >= 256 zero bytes in device memory (rows without a neighbour read them)
+};
+
+// conv_f16x3.hip: reduction + epilogue of a split over the kernel offsets (after a launch with args.ksplit > 1)
+int ph_launch_splitk_epilogue(const ConvArgsH &args, hipStream_t st);
+// conv_dma.hip: the LDS-DMA pipelined kernel; -1 = shape not served (caller falls back to k_conv_h2)
+int ph_conv_dma_try(const ConvArgsH &a, int bn, hipStream_t st);
+
+// hi / lo halves of four values -> the [hi x32 | lo x32] group layout (dst points at the run's hi slot)
+__device__ __forceinline__ bool emit_split4(const float v[4], const float *sc, const float *sh, int has, float neg,
+                                            float pow2, _Float16 *dst) {
+  f16x4 hi, lo;
+  bool bad = false;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float t = v[q];
+    if (has) {   // separate multiply and add, like ph_split_rows and the C restatement
+#pragma clang fp contract(off)
+      const float m = t * (sc ? sc[q] : 1.f);
+      t = h_act(m + (sh ? sh[q] : 0.f), neg);
+    }
+    t *= pow2;
+    bad |= h_out_of_range(t);
+    const _Float16 th = (_Float16)t;
+    hi[q] = th;
+    lo[q] = (_Float16)(t - (float)th);
+  }
+  *reinterpret_cast<f16x4 *>(dst) = hi;
+  *reinterpret_cast<f16x4 *>(dst + 32) = lo;
+  return bad;
+}
+
+
+
+// Epilogue of the transposed-accumulator tile (shared by k_conv_h2 and k_conv_dma): raw partial sums for a split over
+// the kernel offsets, else bias / BN / activation / residual tail as float4 stores and, with EMIT, the next
+// convolution's split operand.
+template <int TM, int TN, bool EMIT>
+__device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm,
+                                              int wn, int h, int l31) {
+  const int cout = a.cout;
+  // accumulator layout (transposed block): acc[i][j][4g + q] = out[row = m0 + (wm*TM+i)*32 + l31]
+  //                                                          [col = n0 + (wn*TN+j)*32 + 8g + 4h + q]
+  if (a.ksplit > 1) {   // raw partial sums; k_splitk_epilogue reduces them in a fixed order
+    float *part = a.partial + (int64_t)blockIdx.y * a.n_out * cout;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int64_t row = m0 + (wm * TM + i) * 32 + l31;
+      if (row >= a.n_out) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = n0 + (wn * TN + j) * 32 + 8 * g + 4 * h;
+          if (col >= cout) continue;
+          *reinterpret_cast<float4 *>(part + row * cout + col) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+    }
+    return;
+  }
+
+  bool obad = false;
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {       // pairs of 4-channel runs: g = 2m, 2m + 1
+      const int cbase = n0 + (wn * TN + j) * 32 + 16 * m;
+      if (cbase >= cout) continue;      // uniform over the wave (cout % 4 == 0; with out_split cout % 32 == 0)
+      float bias[2][4], es[2][4], eb[2][4], es2[2][4], eb2[2][4];
+      bool cok[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int col = cbase + 8 * u + 4 * h;
+        cok[u] = col < cout;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = cok[u] ? col + q : 0;
+          bias[u][q] = a.bias ? a.bias[c] : 0.f;
+          es[u][q] = a.epi_scale ? a.epi_scale[c] : 1.f;
+          eb[u][q] = a.epi_shift ? a.epi_shift[c] : 0.f;
+          es2[u][q] = a.epi2_scale ? a.epi2_scale[c] : 1.f;
+          eb2[u][q] = a.epi2_shift ? a.epi2_shift[c] : 0.f;
+        }
+      }
+      // operand emission: after a half-wave exchange this lane owns 8 consecutive channels cbase + 8h .. + 7
+      float sc[8], sh[8];
+      if (EMIT) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          sc[q] = a.osp_scale ? a.osp_scale[cbase + 8 * h + q] : 1.f;
+          sh[q] = a.osp_shift ? a.osp_shift[cbase + 8 * h + q] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int64_t row = m0 + (wm * TM + i) * 32 + l31;
+        const bool rok = row < a.n_out;
+        float v[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int g = 2 * m + u;
+          const int col = cbase + 8 * u + 4 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            v[u][q] = h_act((acc[i][j][4 * g + q] * a.w_unscale + bias[u][q]) * es[u][q] + eb[u][q], a.epi_neg);
+          if (a.has_tail) {
+            float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.residual && rok && cok[u]) rs = *reinterpret_cast<const float4 *>(a.residual + row * cout + col);
+            const float r4[4] = {rs.x, rs.y, rs.z, rs.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[u][q] = h_act(v[u][q] * es2[u][q] + eb2[u][q] + r4[q], a.res_neg);
+          }
+          if ((!EMIT || a.out) && rok && cok[u])
+            *reinterpret_cast<float4 *>(a.out + row * cout + col) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+        }
+        if (EMIT) {
+          // lanes l and l ^ 32 hold the same row: h = 0 keeps run u = 0 and takes the partner's u = 0 (channels
+          // +4..7); h = 1 takes the partner's u = 1 (channels +8..11) and keeps its own u = 1
+          float w8[8];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float send = h ? v[0][q] : v[1][q];
+            const float recv = __shfl_xor(send, 32);
+            w8[q] = h ? recv : v[0][q];
+            w8[4 + q] = h ? v[1][q] : recv;
+          }
+          if (rok) {
+            f16x8 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              float t = w8[q];
+              if (a.osp_has) {   // separate multiply and add, like ph_split_rows and the C restatement
+#pragma clang fp contract(off)
+                const float mm = t * sc[q];
+                t = h_act(mm + sh[q], a.osp_neg);
+              }
+              t *= a.act_pow2;
+              obad |= h_out_of_range(t);
+              const _Float16 th = (_Float16)t;
+              hi[q] = th;
+              lo[q] = (_Float16)(t - (float)th);
+            }
+            const int col8 = cbase + 8 * h;
+            _Float16 *dst = a.out_split + (row * (cout >> 5) + (col8 >> 5)) * 64 + (col8 & 31);
+            *reinterpret_cast<f16x8 *>(dst) = hi;
+            *reinterpret_cast<f16x8 *>(dst + 32) = lo;
+          }
+        }
+      }
+    }
+  if (EMIT && a.status != nullptr && obad) atomicOr(a.status, 1);
+}

@@ -236,25 +236,34 @@ class TransformerPredictorV2(nn.Module):
             output = self.transformer_ffn_layers[layer](output)
         return (output,) + tuple(self.heads_query_side(output, want_operand))
 
+    _QGRAPH_MAX = 16     # captured graphs kept per module (3 layers + heads, a few batch shapes); oldest evicted
+
     def query_step(self, layer: int, output, query_embed, want_operand: bool):
-        if not output.is_cuda or self.training or os.environ.get("PASCO_QUERY_GRAPH", "1") == "0" or \
-                self.__dict__.get("_qgraph_broken", False):
+        if not output.is_cuda or self.training or torch.is_grad_enabled() or \
+                os.environ.get("PASCO_QUERY_GRAPH", "1") == "0" or self.__dict__.get("_qgraph_broken", False):
             return self._query_step(layer, output, query_embed, want_operand)
         graphs = self.__dict__.setdefault("_qgraphs", {})
-        vers = tuple(p._version for p in self.parameters())
-        key = (layer, tuple(output.shape), output.device, want_operand, query_embed.data_ptr())
+        # a captured graph bakes in the ADDRESSES of every parameter it reads: the key carries version and storage
+        # address of each (load_state_dict(assign=True), .cpu().cuda() round trips, param.data = ... change the
+        # address without bumping the version)
+        vers = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        key = (layer, tuple(output.shape), tuple(query_embed.shape), output.device, want_operand)
         hit = graphs.get(key)
         if hit is None or hit["vers"] != vers:
             try:
                 hit = self._capture_query_step(layer, output, query_embed, want_operand)
                 hit["vers"] = vers
+                graphs.pop(key, None)
                 graphs[key] = hit
+                while len(graphs) > self._QGRAPH_MAX:          # dicts keep insertion order: drop the oldest capture
+                    graphs.pop(next(iter(graphs)))
             except Exception as exc:       # capture is an optimisation: never let it take the step down
                 self.__dict__["_qgraph_broken"] = True
                 import warnings
                 warnings.warn(f"pasco_amd: query-side graph capture failed ({type(exc).__name__}: {exc}); running eagerly")
                 return self._query_step(layer, output, query_embed, want_operand)
         hit["x"].copy_(output)
+        hit["qe"].copy_(query_embed)       # per-call tensor (a row selection of the embedding with subnets): static copy
         hit["graph"].replay()
         out, oc, me, prepared = hit["outs"]
         # the class logits are kept by the caller across replays -> private copy; the rest is consumed before the next replay
@@ -262,16 +271,17 @@ class TransformerPredictorV2(nn.Module):
 
     def _capture_query_step(self, layer, output, query_embed, want_operand):
         x = output.detach().clone()
+        qe = query_embed.detach().clone()
         side = torch.cuda.Stream(device=output.device)
         side.wait_stream(torch.cuda.current_stream(output.device))
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(2):             # warm-up outside the capture: library handles, workspaces, autotuning
-                self._query_step(layer, x, query_embed, want_operand)
+                self._query_step(layer, x, qe, want_operand)
         torch.cuda.current_stream(output.device).wait_stream(side)
         g = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(g):
-            outs = self._query_step(layer, x, query_embed, want_operand)
-        return {"graph": g, "x": x, "outs": outs}
+            outs = self._query_step(layer, x, qe, want_operand)
+        return {"graph": g, "x": x, "qe": qe, "outs": outs}
 
     # -- attention mask -----------------------------------------------------------------------------
     def compute_mask_bits(self, outputs_mask, voxel_coord, src_C, src_scale, min_Cs, max_Cs, cache=None):
