@@ -5,20 +5,31 @@ scene S10 (BASELINE.json metric / SURVEY.md 8(d)).
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one scene through the hot path: point-feature MLP + voxel max (CylinderFeat), MIMO
-input merge, sparse U-Net encoder / dense bottleneck / generative decoder, and the mask-transformer
+input merge, sparse U-Net encoder / dense bottleneck / generative decoder, the mask-transformer
 decoder (the reference's `Net.step_inference` up to and including `self.unet3d(...)`,
-net_panoptic_sparse.py:548-550,233-245).  Inputs are resident in HBM before the timed region.
-Weights are seeded random (no checkpoints offline), BN statistics randomised, light decoder,
-teacher-forced pruning.  N > 1: one process per GPU (torchrun), every rank runs its
-own scenes (weak scaling, no data-path collective); time = max over ranks.
+net_panoptic_sparse.py:548-550,233-245) and semantic + panoptic ensembling.  Inputs are resident in HBM
+before the timed region.  Weights are seeded random (no checkpoints offline), BN statistics randomised,
+light decoder, teacher-forced pruning.  The timed loop rotates over four different scenes
+(seeds 4 r .. 4 r + 3 on rank r).
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel =
-k=3 sparse convolution, measured live with HIP events on the launch stream) and `cpu_baseline`
-(the CPU oracle running the same graph on the host cores - the ONLY place the oracle is used here).
+N > 1: one process per GPU.  Started without a launcher (`python bench.py --gpus N`) the script re-executes
+itself under `torch.distributed.run`; under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.
+  --mode scenes        (default) every rank runs its own scenes: weak scaling, no data-path collective
+  --mode subnet-heads  config C4: MIMO M = --n-infers (8), every rank runs the shared trunk on the SAME scene and
+                       only its own subnet heads; one RCCL all-gather of per-voxel logits; strong scaling
+Time = max over ranks between two barrier + device-sync fences.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant convolution kernel,
+measured live with HIP events on the launch stream, per layer class with both roofs), `cpu_baseline` (the CPU
+oracle running the same graph on the host cores - the ONLY place the oracle is used here) and `configs` (short
+driver-timed rows of BASELINE.json's other single-GPU configurations).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,39 +41,67 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (matrix) = vector rate
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA peak
 HBM_PEAK_GBS = 8000.0
+SPLIT_KERNELS = ("k_conv_dma", "k_conv_h2", "k_conv_f16x3", "k_conv_rl")   # 3 f16 MFMAs per product
+
+
+# ------------------------------------------------------------------------------------------------------
+# roofline
+# ------------------------------------------------------------------------------------------------------
+def pmc_record(kernel):
+    """The newest committed PMC pass that lists `kernel`: profiles/r*_pmc_conv.json (tools/pmc_summary.py from
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md).  PMC counters cannot be read from inside the process: a recorded measurement, with
+    the commit it was taken at, or None."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv.json")), reverse=True):
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+            k = doc["kernels"][kernel]
+            return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "commit": doc.get("commit"),
+                    "file": os.path.relpath(path, ROOT)}
+        except Exception:
+            continue
+    return None
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r1_pmc_conv.json, produced by tools/pmc_summary.py; FETCH_SIZE doubled per
-    MI355X_MICROARCH.md).  PMC counters cannot be collected from inside the process, so this is a
-    recorded measurement, or null when none is committed."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_conv.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    r = pmc_record(kernel)
+    return None if r is None else r["hbm_bytes_per_launch"]
 
 
-def roofline_object(per_kernel, steps):
-    """`roofline` for the dominant kernel (most time in the timed region), the other conv kernel beside it."""
+def _roofs(name, flops, bytes_alg, time_s):
+    """Both roofs of one group of launches: algorithmic bytes against the HBM peak, matrix work against the
+    MFMA peak of the arithmetic actually used; `bound` = the roof the group sits closer to."""
+    tf = flops / time_s / 1e12
+    gbs = bytes_alg / time_s / 1e9
+    hbm_frac = gbs / HBM_PEAK_GBS
+    if name in SPLIT_KERNELS:
+        mfma_frac, mfma_peak, mfma_tf = 3.0 * tf / F16_MFMA_PEAK_TFLOPS, F16_MFMA_PEAK_TFLOPS, 3.0 * tf
+    else:
+        mfma_frac, mfma_peak, mfma_tf = tf / F32_MFMA_PEAK_TFLOPS, F32_MFMA_PEAK_TFLOPS, tf
+    e = {"useful_TFLOPs": round(tf, 3), "alg_GBps": round(gbs, 1), "alg_frac_of_hbm_peak": round(hbm_frac, 4),
+         "mfma_TFLOPs_issued": round(mfma_tf, 2), "mfma_frac_of_peak": round(mfma_frac, 4)}
+    if hbm_frac >= mfma_frac:
+        e.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_frac, 4))
+    else:
+        e.update(bound="mfma", achieved=round(mfma_tf, 2), peak=mfma_peak, unit="TFLOP/s", frac=round(mfma_frac, 4))
+    return e
+
+
+def roofline_object(per_kernel, steps, classes=None):
+    """`roofline` for the dominant convolution kernel (most time in the timed region), the other convolution
+    kernels beside it, the operand-split passes, and the per-layer-class table."""
     def entry(name, s):
         avg = s["time_s"] / s["launches"]
-        tf = s["flops"] / s["time_s"] / 1e12
-        gbs = s["bytes_alg"] / s["time_s"] / 1e9
         e = {"kernel": name, "launches_per_step": s["launches"] / steps, "avg_launch_us": round(avg * 1e6, 2),
              "ms_per_step": round(s["time_s"] / steps * 1e3, 3), "flops_per_launch": s["flops"] / s["launches"],
-             "alg_bytes_per_launch": s["bytes_alg"] / s["launches"], "useful_TFLOPs": round(tf, 3),
-             "alg_GBps": round(gbs, 1), "traffic": pmc_traffic(name)}
-        if name == "k_conv_mfma":    # exact fp32 MFMA: matrix-pipe bound (SURVEY.md section 7 roofline check)
-            e.update(bound="mfma", achieved=round(tf, 3), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                     frac=round(tf / F32_MFMA_PEAK_TFLOPS, 4), alg_frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4))
-        else:                        # split-precision products: the matrix pipe is ~1/5 busy, the gather side bounds
-            e.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                     frac=round(gbs / HBM_PEAK_GBS, 4),
-                     mfma_frac_of_f16_peak=round(3.0 * tf / F16_MFMA_PEAK_TFLOPS, 4))
-        if s["k3_launches"]:
+             "alg_bytes_per_launch": s["bytes_alg"] / s["launches"]}
+        e.update(_roofs(name, s["flops"], s["bytes_alg"], s["time_s"]))
+        rec = pmc_record(name)
+        e["traffic"] = None if rec is None else rec["hbm_bytes_per_launch"]
+        if rec is not None:
+            e["traffic_source"] = {"file": rec["file"], "commit": rec["commit"]}
+        if s.get("k3_launches"):
             e["k3_only"] = {"launches_per_step": s["k3_launches"] / steps,
                             "TFLOPs": round(s["k3_flops"] / max(s["k3_time_s"], 1e-12) / 1e12, 3),
                             "ms_per_step": round(s["k3_time_s"] / steps * 1e3, 3)}
@@ -73,19 +112,33 @@ def roofline_object(per_kernel, steps):
     out["conv_ms_per_step"] = round(sum(per_kernel[n]["time_s"] for n in names) / steps * 1e3, 3)
     if len(names) > 1:
         out["other_conv_kernel"] = entry(names[1], per_kernel[names[1]])
+    if len(names) > 2:
+        out["more_conv_kernels"] = [entry(n, per_kernel[n]) for n in names[2:]]
     sp = per_kernel.get("k_split_rows")
-    if sp:     # operand preparation of the split kernel (one pass per conv input, not per gather)
+    if sp:     # operand preparation of the split kernels (one pass per conv input, not per gather)
         out["operand_split"] = {"kernel": "k_split_rows", "launches_per_step": sp["launches"] / steps,
                                 "ms_per_step": round(sp["time_s"] / steps * 1e3, 3),
                                 "alg_GBps": round(sp["bytes_alg"] / sp["time_s"] / 1e9, 1),
                                 "traffic": pmc_traffic("k_split_rows")}
+    if classes:
+        rows = []
+        for (cls, kern), s in sorted(classes.items(), key=lambda kv: -kv[1]["time_s"]):
+            r = {"class": cls, "kernel": kern, "launches_per_step": s["launches"] / steps,
+                 "ms_per_step": round(s["time_s"] / steps * 1e3, 3),
+                 "avg_launch_us": round(s["time_s"] / s["launches"] * 1e6, 1)}
+            r.update(_roofs(kern, s["flops"], s["bytes_alg"], s["time_s"]))
+            rows.append(r)
+        out["by_layer_class"] = rows
     return out
 
 
-def build_net(n_infers, in_channels, device, heavy=False):
+# ------------------------------------------------------------------------------------------------------
+# workload
+# ------------------------------------------------------------------------------------------------------
+def build_net(n_infers, in_channels, device, heavy=False, n_classes=20):
     from pasco_amd.graph import PascoNet
     torch.manual_seed(1234)
-    net = PascoNet(n_classes=20, n_infers=n_infers, in_channels=in_channels, f=64, num_queries=100,
+    net = PascoNet(n_classes=n_classes, n_infers=n_infers, in_channels=in_channels, f=64, num_queries=100,
                    heavy_decoder=heavy)
     g = torch.Generator().manual_seed(4321)
     for m in net.modules():
@@ -113,69 +166,163 @@ def run_scene(net, scene, teacher, window=None):
     return ret, panop
 
 
-def cpu_baseline(n_infers, in_channels, n1_full, budget_s=30.0):
-    """Same graph, oracle backend (C + OpenMP) + torch CPU for the dense parts, host cores only."""
+def run_scene_subnet_heads(net, scene, teacher):
+    """Config C4 step: shared trunk on every rank, this rank's subnet heads, all-gather, ensembling."""
+    from pasco_amd.graph.dist import subnet_parallel_forward
+    x = net.prepare_input(scene.in_feats, scene.in_coords)
+    ret = subnet_parallel_forward(net, x, scene.global_min_Cs, scene.global_max_Cs, scene.min_Cs, scene.max_Cs,
+                                  keep_override=teacher)
+    ssc_conf, sem_probs, panop = net.ensemble(ret, scene.Ts)
+    return ret, panop
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(n_infers, in_channels):
+    """Same graph, oracle backend (C + OpenMP) + torch CPU for the dense parts, host cores only: one warm-up
+    scene on a 128x128x16 grid (thread pools, page faults, weight operand caches), then ONE full S10 scene timed."""
     from oracle.build import build_oracle
     from pasco_amd.me import backend
     from pasco_amd.me.backend import CBackend
     from pasco_amd.graph.synth import make_scene, TeacherKeep
     cores = os.cpu_count() or 1
-    torch.set_num_threads(min(cores, 128))
+    torch.set_num_threads(cores)
     backend.register_checker_backend(CBackend(build_oracle(), "pho_", "cpu"))
     try:
         net = build_net(n_infers, in_channels, "cpu")
         small = make_scene(0, n_infers=n_infers, in_channels=in_channels, grid=(128, 128, 16))
         tk = TeacherKeep(small, "cpu")
         with torch.no_grad():
-            t0 = time.time()
             run_scene(net, small, tk)
-            t_small = time.time() - t0
-        n1_small = int(small.occ.sum())
-        ratio = n1_full / n1_small
-        if t_small * ratio <= budget_s:
-            full = make_scene(0, n_infers=n_infers, in_channels=in_channels)
-            tk = TeacherKeep(full, "cpu")
-            with torch.no_grad():
-                t0 = time.time()
-                run_scene(net, full, tk)
-                t_full = time.time() - t0
-            return dict(value=1.0 / t_full, unit="scenes/s", cores=min(cores, 128), kind="port",
-                        sample=f"1 full S10 scene (seed 0, M={n_infers}), {t_full:.2f} s, no warm-up; "
-                               "oracle C/OpenMP sparse ops + torch-CPU dense ops")
-        return dict(value=1.0 / (t_small * ratio), unit="scenes/s", cores=min(cores, 128), kind="port",
-                    sample=f"1 scene on a 128x128x16 grid ({n1_small} occupied voxels, {t_small:.2f} s), scaled by "
-                           f"the occupied-voxel ratio {ratio:.2f} to S10; oracle C/OpenMP sparse ops + torch-CPU dense ops")
+        full = make_scene(0, n_infers=n_infers, in_channels=in_channels)
+        tk = TeacherKeep(full, "cpu")
+        with torch.no_grad():
+            t0 = time.time()
+            run_scene(net, full, tk)
+            t_full = time.time() - t0
+        return dict(value=round(1.0 / t_full, 5), unit="scenes/s", cores=cores, kind="port",
+                    sample=f"1 full S10 scene (seed 0, M={n_infers}, {int(full.occ.sum())} occupied voxels) in {t_full:.2f} s after a "
+                           f"warm-up scene on a 128x128x16 grid; oracle C/OpenMP sparse ops + torch-CPU dense ops; "
+                           f"{cpu_model()}, {cores} logical CPUs (OpenMP and torch both use all of them)")
     finally:
         backend.register_checker_backend(None)
+
+
+# ------------------------------------------------------------------------------------------------------
+# launcher
+# ------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """Launcher self-test (tests/test_dist_gloo.py): the process-group / fence / max-over-ranks / JSON plumbing on
+    CPU + gloo with a sleep instead of a scene.  Never a measurement: `data` says so."""
+    import torch.distributed as dist
+    from pasco_amd.graph.dist import timed_steps
+    if world > 1:
+        dist.init_process_group("gloo")
+    elapsed = timed_steps(lambda: time.sleep(0.005 * (1 + rank)), args.steps, args.warmup)
+    per_rank = [elapsed]
+    if world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, elapsed)
+        per_rank = box
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (launcher self-test, no compute)", "value": world * args.steps / elapsed,
+                          "unit": "steps/s", "n_gpus": world, "n_ranks": dist.get_world_size() if world > 1 else 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "per_rank_ms_per_step": [p / args.steps * 1e3 for p in per_rank],
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "dry-run (no compute)", "config": {"workload": "sleep"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False):
+    """Short timed row of another BASELINE.json configuration on this GPU (1 warm-up + `steps` scenes)."""
+    from pasco_amd.graph import fused
+    from pasco_amd.graph.synth import make_scene, TeacherKeep
+    net = build_net(n_infers, in_channels, device, n_classes=n_classes)
+    scene = make_scene(seed=0, n_infers=n_infers, in_channels=in_channels).to(device)
+    teacher = TeacherKeep(scene, device)
+    if unfused:
+        fused.set_fusion(False)
+    try:
+        with torch.no_grad():
+            run_scene(net, scene, teacher)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run_scene(net, scene, teacher)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+    finally:
+        if unfused:
+            fused.set_fusion(True)
+    return {"scenes_per_s": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": 1}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n-infers", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--mode", choices=["scenes", "subnet-heads"], default="scenes")
+    ap.add_argument("--n-infers", type=int, default=None, help="MIMO subnets (default 3; 8 with --mode subnet-heads)")
     ap.add_argument("--in-channels", type=int, default=283)
+    ap.add_argument("--n-classes", type=int, default=20)
     ap.add_argument("--heavy", action="store_true")
+    ap.add_argument("--scenes", type=int, default=4, help="different scenes the timed loop rotates over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short rows of the other configurations")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--conv-precision", choices=["f32", "f16x3"], default="f16x3",
                     help="f16x3 (default) = conv products as 3 x f16 split MFMA with fp32 accumulation (error vs fp64 <= "
                          "the fp32-MFMA path); f32 = every product on the exact fp32 MFMA")
     args = ap.parse_args()
+    if args.n_infers is None:
+        args.n_infers = 8 if args.mode == "subnet-heads" else 3
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (MI355X); the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
     if world > 1:
-        import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from pasco_amd.me.backend import hip_backend
     from pasco_amd.graph.synth import make_scene, TeacherKeep
@@ -184,9 +331,13 @@ def main():
     be = hip_backend()   # raises if libpascohip.so is missing
     from pasco_amd.graph import fused
     fused.set_conv_precision(args.conv_precision)
-    net = build_net(args.n_infers, args.in_channels, device, heavy=args.heavy)
-    scene = make_scene(seed=rank, n_infers=args.n_infers, in_channels=args.in_channels).to(device)
-    teacher = TeacherKeep(scene, device)
+    net = build_net(args.n_infers, args.in_channels, device, heavy=args.heavy, n_classes=args.n_classes)
+    heads = args.mode == "subnet-heads"
+    # scenes-mode: rank r owns its own scenes; subnet-heads: every rank works on the SAME scene sequence
+    seeds = [(0 if heads else rank * args.scenes) + i for i in range(args.scenes)]
+    scenes = [make_scene(seed=s, n_infers=args.n_infers, in_channels=args.in_channels).to(device) for s in seeds]
+    teachers = [TeacherKeep(sc, device) for sc in scenes]
+    step_fn = run_scene_subnet_heads if (heads and world > 1) else (lambda n, s, t, w=None: run_scene(n, s, t, w))
     prof = ConvProfiler()
     prof.wrap(be)
 
@@ -196,13 +347,14 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            out, _ = run_scene(net, scene, teacher)
+        for i in range(args.warmup):
+            out, _ = (step_fn(net, scenes[i % len(scenes)], teachers[i % len(scenes)]))
         n1 = int(out["sem_logits_at_scales"][1][0].F.shape[0])
         window = []
         prof.enabled = not args.no_profile
         # the cyclic garbage collector is paused over the timed steps (as a serving loop would): a generation-2
-        # pass over the step's many small Python objects costs ~27 ms whenever it lands inside a step
+        # pass over the step's many small Python objects costs ~27 ms whenever it lands inside a step; the same
+        # loop with the collector running is reported beside it (`gc_enabled`)
         import gc
         gc.collect()
         gc.freeze()              # model / caches built during warm-up: out of the collector's reach from here on
@@ -212,8 +364,12 @@ def main():
         barrier()
         t0 = time.perf_counter()
         marks = [t0]
-        for _ in range(args.steps):
-            out, panop = run_scene(net, scene, teacher, window)
+        for i in range(args.steps):
+            j = i % len(scenes)
+            if heads and world > 1:
+                out, panop = step_fn(net, scenes[j], teachers[j])
+            else:
+                out, panop = run_scene(net, scenes[j], teachers[j], window)
             marks.append(time.perf_counter())      # host-side enqueue clock of each step (diagnostic, stderr only)
         barrier()
         elapsed = time.perf_counter() - t0
@@ -224,22 +380,39 @@ def main():
             per = [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])]
             print(f"[bench] per-step host ms: {per}", file=sys.stderr, flush=True)
 
+    per_rank = [elapsed]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        box = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(box, t)
+        per_rank = [float(b.item()) for b in box]
+        elapsed = max(per_rank)
+
+    single = world == 1
+    gc_row = None
+    if single:                    # the same loop with Python's collector running (what an unmanaged serving loop pays)
+        import gc
+        k3 = max(4, args.steps // 3)
+        with torch.no_grad():
+            gc.enable()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(k3):
+                run_scene(net, scenes[i % len(scenes)], teachers[i % len(scenes)])
+            torch.cuda.synchronize()
+            gc_row = {"ms_per_step": round((time.perf_counter() - t0) / k3 * 1e3, 3), "steps": k3}
 
     # the same step with every product on the exact fp32 MFMA, reported next to the headline
     exact = None
-    if args.conv_precision == "f16x3" and world == 1 and not args.no_exact:
+    if args.conv_precision == "f16x3" and single and not args.no_exact:
         fused.set_conv_precision("f32")
-        k2 = max(3, args.steps // 2)
+        k2 = max(4, args.steps // 3)
         with torch.no_grad():
-            run_scene(net, scene, teacher)
+            run_scene(net, scenes[0], teachers[0])
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(k2):
-                run_scene(net, scene, teacher)
+            for i in range(k2):
+                run_scene(net, scenes[i % len(scenes)], teachers[i % len(scenes)])
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / k2
         exact = {"value": round(1.0 / dt, 4), "unit": "scenes/s", "ms_per_step": round(dt * 1e3, 3), "steps": k2}
@@ -247,34 +420,66 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        value = world * args.steps / elapsed
+        scenes_done = args.steps if heads else world * args.steps     # subnet-heads: ONE scene per step for the whole job
+        value = scenes_done / elapsed
+        occ = int(scenes[0].occ.sum())
+        if heads:
+            metric = f"scenes/sec (256x256x32, ~10% occ) PaSCo MIMO-{args.n_infers}, one subnet head per GPU"
+            par = f"subnet-heads x{world}: trunk replicated, heads sharded, RCCL all-gather of per-voxel logits"
+        else:
+            metric = f"scenes/sec (256x256x32, ~10% occ) PaSCo MIMO-{args.n_infers}"
+            par = f"scene-parallel x{world}, no collective"
         res = {
-            "metric": f"scenes/sec (256x256x32, ~10% occ) PaSCo MIMO-{args.n_infers}",
-            "value": round(value, 4), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "metric": metric,
+            "value": round(value, 4), "unit": "scenes/s", "n_gpus": world,
+            "n_ranks_rccl": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "per_rank_ms_per_step": [round(p / args.steps * 1e3, 3) for p in per_rank],
+            "higher_is_better": True, "scaling": "strong" if heads else "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.conv_precision == "f32" else "f32 (conv products as 3 x f16 split MFMA, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"PaSCo MIMO M={args.n_infers} ({'heavy' if args.heavy else 'light'} decoder, f=64, "
-                                   f"100 queries, {args.in_channels}-ch points), S10 scene 256x256x32 "
-                                   f"({int(scene.occ.sum())} occupied voxels, {n1} kept at stride 1), 1 scene/step/GPU",
+                                   f"100 queries, {args.in_channels}-ch points, {args.n_classes} classes), S10 scenes 256x256x32 "
+                                   f"(seed {seeds[0]}: {occ} occupied voxels, {n1} kept at stride 1), "
+                                   f"{len(scenes)} different scenes rotated, 1 scene/step" + ("" if heads else "/GPU"),
                        "stages": "point MLP + voxel max, MIMO merge, sparse U-Net (encoder, dense bottleneck, "
                                  "generative decoder), mask transformer, semantic + panoptic ensembling "
                                  "(= Net.forward(return_ensemble=True) + its input stage)",
-                       "pruning": "teacher-forced", "parallelism": f"scene-parallel x{world}, no collective"},
+                       "pruning": "teacher-forced", "parallelism": par},
         }
-        unet_ms = sum(a.elapsed_time(b) for a, b in window) / max(len(window), 1)
-        res["unet_window_ms"] = round(unet_ms, 3)   # the reference's own "inference time" window (README.md:448-449)
-        res["unet_window_scenes_per_s"] = round(world * 1e3 / unet_ms, 4) if unet_ms > 0 else None
+        if heads:
+            res["bound_note"] = ("trunk replicated on every rank: speed-up over 1 GPU is bounded by (T + 8 H) / (T + H) "
+                                 "~ 2.2x at S10 (T ~ 2.1 TFLOP trunk, H ~ 0.43 TFLOP per subnet head; SURVEY.md 8(e))")
+        if window:
+            unet_ms = sum(a.elapsed_time(b) for a, b in window) / len(window)
+            res["unet_window_ms"] = round(unet_ms, 3)   # the reference's own "inference time" window (README.md:448-449)
+            res["unet_window_scenes_per_s"] = round(world * 1e3 / unet_ms, 4) if unet_ms > 0 else None
         if not args.no_profile:
-            per_kernel = prof.summary()
+            per_kernel, classes = prof.summary(by_class=True)
             if per_kernel:
-                res["roofline"] = roofline_object(per_kernel, args.steps)
+                res["roofline"] = roofline_object(per_kernel, args.steps, classes)
+        if gc_row is not None:
+            res["gc_enabled"] = gc_row
         if exact is not None:
             res["exact_fp32_mfma"] = exact
-        if not args.no_cpu_baseline and world == 1:
+        if single and not args.no_configs and not heads and not args.heavy and args.n_infers == 3:
+            del scenes, teachers, net, out, panop
+            torch.cuda.empty_cache()
+            rows = {}
+            for name, kw in (("mimo1_semantickitti", dict(n_infers=1, in_channels=283, n_classes=20)),
+                             ("mimo3_sscbench_kitti360", dict(n_infers=3, in_channels=8, n_classes=19)),
+                             ("mimo8_one_gpu", dict(n_infers=8, in_channels=283, n_classes=20)),
+                             ("mimo1_unfused_me_modules", dict(n_infers=1, in_channels=283, n_classes=20, unfused=True))):
+                try:
+                    rows[name] = short_row(device=device, **kw)
+                except Exception as e:  # a side row must never take the headline down
+                    rows[name] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
+            res["configs"] = rows
+        if not args.no_cpu_baseline and single:
             try:
-                res["cpu_baseline"] = cpu_baseline(args.n_infers, args.in_channels, int(scene.occ.sum()))
+                res["cpu_baseline"] = cpu_baseline(args.n_infers, args.in_channels)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "unit": "scenes/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}

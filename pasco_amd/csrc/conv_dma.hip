@@ -24,6 +24,11 @@
 
 constexpr int DMA_KMAX = 32;   // kernel offsets one workgroup walks (its slice of the split over the offsets)
 
+// Development hook (tools/dma_ablate.py; results are WRONG with any bit set): 1 = skip the MFMAs, 2 = every gathered
+// row reads the zero line (no gather misses), 4 = every weight row reads row 0 of its slab, 8 = skip the fragment reads
+static int g_dma_ablate = 0;
+extern "C" void ph_conv_dma_set_ablate(int mask) { g_dma_ablate = mask; }
+
 // One workgroup = 256 threads = 4 waves (WM x WN), tile BM = WM*TM*32 = 128 rows x BN = WN*TN*32 channels,
 // 32 input channels per stage.
 template <int WM, int WN, int TM, int TN, bool EMIT>
@@ -131,7 +136,7 @@ __global__ void __launch_bounds__(HV_THREADS, 2) k_conv_dma(ConvArgsH a) {
         const int ix = idx[p];
         uint64_t v = in_base + (uint64_t)(uint32_t)(ix < 0 ? 0 : ix) * rsb + coff;
         asm volatile("" : "+v"(v));            // materialise before the select: a select, not a branch per row
-        src.a[p] = ix >= 0 ? v : zero_src;
+        src.a[p] = (ix >= 0 && !(a.ablate & 2)) ? v : zero_src;
       }
       src.w = w_base + (uint64_t)((int64_t)(k_begin + k) * wslab) + coff;
     };
@@ -146,7 +151,7 @@ __global__ void __launch_bounds__(HV_THREADS, 2) k_conv_dma(ConvArgsH a) {
 #pragma unroll
       for (int q = 0; q < B_PASSES; ++q) {
         char *dst = abuf + A_BYTES + (q * 32 + wave * 8) * 128;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(src.w + boff[q]),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(src.w + ((a.ablate & 4) ? 0u : boff[q])),
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
       }
     };
@@ -226,9 +231,9 @@ __global__ void __launch_bounds__(HV_THREADS, 2) k_conv_dma(ConvArgsH a) {
       // stage s from f0; fragments of stage s + 1 from buffer 1; DMA of stage s + 3 into buffer 1 afterwards
       DMA_WAIT_STAGE();
       prep(s + 3, ix, src);
-      readfrag(1, f1);
+      if (!(a.ablate & 8)) readfrag(1, f1);
       __builtin_amdgcn_sched_barrier(0);
-      mfma(f0);
+      if (!(a.ablate & 1)) mfma(f0);
       __builtin_amdgcn_sched_barrier(0);
       DMA_READS_DONE();
       fire(src, 1);
@@ -236,9 +241,9 @@ __global__ void __launch_bounds__(HV_THREADS, 2) k_conv_dma(ConvArgsH a) {
       // stage s + 1 from f1; fragments of stage s + 2 from buffer 0; DMA of stage s + 4 into buffer 0 afterwards
       DMA_WAIT_STAGE();
       prep(s + 4, ix, src);
-      readfrag(0, f0);
+      if (!(a.ablate & 8)) readfrag(0, f0);
       __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < nstages) mfma(f1);
+      if (s + 1 < nstages && !(a.ablate & 1)) mfma(f1);
       __builtin_amdgcn_sched_barrier(0);
       DMA_READS_DONE();
       fire(src, 0);
@@ -273,21 +278,31 @@ static int launch_dma(const ConvArgsH &a, hipStream_t st) {
   return 0;
 }
 
-__device__ __attribute__((aligned(256))) const uint32_t ph_dma_zero_line[64] = {0};   // absent neighbours read this
+// 256 zero bytes per device for rows without a neighbour: the one piece of device memory the library owns
+// (allocated at the first launch on a device, never inside a stream capture: convolutions are not captured)
+static const char *dma_zero_line() {
+  static const char *zero[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (zero[dev] == nullptr) {
+    void *p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;   // once per device
+    zero[dev] = (const char *)p;
+  }
+  return zero[dev];
+}
 
 // Takes the launch when the shape fits the DMA pipeline; returns -1 when the caller should use k_conv_h2.
 // `a` arrives fully prepared (tile-independent fields, ksplit / partial chosen by the caller for 128-row tiles).
 int ph_conv_dma_try(const ConvArgsH &a_in, int bn, hipStream_t st) {
   const int kper = (a_in.kvol + a_in.ksplit - 1) / a_in.ksplit;
   if (kper > DMA_KMAX) return -1;
-  static const char *zero = nullptr;
-  if (zero == nullptr) {
-    void *p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(ph_dma_zero_line)) != hipSuccess || p == nullptr) return -1;
-    zero = (const char *)p;
-  }
+  const char *zero = dma_zero_line();
+  if (zero == nullptr) return -1;
   ConvArgsH a = a_in;
   a.zero = zero;
+  a.ablate = g_dma_ablate;
   if (bn == 32) return launch_dma<4, 1, 1, 1>(a, st);
   if (bn == 64) return launch_dma<4, 1, 1, 2>(a, st);
   return launch_dma<2, 2, 2, 2>(a, st);

@@ -661,6 +661,7 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.n_row_tiles = a.n_col_tiles = 0;
   a.status = d->status;
   a.zero = nullptr;
+  a.ablate = 0;
   const int bn = d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128);
   const int64_t ncol = (d->cout + bn - 1) / bn;
   // tile height: the tallest tile that still gives >= 2 workgroups per CU (profiles/r1e_op_bench.json)

@@ -41,6 +41,7 @@ struct ConvArgsH {
   int osp_has;
   float act_pow2;             // 2^split_exp2: scale of the activation operand (mode 1 gather, emitted out_split)
   const char *zero;           // k_conv_dma: >= 256 zero bytes in device memory (rows without a neighbour read them)
+  int ablate;                 // k_conv_dma development hook (0 in production)
 };
 
 // conv_f16x3.hip: reduction + epilogue of a split over the kernel offsets (after a launch with args.ksplit > 1)
