@@ -27,20 +27,25 @@ constexpr int DMA_KMAX = 32;   // kernel offsets one workgroup walks (its slice 
 // Development hook (tools/dma_ablate.py; results are WRONG with any bit set): 1 = skip the MFMAs, 2 = every gathered
 // row reads the zero line (no gather misses), 4 = every weight row reads row 0 of its slab, 8 = skip the fragment reads
 static int g_dma_ablate = 0;
-extern "C" void ph_conv_dma_set_ablate(int mask) { g_dma_ablate = mask; }
+static int g_dma_tall = 1;     // 0: 128-row tiles only (A/B comparison)
+extern "C" void ph_conv_dma_set_ablate(int mask) { g_dma_ablate = mask & 0xFF; g_dma_tall = (mask & 0x100) ? 0 : 1; }
 
-// One workgroup = 256 threads = 4 waves (WM x WN), tile BM = WM*TM*32 = 128 rows x BN = WN*TN*32 channels,
-// 32 input channels per stage.
-template <int WM, int WN, int TM, int TN, bool EMIT>
-__global__ void __launch_bounds__(HV_THREADS, 2) k_conv_dma(ConvArgsH a) {
+// One workgroup = WAVES (4 or 8) waves as WM x WN, tile BM = WM*TM*32 rows (128 / 256) x BN = WN*TN*32 channels,
+// 32 input channels per stage.  Everything that crosses the vector-memory path (gathered rows AND the weight tile of
+// every workgroup) is paid at ~32 B/clk/CU whether it hits L1 / L2 or not (profiles/README.md, k_conv_dma ablation):
+// the 256-row tile halves the weight bytes per output row.
+template <int WAVES, int WM, int WN, int TM, int TN, bool EMIT>
+__global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
+  constexpr int NT = WAVES * 64;
   constexpr int BM = WM * TM * 32;
   constexpr int BN = WN * TN * 32;
-  static_assert(WM * WN == 4 && BM == 128, "tile shape");
+  constexpr int RPP = NT / 8;                // tile rows one DMA pass covers: every wave 8 rows x 128 B
+  static_assert(WM * WN == WAVES && BM == 4 * RPP && BN % RPP == 0, "tile shape");
   constexpr int A_BYTES = BM * 128;
   constexpr int B_BYTES = BN * 128;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int A_PASSES = BM / 32;          // one pass = 32 tile rows = 4 waves x (8 rows x 128 B)
-  constexpr int B_PASSES = BN / 32;
+  constexpr int A_PASSES = BM / RPP;
+  constexpr int B_PASSES = BN / RPP;
   constexpr int L = A_PASSES + B_PASSES;     // DMA instructions per thread and stage
   __shared__ __attribute__((aligned(128))) char lds[2 * STAGE + DMA_KMAX * BM * 4];
 
@@ -81,19 +86,19 @@ __global__ void __launch_bounds__(HV_THREADS, 2) k_conv_dma(ConvArgsH a) {
 
   if (nstages > 0) {
     // ---- neighbour indices of the tile -> LDS (the only ordinary loads before the epilogue) ----------------
-    // layout [offset][l_r = tile row mod 32][p = tile row / 32]: the four rows one thread feeds are one 16-byte read
+    // layout [offset][l_r = tile row mod RPP][p = tile row / RPP]: the four rows one thread feeds are one 16-byte read
     int *idx_lds = reinterpret_cast<int *>(lds + 2 * STAGE);
-    for (int i = tid; i < kcount * BM; i += HV_THREADS) {
+    for (int i = tid; i < kcount * BM; i += NT) {
       const int k = i / BM, r = i - k * BM;
       const int64_t row = m0 + r;
       int idx = -1;
       if (row < a.n_out) idx = a.nbr ? a.nbr[(int64_t)(k_begin + k) * a.n_out + row] : (int)row;
-      idx_lds[k * BM + (r & 31) * 4 + (r >> 5)] = idx;
+      idx_lds[k * BM + (r % RPP) * 4 + (r / RPP)] = idx;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // ---- DMA geometry of this thread: tile row l_r + 32 p, 16-byte slot l_j; source chunk swizzled ----------
+    // ---- DMA geometry of this thread: tile row l_r + RPP p, 16-byte slot l_j; source chunk swizzled ---------
     const int l_j = tid & 7;
     const int l_r = tid >> 3;
     const uint32_t sj16 = (uint32_t)((l_j ^ ((l_r >> 1) & 7)) << 4);
@@ -103,7 +108,7 @@ __global__ void __launch_bounds__(HV_THREADS, 2) k_conv_dma(ConvArgsH a) {
     uint32_t boff[B_PASSES];   // byte offset of this thread's weight rows inside one offset's [cout][rs] slab
 #pragma unroll
     for (int q = 0; q < B_PASSES; ++q) {
-      int n = n0 + l_r + q * 32;
+      int n = n0 + l_r + q * RPP;
       n = n < cout ? n : cout - 1;   // columns >= cout are never stored: any finite row will do
       boff[q] = (uint32_t)n * rsb;
     }
@@ -144,13 +149,13 @@ __global__ void __launch_bounds__(HV_THREADS, 2) k_conv_dma(ConvArgsH a) {
       char *abuf = lds + buf * STAGE;
 #pragma unroll
       for (int p = 0; p < A_PASSES; ++p) {
-        char *dst = abuf + (p * 32 + wave * 8) * 128;   // wave-uniform; the DMA adds lane * 16
+        char *dst = abuf + (p * RPP + wave * 8) * 128;   // wave-uniform; the DMA adds lane * 16
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)src.a[p],
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
       }
 #pragma unroll
       for (int q = 0; q < B_PASSES; ++q) {
-        char *dst = abuf + A_BYTES + (q * 32 + wave * 8) * 128;
+        char *dst = abuf + A_BYTES + (q * RPP + wave * 8) * 128;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(src.w + ((a.ablate & 4) ? 0u : boff[q])),
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
       }
@@ -257,7 +262,7 @@ __global__ void __launch_bounds__(HV_THREADS, 2) k_conv_dma(ConvArgsH a) {
   h2_store_tile<TM, TN, EMIT>(a, acc, m0, n0, wm, wn, h, l31);
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WAVES, int WM, int WN, int TM, int TN>
 static int launch_dma(const ConvArgsH &a, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   ConvArgsH args = a;
@@ -267,14 +272,14 @@ static int launch_dma(const ConvArgsH &a, hipStream_t st) {
   const int grid = ((ntiles + 7) / 8) * 8;
   const bool emit = args.out_split != nullptr && args.ksplit == 1;
   if (emit)
-    hipLaunchKernelGGL((k_conv_dma<WM, WN, TM, TN, true>), dim3(grid, 1), dim3(HV_THREADS), 0, st, args);
+    hipLaunchKernelGGL((k_conv_dma<WAVES, WM, WN, TM, TN, true>), dim3(grid, 1), dim3(WAVES * 64), 0, st, args);
   else
-    hipLaunchKernelGGL((k_conv_dma<WM, WN, TM, TN, false>), dim3(grid, args.ksplit), dim3(HV_THREADS), 0, st, args);
+    hipLaunchKernelGGL((k_conv_dma<WAVES, WM, WN, TM, TN, false>), dim3(grid, args.ksplit), dim3(WAVES * 64), 0, st, args);
   PH_LAUNCH_CHECK();
   if (args.ksplit > 1) {
     if (int rc = ph_launch_splitk_epilogue(args, st)) return rc;
   }
-  ph_record_cfg(2, BM, BN, 32, args.ksplit, emit ? 1 : 0, 4, 4);
+  ph_record_cfg(2, BM, BN, 32, args.ksplit, emit ? 1 : 0, 4, WAVES);
   return 0;
 }
 
@@ -303,7 +308,10 @@ int ph_conv_dma_try(const ConvArgsH &a_in, int bn, hipStream_t st) {
   ConvArgsH a = a_in;
   a.zero = zero;
   a.ablate = g_dma_ablate;
-  if (bn == 32) return launch_dma<4, 1, 1, 1>(a, st);
-  if (bn == 64) return launch_dma<4, 1, 1, 2>(a, st);
-  return launch_dma<2, 2, 2, 2>(a, st);
+  // 256-row tiles (8 waves, one workgroup per CU) when they still cover every CU about twice; else 128-row tiles
+  const int64_t ncol = (a.cout + bn - 1) / bn;
+  const bool tall = bn >= 64 && ((a.n_out + 255) / 256) * ncol * a.ksplit >= 2 * 256 && g_dma_tall;
+  if (bn == 32) return launch_dma<4, 4, 1, 1, 1>(a, st);
+  if (bn == 64) return tall ? launch_dma<8, 8, 1, 1, 2>(a, st) : launch_dma<4, 4, 1, 1, 2>(a, st);
+  return tall ? launch_dma<8, 4, 2, 2, 2>(a, st) : launch_dma<4, 2, 2, 2, 2>(a, st);
 }

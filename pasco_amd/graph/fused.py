@@ -187,8 +187,12 @@ def prepare_batched_weights(w: torch.Tensor):
     B, Q, D = w.shape
     w = w.detach()
     e = 13 - torch.frexp(w.abs().amax())[1]                        # device int: largest magnitude just below 2^14
-    w_split = be.split_rows(torch.ldexp(w, e).reshape(B * Q, D).contiguous(), exp2=0)
-    unscale = torch.ldexp(torch.ones(Q, device=w.device), -e).contiguous()
+    # exact powers of two built from the exponent bits (torch.ldexp / pow on the GPU are not exact)
+    e = e.to(torch.int32).clamp(-100, 100)
+    up = ((e + 127) << 23).view(torch.float32)
+    down = ((127 - e) << 23).view(torch.float32)
+    w_split = be.split_rows((w * up).reshape(B * Q, D).contiguous(), exp2=0)
+    unscale = (torch.ones(Q, device=w.device) * down).contiguous()
     return w_split, unscale
 
 

@@ -383,7 +383,7 @@ class CBackend:
         else:
             wmax = float(w.abs().max())
             e = 0 if wmax == 0.0 else 13 - int(torch.frexp(torch.tensor(wmax))[1])
-        scaled = torch.ldexp(w, torch.tensor(e)).transpose(1, 2).contiguous()
+        scaled = (w * float(2.0 ** e)).transpose(1, 2).contiguous()   # exact power of two (torch.ldexp goes through pow on the GPU: inexact)
         hi = scaled.to(torch.float16)
         lo = (scaled - hi.float()).to(torch.float16)
         return hi.contiguous(), lo.contiguous(), float(2.0 ** (-e))
@@ -423,7 +423,7 @@ class CBackend:
             wmax = float(w.abs().max())
             e = 0 if wmax == 0.0 else 13 - int(torch.frexp(torch.tensor(wmax))[1])
         k, cin, cout = w.shape
-        rows = torch.ldexp(w, torch.tensor(e, device=w.device)).transpose(1, 2).contiguous().view(k * cout, cin)
+        rows = (w * float(2.0 ** e)).transpose(1, 2).contiguous().view(k * cout, cin)   # exact power of two
         return self.split_rows(rows, exp2=0), float(2.0 ** (-e))
 
     def split_capable(self) -> bool:
