@@ -27,8 +27,8 @@ constexpr int DMA_KMAX = 32;   // kernel offsets one workgroup walks (its slice 
 // Development hook (tools/dma_ablate.py; results are WRONG with any bit set): 1 = skip the MFMAs, 2 = every gathered
 // row reads the zero line (no gather misses), 4 = every weight row reads row 0 of its slab, 8 = skip the fragment reads
 static int g_dma_ablate = 0;
-static int g_dma_tall = 1;     // 0: 128-row tiles only (A/B comparison)
-extern "C" void ph_conv_dma_set_ablate(int mask) { g_dma_ablate = mask & 0xFF; g_dma_tall = (mask & 0x100) ? 0 : 1; }
+static int g_dma_tall = 0;     // 256-row / 8-wave tiles: measured no faster (one workgroup per CU convoys); kept for experiments
+extern "C" void ph_conv_dma_set_ablate(int mask) { g_dma_ablate = mask & 0xFF; g_dma_tall = (mask & 0x100) ? 1 : 0; }
 
 // One workgroup = WAVES (4 or 8) waves as WM x WN, tile BM = WM*TM*32 rows (128 / 256) x BN = WN*TN*32 channels,
 // 32 input channels per stage.  Everything that crosses the vector-memory path (gathered rows AND the weight tile of
@@ -233,26 +233,27 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
     fire(src, 0);
     ix = load_idx(3);            // index reads run one step ahead of the address arithmetic that consumes them
     for (int s = 0; s < nstages; s += 2) {
-      // stage s from f0; fragments of stage s + 1 from buffer 1; DMA of stage s + 3 into buffer 1 afterwards
+      // stage s from f0; fragments of stage s + 1 from buffer 1, then the DMA of stage s + 3 into buffer 1 is FIRED
+      // BEFORE the matrix work of stage s so that it flies underneath it
       DMA_WAIT_STAGE();
       prep(s + 3, ix, src);
       if (!(a.ablate & 8)) readfrag(1, f1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(a.ablate & 1)) mfma(f0);
-      __builtin_amdgcn_sched_barrier(0);
       DMA_READS_DONE();
       fire(src, 1);
       ix = load_idx(s + 4);
-      // stage s + 1 from f1; fragments of stage s + 2 from buffer 0; DMA of stage s + 4 into buffer 0 afterwards
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(a.ablate & 1)) mfma(f0);
+      __builtin_amdgcn_sched_barrier(0);
+      // stage s + 1 from f1; fragments of stage s + 2 from buffer 0; DMA of stage s + 4 into buffer 0
       DMA_WAIT_STAGE();
       prep(s + 4, ix, src);
       if (!(a.ablate & 8)) readfrag(0, f0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < nstages && !(a.ablate & 1)) mfma(f1);
-      __builtin_amdgcn_sched_barrier(0);
       DMA_READS_DONE();
       fire(src, 0);
       ix = load_idx(s + 5);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < nstages && !(a.ablate & 1)) mfma(f1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail loads: nothing may land after the epilogue starts
 #undef DMA_WAIT_STAGE

@@ -586,9 +586,13 @@ struct ConvHKnobs {
   int cfg_bm = 0, cfg_kc = 0;
   bool has_ksplit = false;
   int ksplit = 0;
+  bool dma_all = false;
   bool dma_on = true;      // PASCO_CONV_DMA=0: keep every launch on the register-staged k_conv_h2 (A/B comparisons)
   ConvHKnobs() {
-    if (const char *e = getenv("PASCO_CONV_DMA")) dma_on = atoi(e) != 0;
+    if (const char *e = getenv("PASCO_CONV_DMA")) {
+      dma_on = atoi(e) != 0;
+      dma_all = atoi(e) == 2;      // 2: every tile width on the DMA kernel
+    }
     if (const char *e = getenv("PASCO_CONVH_MID")) mid_on = atoi(e) != 0;
     if (const char *e = getenv("PASCO_CONVH_CFG")) has_cfg = sscanf(e, "%d,%d", &cfg_bm, &cfg_kc) >= 1;
     if (const char *e = getenv("PASCO_CONVH_KSPLIT")) {
@@ -708,7 +712,8 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   }
   // default for pre-split operands: the LDS-DMA pipelined kernel (conv_dma.hip; 128-row tiles, parallelism of few-row
   // layers from the split over the offsets chosen above); it declines slices of more than 32 offsets
-  if (pre && knobs.dma_on && !env) {
+  // measured (profiles/README.md, round 2): 6-9 % faster than k_conv_h2 on 128-channel-wide tiles, a few % slower on 64-wide
+  if (pre && knobs.dma_on && !env && (bn == 128 || knobs.dma_all)) {
     ConvArgsH b = a;
     if (bm != 128) {        // the choice above was made for a shorter tile: redo the split decision for 128 rows
       const int64_t t128 = ((d->n_out + 127) / 128) * ncol;

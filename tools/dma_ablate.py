@@ -41,7 +41,7 @@ for key, rec in want.items():
     if rec is None:
         continue
     x, weight, nbr, n_out, kw = rec
-    for mask, name in ((0x100, "128-row tiles: full"), (0x10F, "128-row tiles: hot-line DMA only"), (0, "full"), (1, "no MFMA"), (2, "A from zero line"), (4, "W one row"), (6, "A zero + W one row"),
+    for mask, name in ((0x100, "256-row tiles: full"), (0x10F, "256-row tiles: hot-line DMA only"), (0, "full"), (1, "no MFMA"), (2, "A from zero line"), (4, "W one row"), (6, "A zero + W one row"),
                        (8, "no fragment reads"), (9, "no MFMA, no frag reads"), (15, "DMA of hot lines only")):
         lib.ph_conv_dma_set_ablate(mask)
         ts = []
