@@ -267,8 +267,9 @@ def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False):
     net = build_net(n_infers, in_channels, device, n_classes=n_classes)
     scene = make_scene(seed=0, n_infers=n_infers, in_channels=in_channels).to(device)
     teacher = TeacherKeep(scene, device)
-    if unfused:
+    if unfused:                 # INTEGRATION.md route (a): reference-style module sequence, exact fp32 products
         fused.set_fusion(False)
+        fused.set_conv_precision("f32")
     try:
         with torch.no_grad():
             run_scene(net, scene, teacher)
@@ -281,6 +282,7 @@ def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False):
     finally:
         if unfused:
             fused.set_fusion(True)
+            fused.set_conv_precision("f16x3")
     return {"scenes_per_s": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": 1}
 
 

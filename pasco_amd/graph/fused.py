@@ -21,6 +21,7 @@ from ..me.modules import MinkowskiBatchNorm, _ConvBase
 
 _CONV_PRECISION = "f16x3"
 _PRESPLIT = True     # f16x3 operands pre-split once per tensor (mma_mode 2) instead of per gather (mode 1)
+_FUSION = True       # False: route (a) of INTEGRATION.md - every block as the reference's own module sequence
 MIN_ROWS_LINEAR = 16384    # tall-operand threshold above which linear layers run on the convolution kernel
 
 
@@ -48,6 +49,56 @@ def set_conv_precision(mode: str) -> None:
 
 def conv_precision() -> str:
     return _CONV_PRECISION
+
+
+def set_fusion(on: bool) -> None:
+    """False = the UNFUSED drop-in route (INTEGRATION.md route (a)): `conv` runs what the reference's module trees
+    launch on `pasco_amd.me` - MinkowskiBatchNorm, MinkowskiReLU / LeakyReLU, the plain `MinkowskiConvolution`
+    forward (exact fp32 products, bias only), a separate residual add - and the tall linear layers run as torch
+    modules.  Same numbers as the fused graph to fp32 rounding; it exists so that the drop-in route has a GPU test
+    and a benchmark row of its own."""
+    global _FUSION
+    _FUSION = bool(on)
+
+
+def fusion() -> bool:
+    return _FUSION
+
+
+def _act_rows(F: torch.Tensor, act: int, slope: float) -> torch.Tensor:
+    if act == ACT_RELU:
+        return torch.relu(F)
+    if act == ACT_LEAKY:
+        return torch.nn.functional.leaky_relu(F, slope)
+    return F
+
+
+def _conv_unfused(x, mod, pro_bn, pro_act, epi_bn, epi_act, epi2_bn, residual, res_act, slope, out_key, nbr):
+    """The module-by-module sequence (route (a)): BN -> act -> conv (+ bias) -> BN -> act -> BN -> (+ residual) -> act."""
+    mgr = x.coordinate_manager
+    y = x
+    if pro_bn is not None:
+        y = pro_bn(y) if isinstance(pro_bn, MinkowskiBatchNorm) else SparseTensor(
+            pro_bn(y.F), coordinate_map_key=y.coordinate_map_key, coordinate_manager=mgr)
+    if pro_act != ACT_NONE:
+        y = SparseTensor(_act_rows(y.F, pro_act, slope), coordinate_map_key=y.coordinate_map_key, coordinate_manager=mgr)
+    if out_key is None:
+        y = mod(y)                      # MinkowskiConvolution.forward: its own maps, plain launch
+        out_key = y.coordinate_map_key
+        F = y.F
+    else:                               # the caller fixed the output map (pruned generative expansion)
+        bias = mod.bias.detach().reshape(-1).contiguous() if mod.bias is not None else None
+        F = mgr.backend().conv_fwd(y.F.contiguous(), mod.kernel.detach().contiguous(), nbr, mgr.size(out_key), bias=bias)
+    bn_rows = lambda bn, t: (bn.bn if isinstance(bn, MinkowskiBatchNorm) else bn)(t)
+    if epi_bn is not None:
+        F = bn_rows(epi_bn, F)
+    F = _act_rows(F, epi_act, slope)
+    if epi2_bn is not None:
+        F = bn_rows(epi2_bn, F)
+    if residual is not None:
+        F = F + residual
+    F = _act_rows(F, res_act, slope)
+    return SparseTensor(F, coordinate_map_key=out_key, coordinate_manager=mgr)
 
 
 def _split_of(w, be):
@@ -81,7 +132,7 @@ def split_input(x: SparseTensor, be, ps, pb, pro_act, slope):
 def split_rows_2d(x2d: torch.Tensor):
     """Pre-split operand of a tall [N, cin] matrix for several `linear_rows` calls on it (None when the split
     path does not apply)."""
-    if not (_kernel_device(x2d.device) and _CONV_PRECISION == "f16x3" and _PRESPLIT and x2d.shape[1] % 8 == 0):
+    if not (_FUSION and _kernel_device(x2d.device) and _CONV_PRECISION == "f16x3" and _PRESPLIT and x2d.shape[1] % 8 == 0):
         return None
     from ..me.backend import backend_for
     return backend_for(x2d.device).split_rows(x2d.contiguous())
@@ -103,7 +154,7 @@ def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_o
     dev = x2d.device if x2d is not None else in_split.device
     be = None
     min_rows = MIN_ROWS_LINEAR if min_rows is None else min_rows
-    if _kernel_device(dev) and n >= min_rows and _CONV_PRECISION == "f16x3":
+    if _FUSION and _kernel_device(dev) and n >= min_rows and _CONV_PRECISION == "f16x3":
         from ..me.backend import backend_for
         be = backend_for(dev)
         if not be.split_supported(cin, cout):
@@ -144,7 +195,7 @@ def linear_bn_act(x2d: Optional[torch.Tensor], lin: nn.Linear, *, pro_bn=None, e
     n = x2d.shape[0] if x2d is not None else in_split.shape[0]
     dev = x2d.device if x2d is not None else in_split.device
     min_rows = MIN_ROWS_LINEAR if min_rows is None else min_rows
-    if not (_kernel_device(dev) and n >= min_rows):
+    if not (_FUSION and _kernel_device(dev) and n >= min_rows):
         assert x2d is not None
         y = x2d if pro_bn is None else pro_bn(x2d)
         y = lin(y)
@@ -266,6 +317,9 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     reader) the fp32 result is not written at all and a `SplitRows` is returned - when the split path does not
     apply, a normal SparseTensor comes back.  `x` may itself be a `SplitRows`."""
     mgr = x.coordinate_manager
+    if not _FUSION:
+        assert not isinstance(x, SplitRows)
+        return _conv_unfused(x, mod, pro_bn, pro_act, epi_bn, epi_act, epi2_bn, residual, res_act, slope, out_key, nbr)
     if out_key is None:
         out_key, nbr = mod._maps(x)
     n_out = mgr.size(out_key)
@@ -314,4 +368,4 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     return y
 
 
-__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "linear_rows", "split_rows_2d", "batched_rows_matmul", "prepare_batched_weights", "linear_bn_act", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]
+__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "set_fusion", "fusion", "linear_rows", "split_rows_2d", "batched_rows_matmul", "prepare_batched_weights", "linear_bn_act", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]

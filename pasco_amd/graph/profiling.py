@@ -11,6 +11,21 @@ from typing import List
 
 import torch
 
+KERNEL_NAMES = {0: "k_conv_mfma", 1: "k_conv_f16x3", 2: "k_conv_h2", 3: "k_conv_rl", 4: "k_conv_dma"}
+
+
+def layer_class(kvol: int, cin: int, cout: int) -> str:
+    """Layer classes of the per-class roofline table (bench.py): by kernel volume and width."""
+    if kvol == 27:
+        return f"k3 C={max(cin, cout)}"
+    if kvol > 27:
+        return "dense bottleneck (implicit GEMM, k > 27)"
+    if kvol == 8:
+        return "k2 strided / generative transposed"
+    if kvol == 1:
+        return "k1 tall (linear / 1x1)" if max(cin, cout) >= 256 else "k1 (1x1)"
+    return f"k{kvol}"
+
 
 class ConvProfiler:
     def __init__(self):
@@ -38,10 +53,9 @@ class ConvProfiler:
             else:
                 kvol, cout = (1 if weight.dim() == 2 else weight.shape[0]), weight.shape[-1]
             n_in, cin = tuple(x.shape) if x is not None else kw["xshape"]
+            kid = backend.conv_last_config()["kernel"]          # which kernel the library actually launched
             prof.records.append(dict(e0=e0, e1=e1, nbr=nbr, n_in=n_in, n_out=n_out, cin=cin,
-                                     cout=cout, kvol=kvol,
-                                     kernel=("k_conv_mfma" if kw.get("split") is None else
-                                             ("k_conv_h2" if len(kw["split"]) == 2 else "k_conv_f16x3"))))
+                                     cout=cout, kvol=kvol, kernel=KERNEL_NAMES.get(kid, f"kernel{kid}")))
             return out
 
         inner_split = backend.split_rows
@@ -61,9 +75,9 @@ class ConvProfiler:
         backend.split_rows = split_rows
         backend._conv_profiled = True
 
-    def summary(self):
-        """Per kernel (`k_conv_h2` / `k_conv_f16x3` = split-precision products with pre-split / in-kernel split
-        operands, `k_conv_mfma` = exact fp32 MFMA, `k_split_rows` = the operand split of mode 2) over every
+    def summary(self, by_class: bool = False):
+        """Per kernel (`k_conv_dma` / `k_conv_h2` / `k_conv_f16x3` = split-precision products: LDS-DMA pipeline,
+        register-staged, in-kernel split; `k_conv_mfma` = exact fp32 MFMA; `k_split_rows` = the operand split) over every
         recorded launch (k=3 / k=2 strided / generative transposed / k=1 convolutions and the dense bottleneck's
         implicit GEMMs): launches, time, algorithmic flops / bytes (flops = 2 P Cin Cout,
         B_alg = 4 P Cin + 4 N_out Cout + 8 P + 4 K Cin Cout, P = pairs of the neighbour table, P = N for
@@ -71,6 +85,7 @@ class ConvProfiler:
         torch.cuda.synchronize()
         pair_cache = {}
         out = {}
+        classes = {}
         for r in self.records:
             dt = r["e0"].elapsed_time(r["e1"]) * 1e-3
             if r["kernel"] == "k_split_rows":      # operand preparation of mode 2: 4 B read + 4 B written per element
@@ -102,4 +117,12 @@ class ConvProfiler:
                 d["k3_launches"] += 1
                 d["k3_time_s"] += dt
                 d["k3_flops"] += fl
+            c = classes.setdefault((layer_class(r["kvol"], cin, cout), r["kernel"]),
+                                   dict(launches=0, time_s=0.0, flops=0.0, bytes_alg=0.0))
+            c["launches"] += 1
+            c["time_s"] += dt
+            c["flops"] += fl
+            c["bytes_alg"] += 4.0 * P * cin + 4.0 * n_out * cout + idx_bytes + 4.0 * r["kvol"] * cin * cout
+        if by_class:
+            return out, classes
         return out

@@ -17,9 +17,19 @@ def test_roofline_object_fields():
     per_kernel = {"k_conv_h2": _rec(1120, 0.27, 4.7e13, 8.1e11, k3=600),
                   "k_conv_mfma": _rec(40, 0.0066, 3.1e11, 1.1e10),
                   "k_split_rows": _rec(410, 0.0103, 0.0, 3.7e10)}
-    r = bench.roofline_object(per_kernel, steps=10)
-    assert r["kernel"] == "k_conv_h2" and r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["achieved"] - 8.1e11 / 0.27 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
+    classes = {("k3 C=64", "k_conv_h2"): dict(launches=60, time_s=0.05, flops=1.0e13, bytes_alg=2.0e11),
+               ("k3 C=256", "k_conv_dma"): dict(launches=60, time_s=0.04, flops=2.0e13, bytes_alg=0.6e11)}
+    r = bench.roofline_object(per_kernel, steps=10, classes=classes)
+    # both roofs are reported; `bound` is the one the kernel sits closer to
+    hbm_frac = 8.1e11 / 0.27 / 1e9 / 8000.0
+    mfma_frac = 3 * 4.7e13 / 0.27 / 1e12 / 2500.0
+    assert r["kernel"] == "k_conv_h2" and abs(r["alg_frac_of_hbm_peak"] - hbm_frac) < 1e-3
+    assert abs(r["mfma_frac_of_peak"] - mfma_frac) < 1e-3
+    assert r["bound"] == ("hbm" if hbm_frac >= mfma_frac else "mfma") and abs(r["frac"] - max(hbm_frac, mfma_frac)) < 1e-3
+    assert r["unit"] == ("GB/s" if r["bound"] == "hbm" else "TFLOP/s")
+    rows = {x["class"]: x for x in r["by_layer_class"]}
+    assert rows["k3 C=256"]["bound"] == "mfma" and rows["k3 C=256"]["kernel"] == "k_conv_dma"
+    assert rows["k3 C=64"]["bound"] == "hbm"
     assert r["launches_per_step"] == 112.0 and abs(r["avg_launch_us"] - 0.27 / 1120 * 1e6) < 0.01
     assert r["other_conv_kernel"]["kernel"] == "k_conv_mfma" and r["other_conv_kernel"]["bound"] == "mfma"
     assert r["other_conv_kernel"]["peak"] == 157.3
@@ -29,9 +39,13 @@ def test_roofline_object_fields():
 
 
 def test_committed_pmc_file_serves_the_traffic_field():
-    with open(os.path.join(ROOT, "profiles", "r1_pmc_conv.json")) as f:
-        kernels = json.load(f)["kernels"]
+    """`roofline.traffic` is a recorded PMC measurement: the newest profiles/r*_pmc_conv.json that lists the kernel,
+    with the commit it was taken at."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv.json")))
+    assert files
     for name in ("k_conv_h2", "k_conv_mfma", "k_split_rows"):
-        assert name in kernels and kernels[name]["hbm_bytes_per_launch"] > 0
-        assert bench.pmc_traffic(name) == kernels[name]["hbm_bytes_per_launch"]
+        rec = bench.pmc_record(name)
+        assert rec is not None and rec["hbm_bytes_per_launch"] > 0 and rec["file"].startswith("profiles/")
+        assert bench.pmc_traffic(name) == rec["hbm_bytes_per_launch"]
     assert bench.pmc_traffic("no_such_kernel") is None

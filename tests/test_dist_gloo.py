@@ -109,3 +109,28 @@ def test_subnet_parallel_heads_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[1] for r in res)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher re-executes itself under torch.distributed.run (one rank per
+    GPU) - exercised here on CPU / gloo through the hidden --dry-run mode (a sleep instead of a scene): the JSON line
+    carries the rank count the process group saw and the max-over-ranks time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--dry-run"], capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["n_ranks"] == 2 and r["steps"] == 3 and r["warmup"] == 1
+    assert len(r["per_rank_ms_per_step"]) == 2
+    # rank 1 sleeps twice as long: the slow rank sets the time
+    assert r["ms_per_step"] >= 0.9 * max(r["per_rank_ms_per_step"]) and r["ms_per_step"] >= 9.0
+    # single process: the same path without a process group
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "0", "--dry-run"],
+                         capture_output=True, text=True, timeout=120, env=env, cwd=root)
+    assert one.returncode == 0 and json.loads(one.stdout.strip().splitlines()[-1])["n_ranks"] == 1

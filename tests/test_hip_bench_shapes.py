@@ -56,7 +56,8 @@ def test_every_bench_instantiation_vs_oracle_and_fp64(hip, oracle, s10_net):
     table = []
     for key, (launches, checked, worst, m1) in sorted(chk.seen.items()):
         kid, bm, bn, kc, waves, ks, em = key
-        table.append(dict(kernel={0: "k_conv_mfma", 1: "k_conv_f16x3", 2: "k_conv_h2", 3: "k_conv_rl"}.get(kid, str(kid)),
+        from pasco_amd.graph.profiling import KERNEL_NAMES
+        table.append(dict(kernel=KERNEL_NAMES.get(kid, str(kid)),
                           bm=bm, bn=bn, kc=kc, waves=waves, ksplit=ks, emit=em, launches_per_step=launches,
                           checked=checked, worst_err_of_mean_abs=worst, bit_equal_mode1_shapes=sorted(m1)))
         print(table[-1])

@@ -109,9 +109,14 @@ def test_prune_union_stride_expand_properties(hip, oracle):
 
 
 @pytest.mark.parametrize("cfg", [dict(n_classes=19, in_channels=8, heavy=True, n_infers=2),
-                                 dict(n_classes=20, in_channels=16, heavy=False, n_infers=3)])
+                                 dict(n_classes=20, in_channels=16, heavy=False, n_infers=3),
+                                 dict(n_classes=19, in_channels=8, heavy=False, n_infers=3),    # BASELINE config 4
+                                 dict(n_classes=20, in_channels=16, heavy=False, n_infers=8)])  # config 5's arithmetic
 def test_config_shaped_graphs_vs_oracle(hip, oracle, cfg):
-    """configs[3]-like (SSCBench-KITTI360: 8 input channels, 19 classes) and MIMO-3 graphs: HIP == oracle."""
+    """BASELINE.json configurations on the HIP path against the oracle on a reduced grid: SSCBench-KITTI360-shaped
+    graphs (8 input channels, 19 classes; scripts/train_kitti360.py:115,152) with M = 2 (heavy decoder) and M = 3
+    (config 4), SemanticKITTI-shaped MIMO-3 (config 3) and the M = 8 graph whose heads config 5 spreads over 8 GPUs
+    (decoder_v3.py:211-229: occ_thres is only dereferenced when training, so M = 8 works at test time)."""
     from pasco_amd.graph import PascoNet
     from pasco_amd.me import backend
     torch.manual_seed(11)
@@ -147,3 +152,35 @@ def test_graft_entry_smoke(hip):
     """The driver's smoke(): one small MIMO-2 scene, HIP vs oracle."""
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_subnet_parallel_forward_nccl_world1(hip):
+    """The C4 exchange path (`subnet_parallel_forward`: trunk, own heads, variable-size all-gather of per-voxel
+    logits) under torch.distributed with the RCCL backend on one GPU / world size 1: same predictions as the plain
+    forward.  The 2-rank semantics are covered on gloo (tests/test_dist_gloo.py); 8 GPUs are the driver's to run."""
+    import socket
+    import torch.distributed as dist
+    from pasco_amd.graph import PascoNet
+    from pasco_amd.graph.dist import subnet_parallel_forward
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(13)
+        net = PascoNet(n_classes=20, n_infers=4, in_channels=16, f=16, num_queries=10, heavy_decoder=False).eval().to(dev)
+        sc = make_scene(3, n_infers=4, in_channels=16, grid=(40, 40, 8), occupancy=0.12).to(dev)
+        tk = TeacherKeep(sc, dev)
+        with torch.no_grad():
+            x = net.prepare_input(sc.in_feats, sc.in_coords)
+            args = (x, sc.global_min_Cs, sc.global_max_Cs, sc.min_Cs, sc.max_Cs)
+            ref = net(*args, keep_override=tk)
+            got = subnet_parallel_forward(net, *args, keep_override=tk)
+        assert len(got["panop_predictions"]) == 4
+        for a, b in zip(got["panop_predictions"], ref["panop_predictions"]):
+            assert torch.equal(a["voxel_logits"].C, b["voxel_logits"].C)
+            assert torch.allclose(a["voxel_logits"].F, b["voxel_logits"].F, rtol=1e-4, atol=1e-5)
+            assert torch.allclose(a["query_logits"], b["query_logits"], rtol=1e-4, atol=1e-5)
+    finally:
+        dist.destroy_process_group()
