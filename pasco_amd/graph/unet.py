@@ -176,13 +176,14 @@ class PascoNet(nn.Module):
 
     def __init__(self, n_classes=20, n_infers=1, in_channels=27 + 256, f=64, num_queries=100, heavy_decoder=True,
                  encoder_dropouts=(0.0, 0.0, 0.0), decoder_dropouts=(0.0, 0.0, 0.0), dense3d_dropout=0.0,
-                 iou_threshold=0.2, overlap_threshold=0.4, object_mask_threshold=0.7, thing_ids=THING_IDS):
+                 iou_threshold=0.2, overlap_threshold=0.4, object_mask_threshold=0.7, thing_ids=THING_IDS,
+                 hidden_dim=384, dim_feedforward=1024):
         super().__init__()
         self.n_infers = n_infers
         self.n_classes = n_classes
         self.transformer_predictor = TransformerPredictorV2(
-            in_channels=[f * 4, f * 2, f], num_classes=n_classes, hidden_dim=384, num_queries=num_queries, nheads=8,
-            dim_feedforward=1024, mask_dim=f, n_infers=n_infers)
+            in_channels=[f * 4, f * 2, f], num_classes=n_classes, hidden_dim=hidden_dim, num_queries=num_queries,
+            nheads=8, dim_feedforward=dim_feedforward, mask_dim=f, n_infers=n_infers)   # reference: 384 / 1024 fixed
         self.unet3d = UNet3DV2(in_channels=f * n_infers, n_classes=n_classes,
                                transformer_predictor=self.transformer_predictor, n_infers=n_infers,
                                f_maps=[f, f * 2, f * 4, f * 4], heavy_decoder=heavy_decoder,

@@ -1,0 +1,142 @@
+"""Data formats either side of the hot path against what the REFERENCE's own readers
+returned for the same files (tests/golden/make_golden_io.py: `io_data._read_*`, `KittiDataset.get_individual`,
+`collate_fn`, `transform_scene`, a Lightning-shaped checkpoint built from the reference's modules)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pasco_amd.data as D
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MINI = os.path.join(GOLD, "kitti_mini")
+SEQ, FRAME = "08", "000005"
+
+
+def gold(name):
+    d = np.load(os.path.join(GOLD, name))
+    return {k: d[k] for k in d.files}
+
+
+def test_bit_packed_voxel_files_match_reference_readers():
+    g = gold("io_files.npz")
+    vox = os.path.join(MINI, "dataset", "sequences", SEQ, "voxels")
+    assert np.array_equal(D.read_occupancy(os.path.join(vox, FRAME + ".bin")), g["occupancy"])
+    assert D.read_occupancy(os.path.join(vox, FRAME + ".bin")).dtype == np.float32
+    assert np.array_equal(D.read_label(os.path.join(vox, FRAME + ".label")), g["label"])
+    assert np.array_equal(D.read_invalid(os.path.join(vox, FRAME + ".invalid")), g["invalid"])
+    assert np.array_equal(D.read_occluded(os.path.join(vox, FRAME + ".occluded")), g["occluded"])
+    pc = D.read_pointcloud(os.path.join(MINI, "dataset", "sequences", SEQ, "velodyne", FRAME + ".bin"))
+    assert np.array_equal(pc, g["pointcloud"]) and pc.shape[1] == 4
+    assert np.array_equal(D.pack_bits(g["bits"]), g["packed"])
+    assert np.array_equal(D.unpack_bits(g["packed"]), g["unpacked"]) and np.array_equal(g["unpacked"], g["bits"])
+    # round trip on ragged / edge sizes: empty, one byte, not a multiple of 8 is refused
+    assert D.unpack_bits(np.zeros(0, np.uint8)).size == 0 and D.pack_bits(np.zeros(0, np.uint8)).size == 0
+    assert D.unpack_bits(np.array([0x81], np.uint8)).tolist() == [1, 0, 0, 0, 0, 0, 0, 1]
+    with pytest.raises(ValueError):
+        D.pack_bits(np.ones(7, np.uint8))
+
+
+def test_point_labels_keep_the_low_16_bits():
+    lab = D.read_point_instance_labels(os.path.join(MINI, "dataset", "sequences", SEQ, "labels", FRAME + ".label"))
+    raw = np.fromfile(os.path.join(MINI, "dataset", "sequences", SEQ, "labels", FRAME + ".label"), dtype=np.int32)
+    assert lab.shape == (raw.shape[0], 1) and np.array_equal(lab[:, 0], raw & 0xFFFF) and int(lab.max()) < 65536
+
+
+def test_transform_scene_matches_reference():
+    g = gold("io_items.npz")
+    f, c, bnd = D.transform_scene(torch.from_numpy(g["ts_coords"]), torch.from_numpy(g["T_fixed"]),
+                                  torch.from_numpy(g["ts_grid"]))
+    assert torch.equal(c, torch.from_numpy(g["ts_out_coords"]))
+    assert torch.equal(f, torch.from_numpy(g["ts_feat"]))
+    assert torch.equal(bnd[0], torch.from_numpy(g["ts_bnd_min"])) and torch.equal(bnd[1], torch.from_numpy(g["ts_bnd_max"]))
+
+
+@pytest.mark.parametrize("tag", ["eye", "rigid"])
+def test_frame_to_subnet_item_matches_reference_dataset(tag):
+    """WaffleIron pickle + instance-label pickle + point labels -> in_feat / in_coord / T / min_C / max_C exactly as
+    `KittiDataset.get_individual` builds them (identity transform and a rigid one with a flip)."""
+    g = gold("io_items.npz")
+    reader = D.FrameReader(MINI, os.path.join(MINI, "preprocess"))
+    lab, feats, pts = reader.paths(SEQ, FRAME)
+    sem, ins = D.read_instance_label_pickle(lab)
+    xyz, vote, intensity, emb = D.read_waffleiron_features(feats, embedding_index=int(g[f"{tag}_emb_index"]))
+    assert emb.shape[1] == 256 and vote.shape[1] == 19
+    T = torch.from_numpy(g[f"{tag}_T"])
+    item = D.build_item(xyz, vote, intensity, emb, sem, ins, T, 8, D.read_point_instance_labels(pts))
+    assert item["in_feat"].shape[1] == 19 + 1 + 1 + 256 + 6 == 283
+    assert torch.equal(item["in_coord"], torch.from_numpy(g[f"{tag}_in_coord"]))
+    assert torch.equal(item["in_feat"], torch.from_numpy(g[f"{tag}_in_feat"]))
+    assert torch.equal(item["min_C"], torch.from_numpy(g[f"{tag}_min_C"]))
+    assert torch.equal(item["max_C"].float(), torch.from_numpy(g[f"{tag}_max_C"]).float())
+    assert np.allclose(item["xyz"], g[f"{tag}_xyz"])
+    assert int(item["min_C"].remainder(8).abs().sum()) == 0          # floored to the completion scale
+
+
+def test_collate_gives_the_step_inference_contract():
+    g = gold("io_items.npz")
+    reader = D.FrameReader(MINI, os.path.join(MINI, "preprocess"))
+    Ts = [torch.from_numpy(g["eye_T"]), torch.from_numpy(g["rigid_T"])]
+    # the reference drew its own embedding index per item; with one fixed index both paths agree on everything
+    # that does not depend on the embedding: coordinates and bounds
+    batch = reader.batch(SEQ, FRAME, Ts, embedding_index=0)
+    assert torch.equal(batch["global_min_Cs"], torch.from_numpy(g["global_min_Cs"]))
+    assert torch.equal(batch["global_max_Cs"].float(), torch.from_numpy(g["global_max_Cs"]).float())
+    ext = batch["global_max_Cs"] - batch["global_min_Cs"] + 1
+    assert int(ext.remainder(8).sum()) == 0
+    assert len(batch["in_feats"]) == 2 and batch["in_feats"][0].dtype == torch.float32 and batch["in_coords"][0].dtype == torch.int64
+    assert torch.equal(batch["in_coords"][1], torch.from_numpy(g["rigid_in_coord"]))
+
+
+def test_lightning_checkpoint_loads_into_pasconet(tmp_path):
+    """`Net.load_from_checkpoint` counterpart (scripts/eval.py:69-71): hyper-parameters -> PascoNet, strict weights,
+    `criterion.*` dropped, the three aliases of the transformer predictor collapsed onto one module."""
+    path = os.path.join(GOLD, "net_mini.ckpt")
+    sd, hp = D.load_lightning_state_dict(path)
+    assert any(k.startswith("criterion.") for k in sd) and hp["n_infers"] == 2 and hp["f"] == 8
+    net = D.net_from_checkpoint(path)
+    assert not net.training and net.n_infers == 2 and net.transformer_predictor.num_queries == 6
+    own = net.state_dict()
+    for k, v in sd.items():
+        if k.startswith("criterion."):
+            assert k not in own
+        else:
+            assert torch.equal(own[k], v), k
+    tp = net.transformer_predictor
+    assert net.unet3d.transformer_predictor is tp and net.unet3d.decoder_generative.transformer_predictor is tp
+    # a checkpoint that kept only ONE alias (state dicts saved with keep_vars / deduplicated) still loads
+    slim = {k: v for k, v in sd.items() if not k.startswith(("unet3d.transformer_predictor.",
+                                                             "unet3d.decoder_generative.transformer_predictor."))}
+    p2 = os.path.join(tmp_path, "slim.ckpt")
+    torch.save({"state_dict": slim, "hyper_parameters": hp}, p2)
+    net2 = D.net_from_checkpoint(p2)
+    assert all(torch.equal(a, b) for a, b in zip(net2.state_dict().values(), own.values()))
+    # disagreeing aliases and foreign keys are errors, not silently resolved
+    bad = dict(sd)
+    k0 = next(k for k in bad if k.startswith("unet3d.transformer_predictor.") and bad[k].dtype == torch.float32)
+    bad[k0] = bad[k0] + 1
+    torch.save({"state_dict": bad, "hyper_parameters": hp}, p2)
+    with pytest.raises(ValueError, match="aliases"):
+        D.net_from_checkpoint(p2)
+    extra = dict(sd)
+    extra["unet3d.no_such_layer.weight"] = torch.zeros(1)
+    torch.save({"state_dict": extra, "hyper_parameters": hp}, p2)
+    with pytest.raises(RuntimeError, match="does not match"):
+        D.net_from_checkpoint(p2)
+
+
+def test_loaded_frame_runs_through_the_graph(oracle_registered):
+    """Files -> a0 contract -> `PascoNet.step_inference` on the checker backend: the formats feed the path."""
+    g = gold("io_items.npz")
+    reader = D.FrameReader(MINI, os.path.join(MINI, "preprocess"))
+    batch = reader.batch(SEQ, FRAME, [torch.from_numpy(g["eye_T"]), torch.from_numpy(g["rigid_T"])], embedding_index=0)
+    from pasco_amd.graph import PascoNet
+    torch.manual_seed(2)
+    net = PascoNet(n_classes=20, n_infers=2, in_channels=283, f=8, num_queries=6, heavy_decoder=False).eval()
+    ext = (batch["global_max_Cs"] - batch["global_min_Cs"] + 1).tolist()
+    net.ensembler.scene_size = tuple(int(v) for v in ext)
+    with torch.no_grad():
+        x = net.prepare_input(batch["in_feats"], batch["in_coords"])
+        ret = net(x, batch["global_min_Cs"], batch["global_max_Cs"], batch["min_Cs"], batch["max_Cs"])
+    assert len(ret["panop_predictions"]) == 2 and ret["sem_logits_at_scales"][1][0].F.shape[1] == 20
