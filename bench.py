@@ -186,6 +186,26 @@ def cpu_model():
     return "unknown CPU"
 
 
+def physical_cores():
+    """Physical cores of the host (SMT siblings counted once): the C / OpenMP oracle ran 2.7x slower on all 256
+    logical CPUs of the 128-core box than on 128 threads."""
+    seen = set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return len(seen) or (os.cpu_count() or 1)
+
+
 def cpu_baseline(n_infers, in_channels):
     """Same graph, oracle backend (C + OpenMP) + torch CPU for the dense parts, host cores only: one warm-up
     scene on a 128x128x16 grid (thread pools, page faults, weight operand caches), then ONE full S10 scene timed."""
@@ -193,8 +213,9 @@ def cpu_baseline(n_infers, in_channels):
     from pasco_amd.me import backend
     from pasco_amd.me.backend import CBackend
     from pasco_amd.graph.synth import make_scene, TeacherKeep
-    cores = os.cpu_count() or 1
+    cores = physical_cores()
     torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)     # the oracle's OpenMP runtime starts with its first call, below
     backend.register_checker_backend(CBackend(build_oracle(), "pho_", "cpu"))
     try:
         net = build_net(n_infers, in_channels, "cpu")
@@ -211,7 +232,7 @@ def cpu_baseline(n_infers, in_channels):
         return dict(value=round(1.0 / t_full, 5), unit="scenes/s", cores=cores, kind="port",
                     sample=f"1 full S10 scene (seed 0, M={n_infers}, {int(full.occ.sum())} occupied voxels) in {t_full:.2f} s after a "
                            f"warm-up scene on a 128x128x16 grid; oracle C/OpenMP sparse ops + torch-CPU dense ops; "
-                           f"{cpu_model()}, {cores} logical CPUs (OpenMP and torch both use all of them)")
+                           f"{cpu_model()}: {cores} threads = physical cores of {os.cpu_count()} logical CPUs (OpenMP and torch)")
     finally:
         backend.register_checker_backend(None)
 

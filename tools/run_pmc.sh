@@ -10,7 +10,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   raw=/tmp/pmc_raw_${tag}_$c
   rm -rf "$raw"; mkdir -p "$raw"
   timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$raw" -o run -- \
-      python bench.py --no-cpu-baseline --no-profile --no-exact "$@" > "$out/bench_$c.json" 2> "$out/bench_$c.err"
+      python bench.py --no-cpu-baseline --no-profile --no-exact --no-configs "$@" > "$out/bench_$c.json" 2> "$out/bench_$c.err"
   echo "rc=$?" >> "$out/bench_$c.err"
   f=$(find "$raw" -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then grep -E "Counter_Name|k_conv_|k_split_rows" "$f" > "$out/conv_$c.csv"; head -2 "$out/conv_$c.csv"; else echo "no counter csv for $c"; find "$raw" | head; fi

@@ -10,7 +10,7 @@ raw=/tmp/rocprof_raw_$tag
 mkdir -p "$out" "$raw"
 export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$raw" -o run -- \
-    python bench.py --no-cpu-baseline --no-exact "$@" > "$out/bench.json" 2> "$out/bench.err"
+    python bench.py --no-cpu-baseline --no-exact --no-configs "$@" > "$out/bench.json" 2> "$out/bench.err"
 echo "rocprofv3 rc=$?" >> "$out/bench.err"
 for f in $(find "$raw" -name "*stats*.csv" 2>/dev/null); do cp "$f" "$out/"; done
 ls -la "$raw" $(find "$raw" -type d | head -3) > "$out/files.txt" 2>&1
