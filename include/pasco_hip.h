@@ -171,14 +171,35 @@ typedef struct ph_conv_desc {
   const float *osp_shift; /* [cout] */
   int32_t osp_act;
   int32_t reserved2;
+  /* mode 2, optional: LDS-window tables of the kernel map (ph_win_build; 3x3x3 maps only).  When all four are given
+   * the library may serve the launch from per-tile input windows instead of per-offset gathers; which of the two
+   * kernels does the work is decided on the device from win_stats (no host read).  Results are the same products
+   * in a different fp32 summation order. */
+  const int32_t *win_rows;   /* [ntiles][27*128] */
+  const int32_t *win_cnt;    /* [ntiles] */
+  const uint16_t *win_slots; /* [ntiles][27][128] */
+  const int32_t *win_stats;  /* [4] */
 } ph_conv_desc;
 
 int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);
 
+/* Input windows of a 3x3x3 kernel map (stride-1 convolutions: MinkowskiConvolution k=3, mink.py:625-638,
+ * decoder_v3.py:267-282), built once per map and cached by the caller next to `nbr`.  For every tile of 128
+ * consecutive output rows:
+ *   win_rows[tile][0 .. cnt)   the DISTINCT input rows its 27 x 128 neighbour entries name, ascending
+ *   win_cnt[tile]              their number (<= 27 * 128)
+ *   win_slots[tile][k][r]      position of nbr[k][tile*128 + r] in that list, 0xFFFF for "no neighbour"
+ *   win_stats[0 / 1]           sum over tiles of ceil(cnt / 416) and ceil(cnt / 512) (window passes of the two
+ *                              kernel shapes; device-side choice between window and gather kernels)
+ * Buffers: win_rows int32 [ntiles * 3456], win_cnt int32 [ntiles], win_slots uint16 [ntiles * 3456],
+ * win_stats int32 [4]; ntiles = ceil(n_out / 128).  (No upstream counterpart: ME gathers per offset.) */
+int PH_FN(win_build)(const int32_t *nbr, int32_t kvol, int64_t n_out, int32_t *win_rows, int32_t *win_cnt,
+                     uint16_t *win_slots, int32_t *win_stats, ph_stream_t stream);
+
 /* Diagnostics for the parity tests: which kernel instantiation the LAST conv_fwd of the calling thread launched.
  * h_out8 (HOST array of 8 ints) = { mma_mode, tile rows, tile channels, input channels per stage, splits over the
  * kernel offsets, 1 if the launch wrote out_split, kernel id (0 k_conv_mfma, 1 k_conv_f16x3, 2 k_conv_h2,
- * 3 k_conv_rl = row-list k = 2 kernel), waves per workgroup }; all -1 / 0 before the first launch.  The checker build reports
+ * 3 k_conv_rl = row-list k = 2 kernel, 4 k_conv_dma, 5 k_conv_win + k_conv_dma pair with the device-side choice), waves per workgroup }; all -1 / 0 before the first launch.  The checker build reports
  * kernel id -1.  (No upstream counterpart: ME picks its kernel inside ConvolutionForwardKernelGPU.) */
 int PH_FN(conv_last_config)(int32_t *h_out8);
 

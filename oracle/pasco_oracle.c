@@ -407,6 +407,65 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   return rc;
 }
 
+/* input windows of a 3x3x3 kernel map (include/pasco_hip.h ph_win_build): per 128-row tile the ascending list of
+ * distinct input rows and the position of every (offset, row) entry in it */
+static int cmp_i32(const void *a, const void *b) {
+  const int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+int pho_win_build(const int32_t *nbr, int32_t kvol, int64_t n_out, int32_t *win_rows, int32_t *win_cnt,
+                  uint16_t *win_slots, int32_t *win_stats, ph_stream_t stream) {
+  (void)stream;
+  enum { BM = 128, KV = 27, CAP = BM * KV };
+  if (kvol != KV) return fail("win_build: serves kvol 27");
+  if (n_out == 0) return 0;
+  if (!nbr || !win_rows || !win_cnt || !win_slots || !win_stats) return fail("win_build: null buffer");
+  const int64_t ntiles = (n_out + BM - 1) / BM;
+  long long pa = 0, pb = 0;
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : pa, pb)
+  for (int64_t t = 0; t < ntiles; ++t) {
+    int32_t buf[CAP];
+    int m = 0;
+    for (int k = 0; k < KV; ++k)
+      for (int r = 0; r < BM; ++r) {
+        const int64_t row = t * BM + r;
+        const int32_t idx = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+        if (idx >= 0) buf[m++] = idx;
+      }
+    qsort(buf, (size_t)m, sizeof(int32_t), cmp_i32);
+    int cnt = 0;
+    for (int i = 0; i < m; ++i)
+      if (i == 0 || buf[i] != buf[i - 1]) buf[cnt++] = buf[i];
+    int32_t *wr = win_rows + t * CAP;
+    for (int i = 0; i < cnt; ++i) wr[i] = buf[i];
+    win_cnt[t] = cnt;
+    pa += cnt > 0 ? (cnt + 415) / 416 : 1;
+    pb += cnt > 0 ? (cnt + 511) / 512 : 1;
+    uint16_t *sl = win_slots + t * CAP;
+    for (int k = 0; k < KV; ++k)
+      for (int r = 0; r < BM; ++r) {
+        const int64_t row = t * BM + r;
+        const int32_t idx = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+        uint16_t s = 0xFFFFu;
+        if (idx >= 0) {
+          int lo = 0, hi = cnt - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (buf[mid] < idx) lo = mid + 1;
+            else hi = mid;
+          }
+          s = (uint16_t)lo;
+        }
+        sl[k * BM + r] = s;
+      }
+  }
+  win_stats[0] = (int32_t)pa;
+  win_stats[1] = (int32_t)pb;
+  win_stats[2] = win_stats[3] = 0;
+  return 0;
+}
+
 /* a10 */
 int pho_maxpool_fwd(const float *in, int32_t c, const int32_t *nbr, int32_t kvol, int64_t n_out,
                     float *out, ph_stream_t stream) {

@@ -55,6 +55,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
   const int tile = (bid & 7) * cpx + (bid >> 3);
   const int ntiles = a.n_row_tiles * a.n_col_tiles;
   if (tile >= ntiles) return;
+  // one of a window / gather pair: the window kernel (conv_win.hip) serves the map when the predicate holds
+  if (a.win_gather && ph_win_pred(a.win_stats, a.win_which, (a.n_out + 127) / 128)) return;
   const int row_tile = tile / a.n_col_tiles;
   const int col_tile = tile - row_tile * a.n_col_tiles;
   const int64_t m0 = (int64_t)row_tile * BM;
@@ -286,7 +288,7 @@ static int launch_dma(const ConvArgsH &a, hipStream_t st) {
 
 // 256 zero bytes per device for rows without a neighbour: the one piece of device memory the library owns
 // (allocated at the first launch on a device, never inside a stream capture: convolutions are not captured)
-static const char *dma_zero_line() {
+const char *ph_dma_zero_line() {
   static const char *zero[64] = {nullptr};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
@@ -304,7 +306,7 @@ static const char *dma_zero_line() {
 int ph_conv_dma_try(const ConvArgsH &a_in, int bn, hipStream_t st) {
   const int kper = (a_in.kvol + a_in.ksplit - 1) / a_in.ksplit;
   if (kper > DMA_KMAX) return -1;
-  const char *zero = dma_zero_line();
+  const char *zero = ph_dma_zero_line();
   if (zero == nullptr) return -1;
   ConvArgsH a = a_in;
   a.zero = zero;

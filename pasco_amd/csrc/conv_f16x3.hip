@@ -299,6 +299,8 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
   const int tile = (bid & 7) * cpx + (bid >> 3);
   const int ntiles = a.n_row_tiles * a.n_col_tiles;
   if (tile >= ntiles) return;
+  // one of a window / gather pair: the window kernel (conv_win.hip) serves the map when the predicate holds
+  if (a.win_gather && ph_win_pred(a.win_stats, a.win_which, (a.n_out + 127) / 128)) return;
   const int row_tile = tile / a.n_col_tiles;
   const int col_tile = tile - row_tile * a.n_col_tiles;
   const int64_t m0 = (int64_t)row_tile * BM;
@@ -587,6 +589,7 @@ struct ConvHKnobs {
   bool has_ksplit = false;
   int ksplit = 0;
   bool dma_all = false;
+  bool win_on = true;      // PASCO_CONV_WIN=0: no LDS-window kernel
   bool dma_on = true;      // PASCO_CONV_DMA=0: keep every launch on the register-staged k_conv_h2 (A/B comparisons)
   ConvHKnobs() {
     if (const char *e = getenv("PASCO_CONV_DMA")) {
@@ -594,6 +597,7 @@ struct ConvHKnobs {
       dma_all = atoi(e) == 2;      // 2: every tile width on the DMA kernel
     }
     if (const char *e = getenv("PASCO_CONVH_MID")) mid_on = atoi(e) != 0;
+    if (const char *e = getenv("PASCO_CONV_WIN")) win_on = atoi(e) != 0;
     if (const char *e = getenv("PASCO_CONVH_CFG")) has_cfg = sscanf(e, "%d,%d", &cfg_bm, &cfg_kc) >= 1;
     if (const char *e = getenv("PASCO_CONVH_KSPLIT")) {
       has_ksplit = true;
@@ -666,6 +670,12 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.status = d->status;
   a.zero = nullptr;
   a.ablate = 0;
+  a.win_rows = d->win_rows;
+  a.win_cnt = d->win_cnt;
+  a.win_slots = d->win_slots;
+  a.win_stats = nullptr;
+  a.win_which = 0;
+  a.win_gather = 0;
   const int bn = d->cout <= 32 ? 32 : (d->cout <= 64 ? 64 : 128);
   const int64_t ncol = (d->cout + bn - 1) / bn;
   // tile height: the tallest tile that still gives >= 2 workgroups per CU (profiles/r1e_op_bench.json)
@@ -710,41 +720,61 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
       a.partial = (float *)d->splitk_ws;
     }
   }
+  // 3x3x3 convolutions on big maps with window tables: launch the window kernel AND the gather kernel below; the
+  // device-side predicate (window passes per tile, ph_win_build) lets exactly one of them do the work.  Only where no
+  // split over the offsets was chosen (its reduction kernel would run unconditionally).
+  bool win_pair = false;
+  if (pre && knobs.win_on && !env && d->kvol == 27 && (bn == 64 || bn == 128) && a.ksplit == 1 && d->win_rows &&
+      d->win_cnt && d->win_slots && d->win_stats) {
+    a.win_stats = d->win_stats;
+    a.win_which = (bn == 64 ? 0 : 1) | ph_win_force_bits();
+    a.win_gather = 0;
+    if (int rc = ph_conv_win_launch(a, bn, st)) return rc;
+    a.win_gather = 1;
+    win_pair = true;
+    if (bm != 128) bm = 128;   // pairs are only formed on big maps: the gather side keeps its 128-row tile
+  }
+  auto gather_launch = [&]() -> int {
   // default for pre-split operands: the LDS-DMA pipelined kernel (conv_dma.hip; 128-row tiles, parallelism of few-row
-  // layers from the split over the offsets chosen above); it declines slices of more than 32 offsets
-  // measured (profiles/README.md, round 2): 6-9 % faster than k_conv_h2 on 128-channel-wide tiles, a few % slower on 64-wide
-  if (pre && knobs.dma_on && !env && (bn == 128 || knobs.dma_all)) {
-    ConvArgsH b = a;
-    if (bm != 128) {        // the choice above was made for a shorter tile: redo the split decision for 128 rows
-      const int64_t t128 = ((d->n_out + 127) / 128) * ncol;
-      int want = (int)(1024 / (t128 > 0 ? t128 : 1));
-      if (want > 8) want = 8;
-      if (want > d->kvol / 4) want = d->kvol / 4;
-      const bool room = d->splitk_ws != nullptr && d->splitk_ws_bytes >= (int64_t)want * d->n_out * d->cout * 4;
-      if (t128 < 256 && want >= 2 && room) {
-        b.ksplit = want;
-        b.partial = (float *)d->splitk_ws;
+    // layers from the split over the offsets chosen above); it declines slices of more than 32 offsets
+    // measured (profiles/README.md, round 2): 6-9 % faster than k_conv_h2 on 128-channel-wide tiles, a few % slower on 64-wide
+    if (pre && knobs.dma_on && !env && (bn == 128 || knobs.dma_all)) {
+      ConvArgsH b = a;
+      if (bm != 128) {        // the choice above was made for a shorter tile: redo the split decision for 128 rows
+        const int64_t t128 = ((d->n_out + 127) / 128) * ncol;
+        int want = (int)(1024 / (t128 > 0 ? t128 : 1));
+        if (want > 8) want = 8;
+        if (want > d->kvol / 4) want = d->kvol / 4;
+        const bool room = d->splitk_ws != nullptr && d->splitk_ws_bytes >= (int64_t)want * d->n_out * d->cout * 4;
+        if (t128 < 256 && want >= 2 && room) {
+          b.ksplit = want;
+          b.partial = (float *)d->splitk_ws;
+        }
       }
+      const int rc = ph_conv_dma_try(b, bn, st);
+      if (rc >= 0) return rc;
     }
-    const int rc = ph_conv_dma_try(b, bn, st);
-    if (rc >= 0) return rc;
-  }
 #define PH_H_CASE(BM_, WM_, WN_, TM_, TN_)                                                                \
-  if (bm == BM_) {                                                                                        \
-    if (pre) return kc == 64 ? launch_h2<BM_, 64, WM_, WN_, TM_, TN_>(a, st) : launch_h2<BM_, 32, WM_, WN_, TM_, TN_>(a, st); \
-    return kc == 64 ? launch_h<BM_, 64, WM_, WN_, TM_, TN_>(a, st) : launch_h<BM_, 32, WM_, WN_, TM_, TN_>(a, st);            \
-  }
-  if (bn == 32) {
-    PH_H_CASE(128, 4, 1, 1, 1);
-  } else if (bn == 64) {
-    PH_H_CASE(128, 4, 1, 1, 2);
-    PH_H_CASE(64, 2, 2, 1, 1);
-  } else {
-    PH_H_CASE(128, 2, 2, 2, 2);
-    PH_H_CASE(64, 2, 2, 1, 2);
-    PH_H_CASE(32, 1, 4, 1, 1);
-  }
+    if (bm == BM_) {                                                                                        \
+      if (pre) return kc == 64 ? launch_h2<BM_, 64, WM_, WN_, TM_, TN_>(a, st) : launch_h2<BM_, 32, WM_, WN_, TM_, TN_>(a, st); \
+      return kc == 64 ? launch_h<BM_, 64, WM_, WN_, TM_, TN_>(a, st) : launch_h<BM_, 32, WM_, WN_, TM_, TN_>(a, st);            \
+    }
+    if (bn == 32) {
+      PH_H_CASE(128, 4, 1, 1, 1);
+    } else if (bn == 64) {
+      PH_H_CASE(128, 4, 1, 1, 2);
+      PH_H_CASE(64, 2, 2, 1, 1);
+    } else {
+      PH_H_CASE(128, 2, 2, 2, 2);
+      PH_H_CASE(64, 2, 2, 1, 2);
+      PH_H_CASE(32, 1, 4, 1, 1);
+    }
 #undef PH_H_CASE
-  ph_set_error("conv_fwd(f16x3): no kernel for bm=%d bn=%d", bm, bn);
-  return 1;
+    ph_set_error("conv_fwd(f16x3): no kernel for bm=%d bn=%d", bm, bn);
+    return 1;
+  };
+  const int rc = gather_launch();
+  if (rc == 0 && win_pair)   // a window / gather pair: which one worked is the device's decision
+    ph_record_cfg(2, 128, bn, 32, 1, a.out_split != nullptr ? 1 : 0, 5, 4);
+  return rc;
 }

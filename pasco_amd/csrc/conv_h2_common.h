@@ -42,7 +42,26 @@ struct ConvArgsH {
   float act_pow2;             // 2^split_exp2: scale of the activation operand (mode 1 gather, emitted out_split)
   const char *zero;           // k_conv_dma: >= 256 zero bytes in device memory (rows without a neighbour read them)
   int ablate;                 // k_conv_dma development hook (0 in production)
+  // LDS-window tables of the kernel map (conv_win.hip); win_stats != nullptr: the launch is one of a window / gather
+  // pair and returns at once unless the device-side predicate picks it
+  const int32_t *win_rows, *win_cnt, *win_stats;
+  const uint16_t *win_slots;
+  int win_which;              // statistics slot of the tile shape (0: 64-wide / 416 rows, 1: 128-wide / 512 rows)
+  int win_gather;             // 1 on the gather kernel of the pair (inverted predicate)
 };
+
+// mean window passes per tile <= 1.25 -> the window kernel serves the map (which: bit 8 / 9 = test override:
+// always / never windows)
+__device__ __forceinline__ bool ph_win_pred(const int32_t *stats, int which, int64_t n_row_tiles) {
+  if (which & 0x100) return true;
+  if (which & 0x200) return false;
+  return (int64_t)stats[which & 1] * 4 <= n_row_tiles * 5;
+}
+int ph_win_force_bits();   // conv_win.hip: 0, 0x100 or 0x200 (ph_conv_win_force, tests only)
+// conv_dma.hip: 256 zero bytes of device memory for absent neighbours
+const char *ph_dma_zero_line();
+// conv_win.hip
+int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st);
 
 // conv_f16x3.hip: reduction + epilogue of a split over the kernel offsets (after a launch with args.ksplit > 1)
 int ph_launch_splitk_epilogue(const ConvArgsH &args, hipStream_t st);

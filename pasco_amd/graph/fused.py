@@ -23,6 +23,7 @@ _CONV_PRECISION = "f16x3"
 _PRESPLIT = True     # f16x3 operands pre-split once per tensor (mma_mode 2) instead of per gather (mode 1)
 _FUSION = True       # False: route (a) of INTEGRATION.md - every block as the reference's own module sequence
 MIN_ROWS_LINEAR = 16384    # tall-operand threshold above which linear layers run on the convolution kernel
+MIN_ROWS_WINDOWS = 16384   # 3x3x3 maps with at least this many rows get LDS-window tables (conv_win.hip)
 
 
 def _kernel_device(device) -> bool:
@@ -351,11 +352,15 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
         ns, nb = fold_bn(nbn) if nbn is not None else (None, None)
         emit = (ns, nb, nact)
     only = split_only and emit is not None and n_out > 0
+    win = None
+    if in_split is not None and nbr is not None and nbr.shape[0] == 27 and n_out >= MIN_ROWS_WINDOWS and \
+            be.device_type == "cuda" and min(mod.in_channels, mod.out_channels) >= 64:
+        win = mgr.kernel_windows(nbr)
     out = be.conv_fwd(
         x_rows, mod.kernel.detach(), nbr, n_out, xshape=xshape, bias=bias,
         pro_scale=ps, pro_shift=pb, pro_act=pro_act, epi_scale=es, epi_shift=eb, epi_act=epi_act,
         epi2_scale=e2s, epi2_shift=e2b, residual=residual, res_act=res_act, slope=slope, split=split,
-        in_split=in_split, emit_split=emit, want_out=not only)
+        in_split=in_split, emit_split=emit, want_out=not only, win=win)
     if emit is None:
         return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
     out, out_split = out

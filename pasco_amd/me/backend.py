@@ -46,6 +46,7 @@ class ConvDesc(C.Structure):
         ("splitk_ws", _vp), ("splitk_ws_bytes", _i64), ("status", _vp),
         ("in_split", _vp), ("w_split", _vp),
         ("out_split", _vp), ("osp_scale", _vp), ("osp_shift", _vp), ("osp_act", _i32), ("reserved2", _i32),
+        ("win_rows", _vp), ("win_cnt", _vp), ("win_slots", _vp), ("win_stats", _vp),
     ]
 
 
@@ -62,6 +63,7 @@ _SIGNATURES = {
     "kmap_compact": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
     "conv_fwd": [C.POINTER(ConvDesc), _vp],
     "conv_last_config": [_vp],
+    "win_build": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
     "split_rows": [_vp, _i64, _i32, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp, _vp],
     "maxpool_fwd": [_vp, _i32, _vp, _i32, _i64, _vp, _vp],
     "mask_compact": [_vp, _i64, _vp, _vp, _vp, _i64, _vp],
@@ -223,6 +225,26 @@ class CBackend:
         self._check(rc, "nbr_build")
         return nbr
 
+    def win_build(self, nbr: torch.Tensor) -> dict:
+        """Input windows of a 3x3x3 kernel map (include/pasco_hip.h ph_win_build): per tile of 128 consecutive output rows
+        the ascending list of distinct input rows (`rows` [T, 3456], `cnt` [T]) and the position of every (offset, row)
+        entry in it (`slots` uint16 [T, 27, 128], 0xFFFF = none); `stats` = device-side pass counts.  Cached by the
+        coordinate manager next to `nbr`."""
+        self._chk(nbr, torch.int32, "nbr")
+        kvol, n_out = nbr.shape
+        if kvol != 27:
+            raise ValueError("win_build serves 3x3x3 kernel maps")
+        dev = nbr.device
+        t = (n_out + 127) // 128
+        win = {"rows": torch.empty((max(t, 1), 27 * 128), dtype=torch.int32, device=dev),
+               "cnt": torch.zeros(max(t, 1), dtype=torch.int32, device=dev),
+               "slots": torch.empty((max(t, 1), 27, 128), dtype=torch.int16, device=dev),     # uint16 bit patterns
+               "stats": torch.zeros(4, dtype=torch.int32, device=dev), "n_out": n_out}
+        rc = self.fn["win_build"](_ptr(nbr), kvol, n_out, _ptr(win["rows"]), _ptr(win["cnt"]), _ptr(win["slots"]),
+                                  _ptr(win["stats"]), self.stream(dev))
+        self._check(rc, "win_build")
+        return win
+
     def kmap_compact(self, nbr: torch.Tensor):
         """-> (pairs_in [K,N], pairs_out [K,N], counts [K]) ; segment k valid up to counts[k]."""
         self._chk(nbr, torch.int32, "nbr")
@@ -243,7 +265,7 @@ class CBackend:
                  epi_shift=None, epi_act=ACT_NONE, slope=0.01, residual=None, res_act=ACT_NONE,
                  epi2_scale=None, epi2_shift=None, split=None, in_split: Optional[torch.Tensor] = None,
                  emit_split=None, want_out: bool = True,
-                 out: Optional[torch.Tensor] = None):
+                 out: Optional[torch.Tensor] = None, win=None):
         """out = epilogue(sum_k gather(prologue(x))[k] @ W[k]) - one `ph_conv_fwd` launch (include/pasco_hip.h).
 
         `split` selects the split-precision products: (w_hi, w_lo, unscale) from `split_weight_f16` = mode 1
@@ -252,7 +274,9 @@ class CBackend:
         (`xshape` = (n_in, cin) / `wshape` = (kvol, cin, cout)) when only the operands exist.
         `emit_split` = (scale | None, shift | None, act) (mode 2, cout % 32 == 0): also write the split operand
         of act(out * scale + shift) for the next convolution and return (out, out_split); `want_out=False` then
-        skips the fp32 result (returns (None, out_split))."""
+        skips the fp32 result (returns (None, out_split)).
+        `win` = `win_build(nbr)` (3x3x3 maps, mode 2): lets the library serve the launch from LDS-resident input windows
+        where the map is local enough (decided on the device)."""
         if x is None:          # rows that exist only as a pre-split operand (mode 2): `xshape` = (n_in, cin)
             if xshape is None or in_split is None or split is None or len(split) != 2 or not self.split_capable():
                 raise ValueError("conv: x=None needs xshape, in_split and a mode-2 split on the device backend")
@@ -324,6 +348,9 @@ class CBackend:
                 if w_split.numel() != kvol * cout * 2 * cpad:
                     raise ValueError("conv: w_split does not match the kernel")
                 d.mma_mode, d.in_split, d.w_split = 2, _ptr(in_split), _ptr(w_split)
+                if win is not None and kvol == 27 and nbr is not None:
+                    d.win_rows, d.win_cnt, d.win_slots, d.win_stats = (_ptr(win["rows"]), _ptr(win["cnt"]),
+                                                                       _ptr(win["slots"]), _ptr(win["stats"]))
             else:                  # (w_hi, w_lo, unscale) from split_weight_f16: mode 1, activations split in-kernel
                 w_hi, w_lo, unscale = split
                 d.mma_mode, d.w_f16_hi, d.w_f16_lo = 1, _ptr(w_hi), _ptr(w_lo)

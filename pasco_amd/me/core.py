@@ -219,6 +219,16 @@ class CoordinateManager:
             self._kmap_cache[ck] = nbr
         return nbr
 
+    def kernel_windows(self, nbr: torch.Tensor):
+        """LDS-window tables of a 3x3x3 neighbour table of this manager (backend.win_build), built once per map."""
+        cache = self.__dict__.setdefault("_win_cache", {})
+        key = nbr.data_ptr()
+        hit = cache.get(key)
+        if hit is None or hit[0] is not nbr:
+            hit = (nbr, self.backend().win_build(nbr))
+            cache[key] = hit
+        return hit[1]
+
     def kernel_map_coo(self, in_key, out_key, kernel_size, dilation=1, transposed=False):
         """Upstream-style COO kernel map: list over offsets of (in_rows, out_rows)."""
         nbr = self.kernel_map(in_key, out_key, kernel_size, dilation, transposed)

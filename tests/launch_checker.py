@@ -164,8 +164,8 @@ class LaunchChecker:
         # (no prologue / epilogue: their FMA contraction is each kernel's own business; the products and the
         # accumulation order are what must agree): same x, weights and map through both kernels
         shape_key = key + (kvol, cin, cout)
-        if (fp32_x and weight is not None and cfg["mma_mode"] == 2 and cfg["ksplit"] == 1
-                and shape_key not in self.mode1_done):
+        if (fp32_x and weight is not None and cfg["mma_mode"] == 2 and cfg["ksplit"] == 1 and cfg["kernel"] != 5
+                and shape_key not in self.mode1_done):       # kernel 5 = window / gather pair: other summation order
             self.mode1_done.add(shape_key)
             p2 = self.inner(x, weight, nbr, n_out, split=split)
             cfg2 = hip.conv_last_config()

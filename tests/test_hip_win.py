@@ -1,0 +1,121 @@
+"""LDS-window convolution (pasco_amd/csrc/conv_win.hip): the window tables against the oracle's restatement (bit
+exact), and the convolution served from windows against the gather kernels, the oracle and fp64 - single-pass tiles,
+forced multi-pass tiles on a map without locality, ragged last tiles, emitted operands."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from pasco_amd.graph.synth import make_occupancy
+from pasco_amd.me.core import kernel_offsets
+from tests.test_hip_ops import scene_coords, unique_map
+
+pytestmark = pytest.mark.gpu
+
+
+def _force(hip, mode):
+    hip.lib.ph_conv_win_force.argtypes = [C.c_int]
+    hip.lib.ph_conv_win_force(mode)
+
+
+def s10_map(hip, shuffle=False, n=None):
+    g1 = np.argwhere(make_occupancy(0))
+    if n is not None:
+        g1 = g1[:n]
+    if shuffle:
+        g1 = g1[np.random.default_rng(0).permutation(g1.shape[0])]
+    c = torch.from_numpy(np.concatenate([np.zeros((g1.shape[0], 1), np.int64), g1], 1)).int().cuda().contiguous()
+    tk, tv, _, _, _ = hip.map_insert(c, dedup=False)
+    return hip.nbr_build(c, tk, tv, kernel_offsets(3, 1))
+
+
+@pytest.mark.parametrize("n", [1, 127, 128, 3000, 40000])
+def test_win_build_matches_oracle(hip, oracle, n):
+    coords = scene_coords(61, n)
+    tk_o, tv_o, c_o, _, _ = unique_map(oracle, coords)
+    tk_h, tv_h, c_h, _, _ = unique_map(hip, coords.cuda())
+    offs = kernel_offsets(3, 1)
+    nbr_o, nbr_h = oracle.nbr_build(c_o, tk_o, tv_o, offs), hip.nbr_build(c_h, tk_h, tv_h, offs)
+    wo, wh = oracle.win_build(nbr_o), hip.win_build(nbr_h)
+    assert torch.equal(wh["cnt"].cpu(), wo["cnt"]) and torch.equal(wh["stats"].cpu(), wo["stats"])
+    assert torch.equal(wh["slots"].cpu(), wo["slots"])
+    cnt = wo["cnt"]
+    for t in range(cnt.shape[0]):
+        assert torch.equal(wh["rows"][t, : int(cnt[t])].cpu(), wo["rows"][t, : int(cnt[t])])
+
+
+def _conv_case(hip, nbr, cin, cout, g, emit=False):
+    n = nbr.shape[1]
+    x = torch.randn(n, cin, device="cuda", generator=g) * torch.exp(torch.randn(n, 1, device="cuda", generator=g))
+    w = torch.randn(27, cin, cout, device="cuda", generator=g) / (27 * cin) ** 0.5
+    b = torch.randn(cout, device="cuda", generator=g)
+    res = torch.randn(n, cout, device="cuda", generator=g)
+    sc, sh = torch.rand(cout, device="cuda", generator=g) + 0.5, torch.randn(cout, device="cuda", generator=g) * 0.2
+    kw = dict(bias=b, epi_scale=sc, epi_shift=sh, epi_act=1, residual=res, res_act=1)
+    if emit:
+        kw["emit_split"] = (sc, sh, 1)
+    return x, w, kw
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (64, 128), (256, 256)])
+def test_window_conv_equals_gather_conv(hip, cin, cout):
+    """The same launch with and without window tables on the S10 map (windows chosen by the device-side predicate)."""
+    nbr = s10_map(hip, n=90000 if cin == 256 else None)
+    n = nbr.shape[1]
+    win = hip.win_build(nbr)
+    passes = win["stats"].tolist()
+    tiles = (n + 127) // 128
+    assert passes[0] * 4 <= tiles * 5 and passes[1] * 4 <= tiles * 5, "the S10 map should be window-friendly"
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x, w, kw = _conv_case(hip, nbr, cin, cout, g, emit=True)
+    split = hip.split_weight_rows(w)
+    ref, ref_s = hip.conv_fwd(x, w, nbr, n, split=split, **kw)
+    cfg_ref = hip.conv_last_config()
+    got, got_s = hip.conv_fwd(x, w, nbr, n, split=split, win=win, **kw)
+    cfg = hip.conv_last_config()
+    assert cfg["kernel"] == 5 and cfg_ref["kernel"] in (2, 4)
+    scale = float(ref.abs().mean())
+    assert float((got - ref).abs().max()) <= 2e-5 * scale + 1e-6, float((got - ref).abs().max())
+    # the emitted operand is the split of the fp32 result either way
+    want = hip.split_rows(got, pro_scale=kw["emit_split"][0], pro_shift=kw["emit_split"][1], pro_act=1)
+    assert torch.equal(got_s.view(torch.int16), want.view(torch.int16))
+    # fp64 on sampled rows
+    rows = torch.randint(0, n, (1500,), device="cuda", generator=g)
+    acc = torch.zeros(1500, cout, dtype=torch.float64, device="cuda")
+    for k in range(27):
+        idx = nbr[k][rows].long()
+        ok = idx >= 0
+        acc[ok] += x[idx[ok]].double() @ w[k].double()
+    r = torch.relu((acc + kw["bias"].double()) * kw["epi_scale"].double() + kw["epi_shift"].double())
+    r = torch.relu(r + kw["residual"][rows].double())
+    assert float((got[rows].double() - r).abs().max()) <= 1e-4 * float(acc.abs().mean())
+    hip.check_status(x.device)
+
+
+@pytest.mark.parametrize("cin,cout,n", [(64, 64, 20000), (128, 128, 9000), (64, 64, 129)])
+def test_window_conv_multi_pass_and_ragged(hip, oracle, cin, cout, n):
+    """A shuffled map has no locality (windows of > 1000 rows): forced onto the window kernel it runs 3 - 8 passes
+    per tile; the result must still be the convolution (oracle on fp32 operands)."""
+    nbr = s10_map(hip, shuffle=True, n=n)
+    win = hip.win_build(nbr)
+    if n >= 9000:
+        assert int(win["cnt"].max()) > 1024, "the shuffled map should need several passes"
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x, w, kw = _conv_case(hip, nbr, cin, cout, g)
+    split = hip.split_weight_rows(w)
+    _force(hip, 1)
+    try:
+        got = hip.conv_fwd(x, w, nbr, n, split=split, win=win, **kw)
+    finally:
+        _force(hip, 0)
+    ref = hip.conv_fwd(x, w, nbr, n, split=split, **kw)
+    scale = float(ref.abs().mean())
+    assert float((got - ref).abs().max()) <= 2e-5 * scale + 1e-6
+    okw = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+    exp = oracle.conv_fwd(x.cpu(), w.cpu(), nbr.cpu(), n, **okw)
+    assert torch.allclose(got.cpu(), exp, rtol=1e-4, atol=1e-4 * scale)
+    # the predicate would have sent this map to the gather kernel
+    if n >= 9000:
+        tiles = (n + 127) // 128
+        assert win["stats"].tolist()[0] * 4 > tiles * 5
