@@ -28,6 +28,7 @@ constexpr int DMA_KMAX = 32;   // kernel offsets one workgroup walks (its slice 
 // row reads the zero line (no gather misses), 4 = every weight row reads row 0 of its slab, 8 = skip the fragment reads
 static int g_dma_ablate = 0;
 static int g_dma_tall = 0;     // 256-row / 8-wave tiles: measured no faster (one workgroup per CU convoys); kept for experiments
+int ph_dma_ablate_bits() { return g_dma_ablate; }
 extern "C" void ph_conv_dma_set_ablate(int mask) { g_dma_ablate = mask & 0xFF; g_dma_tall = (mask & 0x100) ? 1 : 0; }
 
 // One workgroup = WAVES (4 or 8) waves as WM x WN, tile BM = WM*TM*32 rows (128 / 256) x BN = WN*TN*32 channels,

@@ -590,6 +590,7 @@ struct ConvHKnobs {
   int ksplit = 0;
   bool dma_all = false;
   bool win_on = true;      // PASCO_CONV_WIN=0: no LDS-window kernel
+  bool win_wide = false;   // PASCO_CONV_WIN=2: also on 128-wide tiles
   bool dma_on = true;      // PASCO_CONV_DMA=0: keep every launch on the register-staged k_conv_h2 (A/B comparisons)
   ConvHKnobs() {
     if (const char *e = getenv("PASCO_CONV_DMA")) {
@@ -597,7 +598,10 @@ struct ConvHKnobs {
       dma_all = atoi(e) == 2;      // 2: every tile width on the DMA kernel
     }
     if (const char *e = getenv("PASCO_CONVH_MID")) mid_on = atoi(e) != 0;
-    if (const char *e = getenv("PASCO_CONV_WIN")) win_on = atoi(e) != 0;
+    if (const char *e = getenv("PASCO_CONV_WIN")) {
+      win_on = atoi(e) != 0;
+      win_wide = atoi(e) == 2;
+    }
     if (const char *e = getenv("PASCO_CONVH_CFG")) has_cfg = sscanf(e, "%d,%d", &cfg_bm, &cfg_kc) >= 1;
     if (const char *e = getenv("PASCO_CONVH_KSPLIT")) {
       has_ksplit = true;
@@ -724,8 +728,12 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   // device-side predicate (window passes per tile, ph_win_build) lets exactly one of them do the work.  Only where no
   // split over the offsets was chosen (its reduction kernel would run unconditionally).
   bool win_pair = false;
-  if (pre && knobs.win_on && !env && d->kvol == 27 && (bn == 64 || bn == 128) && a.ksplit == 1 && d->win_rows &&
-      d->win_cnt && d->win_slots && d->win_stats) {
+  // Measured (profiles/README.md, round 2): 64-wide tiles 638 -> 540 us on the 683 k-row map (two workgroups per CU);
+  // 128-wide tiles lose to the gather kernel (one workgroup per CU: 668 vs 567 us) and stay there unless
+  // PASCO_CONV_WIN=2.
+  if (pre && knobs.win_on && !env && d->kvol == 27 && (bn == 64 || (bn == 128 && (knobs.win_wide || (ph_win_force_bits() & 0x100)))) &&
+      a.ksplit == 1 &&
+      d->win_rows && d->win_cnt && d->win_slots && d->win_stats) {
     a.win_stats = d->win_stats;
     a.win_which = (bn == 64 ? 0 : 1) | ph_win_force_bits();
     a.win_gather = 0;

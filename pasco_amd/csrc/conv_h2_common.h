@@ -60,6 +60,7 @@ __device__ __forceinline__ bool ph_win_pred(const int32_t *stats, int which, int
 int ph_win_force_bits();   // conv_win.hip: 0, 0x100 or 0x200 (ph_conv_win_force, tests only)
 // conv_dma.hip: 256 zero bytes of device memory for absent neighbours
 const char *ph_dma_zero_line();
+int ph_dma_ablate_bits();   // development hook (tools/dma_ablate.py)
 // conv_win.hip
 int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st);
 

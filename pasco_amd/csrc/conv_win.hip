@@ -143,17 +143,22 @@ extern "C" void ph_conv_win_force(int mode) { g_win_force = mode; }
 int ph_win_force_bits() { return g_win_force > 0 ? 0x100 : (g_win_force < 0 ? 0x200 : 0); }
 
 // ---- the convolution -------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, int WMAX, bool EMIT>
-__global__ void __launch_bounds__(HV_THREADS, (WN * TN == 2 ? 2 : 1)) k_conv_win(ConvArgsH a) {
+// WAVES waves as WM x WN: 64-wide tiles run 4 waves (two workgroups per CU), 128-wide tiles 8 waves (one workgroup
+// per CU, two waves per SIMD; with 4 waves the single wave per SIMD could not hide its own LDS / barrier latency:
+// measured 25 % slower than the gather kernel)
+template <int WAVES, int WM, int WN, int TM, int TN, int WMAX, bool EMIT>
+__global__ void __launch_bounds__(WAVES * 64, 2) k_conv_win(ConvArgsH a) {
+  constexpr int NT = WAVES * 64;
+  constexpr int RPP = NT / 8;                       // tile / window rows one DMA pass covers
   constexpr int BM = WIN_BM;
   constexpr int BN = WN * TN * 32;
-  static_assert(WM * WN == 4 && WM * TM * 32 == BM, "tile shape");
+  static_assert(WM * WN == WAVES && WM * TM * 32 == BM, "tile shape");
   constexpr int B_BYTES = BN * 128;
-  constexpr int B_PASSES = BN / 32;
+  constexpr int B_PASSES = BN / RPP;
   constexpr int L = B_PASSES;                       // DMA instructions per thread and stage (weights only)
   constexpr int WIN_BYTES = (WMAX + 1) * 128;       // + the zero row
-  constexpr int W_PASSES = WMAX / 32;
-  static_assert(WMAX % 32 == 0, "window capacity");
+  constexpr int W_PASSES = WMAX / RPP;
+  static_assert(WMAX % RPP == 0 && BN % RPP == 0, "window capacity / tile width vs DMA pass");
   constexpr int OFF_RING = WIN_BYTES;
   constexpr int OFF_SLOT = OFF_RING + 2 * B_BYTES;
   constexpr int OFF_WIDX = OFF_SLOT + WIN_CAP * 2;
@@ -193,7 +198,7 @@ __global__ void __launch_bounds__(HV_THREADS, (WN * TN == 2 ? 2 : 1)) k_conv_win
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(a.win_slots + (int64_t)row_tile * WIN_CAP);
     uint4 *dst = reinterpret_cast<uint4 *>(lds + OFF_SLOT);
-    for (int i = tid; i < WIN_CAP * 2 / 16; i += HV_THREADS) dst[i] = src[i];
+    for (int i = tid; i < WIN_CAP * 2 / 16; i += NT) dst[i] = src[i];
     if (tid < 8) reinterpret_cast<uint4 *>(lds + WMAX * 128)[tid] = make_uint4(0, 0, 0, 0);
   }
   const int cnt = a.win_cnt[row_tile];
@@ -211,7 +216,7 @@ __global__ void __launch_bounds__(HV_THREADS, (WN * TN == 2 ? 2 : 1)) k_conv_win
   uint32_t boff[B_PASSES];
 #pragma unroll
   for (int q = 0; q < B_PASSES; ++q) {
-    int n = n0 + l_r + q * 32;
+    int n = n0 + l_r + q * RPP;
     n = n < cout ? n : cout - 1;
     boff[q] = (uint32_t)n * rsb;
   }
@@ -223,7 +228,7 @@ __global__ void __launch_bounds__(HV_THREADS, (WN * TN == 2 ? 2 : 1)) k_conv_win
     char *bbuf = lds + OFF_RING + buf * B_BYTES;
 #pragma unroll
     for (int q = 0; q < B_PASSES; ++q) {
-      char *dst = bbuf + (q * 32 + wave * 8) * 128;
+      char *dst = bbuf + (q * RPP + wave * 8) * 128;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(wk + boff[q]),
                                        (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     }
@@ -280,8 +285,7 @@ __global__ void __launch_bounds__(HV_THREADS, (WN * TN == 2 ? 2 : 1)) k_conv_win
   };
 #define WIN_WAIT_STAGE()                                                  \
   do {                                                                    \
-    if (L == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          \
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                 \
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                      \
     __builtin_amdgcn_s_barrier();                                         \
   } while (0)
 #define WIN_READS_DONE()                                  \
@@ -289,7 +293,7 @@ __global__ void __launch_bounds__(HV_THREADS, (WN * TN == 2 ? 2 : 1)) k_conv_win
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
     __builtin_amdgcn_s_barrier();                         \
   } while (0)
-  static_assert(L == 2 || L == 4, "vmcnt immediates");
+  static_assert(L == 2, "vmcnt immediate");
 
   Frag f0, f1;
   for (int pass = 0; pass < npass; ++pass) {
@@ -300,7 +304,7 @@ __global__ void __launch_bounds__(HV_THREADS, (WN * TN == 2 ? 2 : 1)) k_conv_win
     __builtin_amdgcn_s_barrier();
     {
       const int32_t *wr = a.win_rows + (int64_t)row_tile * WIN_CAP + base;
-      for (int i = tid; i < WMAX; i += HV_THREADS) widx[i] = i < wp ? wr[i] : -1;
+      for (int i = tid; i < WMAX; i += NT) widx[i] = i < wp ? wr[i] : -1;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -312,38 +316,47 @@ __global__ void __launch_bounds__(HV_THREADS, (WN * TN == 2 ? 2 : 1)) k_conv_win
       // the window: row w of the pass -> LDS row w (lane-linear), source chunk swizzled by w
 #pragma unroll
       for (int p = 0; p < W_PASSES; ++p) {
-        if (p * 32 < wp) {                         // uniform
-          const int ix = widx[p * 32 + l_r];
+        if (p * RPP < wp) {                        // uniform
+          const int ix = widx[p * RPP + l_r];
           uint64_t v = in_base + (uint64_t)(uint32_t)(ix < 0 ? 0 : ix) * rsb + coff;
           asm volatile("" : "+v"(v));
           const uint64_t src = ix >= 0 ? v : zero_src;
-          char *dst = lds + (p * 32 + wave * 8) * 128;
+          char *dst = lds + (p * RPP + wave * 8) * 128;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)src,
                                            (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      // offset loop: fragments one stage ahead in registers, weights two stages ahead in the ring
+      // offset loop, ONE barrier per stage (a barrier costs ~150 clk here: two per stage were a third of the loop):
+      //   fragments of stage k + 1 are read from ring buffer (k + 1) & 1 while the matrix pipe works on stage k;
+      //   then one rendezvous certifies both "every wave has finished reading that buffer" (lgkmcnt) and "every wave's
+      //   weight DMA of stage k + 2 has landed in the other buffer" (vmcnt) - after it the buffer just read is refilled
+      //   with stage k + 3 and the next iteration may read stage k + 2.
       readfrag(0, 0, base, wp, f0);
-      WIN_READS_DONE();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
       fire_w(2, coff, 0);
+#define WIN_STAGE_END()                                                   \
+  do {                                                                    \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           \
+    __builtin_amdgcn_s_barrier();                                         \
+  } while (0)
       for (int k = 0; k < WIN_KV; k += 2) {
-        WIN_WAIT_STAGE();
         readfrag(k + 1, 1, base, wp, f1);
-        WIN_READS_DONE();
-        fire_w(k + 3, coff, 1);
         __builtin_amdgcn_sched_barrier(0);
         mfma(f0);
         __builtin_amdgcn_sched_barrier(0);
-        WIN_WAIT_STAGE();
+        WIN_STAGE_END();
+        fire_w(k + 3, coff, 1);
         readfrag(k + 2, 0, base, wp, f0);
-        WIN_READS_DONE();
-        fire_w(k + 4, coff, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (k + 1 < WIN_KV) mfma(f1);
         __builtin_amdgcn_sched_barrier(0);
+        WIN_STAGE_END();
+        fire_w(k + 4, coff, 0);
       }
+#undef WIN_STAGE_END
       // drain the clamped tail loads before the window and the ring are reused
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -355,7 +368,7 @@ __global__ void __launch_bounds__(HV_THREADS, (WN * TN == 2 ? 2 : 1)) k_conv_win
   h2_store_tile<TM, TN, EMIT>(a, acc, m0, n0, wm, wn, h, l31);
 }
 
-template <int WM, int WN, int TM, int TN, int WMAX>
+template <int WAVES, int WM, int WN, int TM, int TN, int WMAX>
 static int launch_win(const ConvArgsH &a, hipStream_t st) {
   constexpr int BN = WN * TN * 32;
   ConvArgsH args = a;
@@ -365,9 +378,9 @@ static int launch_win(const ConvArgsH &a, hipStream_t st) {
   const int grid = ((ntiles + 7) / 8) * 8;
   const bool emit = args.out_split != nullptr;
   if (emit)
-    hipLaunchKernelGGL((k_conv_win<WM, WN, TM, TN, WMAX, true>), dim3(grid), dim3(HV_THREADS), 0, st, args);
+    hipLaunchKernelGGL((k_conv_win<WAVES, WM, WN, TM, TN, WMAX, true>), dim3(grid), dim3(WAVES * 64), 0, st, args);
   else
-    hipLaunchKernelGGL((k_conv_win<WM, WN, TM, TN, WMAX, false>), dim3(grid), dim3(HV_THREADS), 0, st, args);
+    hipLaunchKernelGGL((k_conv_win<WAVES, WM, WN, TM, TN, WMAX, false>), dim3(grid), dim3(WAVES * 64), 0, st, args);
   PH_LAUNCH_CHECK();
   return 0;
 }
@@ -378,14 +391,15 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st) {
   b.ksplit = 1;
   b.partial = nullptr;
   b.zero = ph_dma_zero_line();
+  b.ablate = ph_dma_ablate_bits();
   if (b.zero == nullptr) {
     ph_set_error("conv_fwd(windows): no zero line");
     return 2;
   }
   if (bn == 64) {
     b.win_which = 0 | ph_win_force_bits();
-    return launch_win<4, 1, 1, 2, WIN_MAX_64>(b, st);
+    return launch_win<4, 4, 1, 1, 2, WIN_MAX_64>(b, st);
   }
   b.win_which = 1 | ph_win_force_bits();
-  return launch_win<2, 2, 2, 2, WIN_MAX_128>(b, st);
+  return launch_win<8, 2, 4, 2, 1, WIN_MAX_128>(b, st);
 }

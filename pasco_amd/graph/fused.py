@@ -10,6 +10,7 @@
   same kernel."""
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -24,6 +25,7 @@ _PRESPLIT = True     # f16x3 operands pre-split once per tensor (mma_mode 2) ins
 _FUSION = True       # False: route (a) of INTEGRATION.md - every block as the reference's own module sequence
 MIN_ROWS_LINEAR = 16384    # tall-operand threshold above which linear layers run on the convolution kernel
 MIN_ROWS_WINDOWS = 16384   # 3x3x3 maps with at least this many rows get LDS-window tables (conv_win.hip)
+_WINDOWS_WIDE = os.environ.get("PASCO_CONV_WIN", "1") == "2"   # tables for 128-wide layers too (experiments)
 
 
 def _kernel_device(device) -> bool:
@@ -354,7 +356,7 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     only = split_only and emit is not None and n_out > 0
     win = None
     if in_split is not None and nbr is not None and nbr.shape[0] == 27 and n_out >= MIN_ROWS_WINDOWS and \
-            be.device_type == "cuda" and min(mod.in_channels, mod.out_channels) >= 64:
+            be.device_type == "cuda" and (33 <= mod.out_channels <= 64 or _WINDOWS_WIDE):   # 64-wide tiles (measured)
         win = mgr.kernel_windows(nbr)
     out = be.conv_fwd(
         x_rows, mod.kernel.detach(), nbr, n_out, xshape=xshape, bias=bias,

@@ -19,13 +19,21 @@ def _force(hip, mode):
     hip.lib.ph_conv_win_force(mode)
 
 
-def s10_map(hip, shuffle=False, n=None):
+def s10_map(hip, shuffle=False, n=None, generative=False):
+    """3x3x3 kernel map of the S10 scene.  generative=True: the rows of the decoder's stride-1 level - all 8 children
+    of the stride-2 voxels, parent-major (octree order: runs of rows are compact bricks); else the lexicographic
+    voxel list, optionally shuffled (no locality at all)."""
     g1 = np.argwhere(make_occupancy(0))
-    if n is not None:
-        g1 = g1[:n]
-    if shuffle:
-        g1 = g1[np.random.default_rng(0).permutation(g1.shape[0])]
     c = torch.from_numpy(np.concatenate([np.zeros((g1.shape[0], 1), np.int64), g1], 1)).int().cuda().contiguous()
+    if generative:
+        c4 = hip.coords_floor(c, 4)
+        _, _, _, uq4, _ = hip.map_insert(c4)
+        c2 = hip.coords_expand(c4[uq4.long()].contiguous(), 2)          # children of the stride-4 voxels ...
+        c = hip.coords_expand(c2, 1)                                     # ... and theirs: two generative levels
+    if shuffle:
+        c = c[torch.from_numpy(np.random.default_rng(0).permutation(c.shape[0])).cuda()].contiguous()
+    if n is not None:
+        c = c[:n].contiguous()
     tk, tv, _, _, _ = hip.map_insert(c, dedup=False)
     return hip.nbr_build(c, tk, tv, kernel_offsets(3, 1))
 
@@ -61,22 +69,28 @@ def _conv_case(hip, nbr, cin, cout, g, emit=False):
 @pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (64, 128), (256, 256)])
 def test_window_conv_equals_gather_conv(hip, cin, cout):
     """The same launch with and without window tables on the S10 map (windows chosen by the device-side predicate)."""
-    nbr = s10_map(hip, n=90000 if cin == 256 else None)
+    nbr = s10_map(hip, n=90112 if cin == 256 else 300032, generative=True)
     n = nbr.shape[1]
     win = hip.win_build(nbr)
     passes = win["stats"].tolist()
     tiles = (n + 127) // 128
-    assert passes[0] * 4 <= tiles * 5 and passes[1] * 4 <= tiles * 5, "the S10 map should be window-friendly"
+    assert passes[0] * 4 <= tiles * 5 and passes[1] * 4 <= tiles * 5, "a generative-order map should be window-friendly"
     g = torch.Generator(device="cuda").manual_seed(7)
     x, w, kw = _conv_case(hip, nbr, cin, cout, g, emit=True)
     split = hip.split_weight_rows(w)
     ref, ref_s = hip.conv_fwd(x, w, nbr, n, split=split, **kw)
     cfg_ref = hip.conv_last_config()
-    got, got_s = hip.conv_fwd(x, w, nbr, n, split=split, win=win, **kw)
+    _force(hip, 1)          # 128-wide tiles use windows only on request (measured slower): force the window side
+    try:
+        got, got_s = hip.conv_fwd(x, w, nbr, n, split=split, win=win, **kw)
+    finally:
+        _force(hip, 0)
     cfg = hip.conv_last_config()
-    assert cfg["kernel"] == 5 and cfg_ref["kernel"] in (2, 4)
-    scale = float(ref.abs().mean())
-    assert float((got - ref).abs().max()) <= 2e-5 * scale + 1e-6, float((got - ref).abs().max())
+    assert cfg_ref["kernel"] in (2, 4) and cfg["kernel"] == 5
+    # same products, different fp32 summation order (chunk-major vs offset-major): rounding-level agreement, measured
+    # against the largest magnitude the sums reach
+    big = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 4e-6 * big, (float((got - ref).abs().max()), big)
     # the emitted operand is the split of the fp32 result either way
     want = hip.split_rows(got, pro_scale=kw["emit_split"][0], pro_shift=kw["emit_split"][1], pro_act=1)
     assert torch.equal(got_s.view(torch.int16), want.view(torch.int16))
@@ -93,11 +107,12 @@ def test_window_conv_equals_gather_conv(hip, cin, cout):
     hip.check_status(x.device)
 
 
-@pytest.mark.parametrize("cin,cout,n", [(64, 64, 20000), (128, 128, 9000), (64, 64, 129)])
+@pytest.mark.parametrize("cin,cout,n", [(64, 64, None), (128, 128, None), (64, 64, 129)])
 def test_window_conv_multi_pass_and_ragged(hip, oracle, cin, cout, n):
-    """A shuffled map has no locality (windows of > 1000 rows): forced onto the window kernel it runs 3 - 8 passes
-    per tile; the result must still be the convolution (oracle on fp32 operands)."""
-    nbr = s10_map(hip, shuffle=True, n=n)
+    """A shuffled map has no locality (windows of > 1000 rows): forced onto the window kernel it runs 3 - 5 passes
+    per tile; the result must still be the convolution (oracle on fp32 operands).  n = 129: a ragged second tile."""
+    nbr = s10_map(hip, shuffle=n is None, n=n)
+    n = nbr.shape[1]
     win = hip.win_build(nbr)
     if n >= 9000:
         assert int(win["cnt"].max()) > 1024, "the shuffled map should need several passes"
@@ -111,10 +126,12 @@ def test_window_conv_multi_pass_and_ragged(hip, oracle, cin, cout, n):
         _force(hip, 0)
     ref = hip.conv_fwd(x, w, nbr, n, split=split, **kw)
     scale = float(ref.abs().mean())
-    assert float((got - ref).abs().max()) <= 2e-5 * scale + 1e-6
+    assert float((got - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
+    rows = torch.randperm(n, device="cuda", generator=g)[:3000].sort()[0]      # the oracle on a row sample
     okw = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
-    exp = oracle.conv_fwd(x.cpu(), w.cpu(), nbr.cpu(), n, **okw)
-    assert torch.allclose(got.cpu(), exp, rtol=1e-4, atol=1e-4 * scale)
+    okw["residual"] = kw["residual"][rows].cpu()
+    exp = oracle.conv_fwd(x.cpu(), w.cpu(), nbr[:, rows].contiguous().cpu(), rows.shape[0], **okw)
+    assert torch.allclose(got[rows].cpu(), exp, rtol=1e-4, atol=1e-4 * scale)
     # the predicate would have sent this map to the gather kernel
     if n >= 9000:
         tiles = (n + 127) // 128
