@@ -226,7 +226,8 @@ def linear_bn_act(x2d: Optional[torch.Tensor], lin: nn.Linear, *, pro_bn=None, e
     out = be.conv_fwd(None if x2d is None else x2d.contiguous(), wt, None, n, xshape=(n, cin) if x2d is None else None,
                       bias=b, pro_scale=ps, pro_shift=pb, epi_scale=es, epi_shift=eb, epi_act=epi_act, split=split,
                       in_split=in_split if (split is not None and _PRESPLIT) else None,
-                      emit_split=(None, None, ACT_NONE) if do_emit else None, want_out=not do_emit)
+                      emit_split=(None, None, ACT_NONE) if do_emit else None, want_out=not do_emit,
+                      in_split_has_prologue=True)
     if not emit:
         return out
     return out if do_emit else (out, None)
@@ -362,7 +363,7 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
         x_rows, mod.kernel.detach(), nbr, n_out, xshape=xshape, bias=bias,
         pro_scale=ps, pro_shift=pb, pro_act=pro_act, epi_scale=es, epi_shift=eb, epi_act=epi_act,
         epi2_scale=e2s, epi2_shift=e2b, residual=residual, res_act=res_act, slope=slope, split=split,
-        in_split=in_split, emit_split=emit, want_out=not only, win=win)
+        in_split=in_split, emit_split=emit, want_out=not only, win=win, in_split_has_prologue=True)
     if emit is None:
         return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
     out, out_split = out

@@ -137,12 +137,18 @@ class CBackend:
             return torch.cuda.current_stream(device).cuda_stream
         return None
 
+    def _stream_key(self, device: torch.device):
+        """Scratch buffers are reused from launch to launch, which is only safe in stream order: one set per
+        (device, stream)."""
+        return (device, self.stream(device) or 0)
+
     def workspace(self, n: int, device: torch.device) -> torch.Tensor:
         need = int(self.fn["workspace_bytes"](int(n)))
-        ws = self._ws.get(device)
+        key = ("ws",) + self._stream_key(device)
+        ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
             ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
-            self._ws[device] = ws
+            self._ws[key] = ws
         return ws
 
     def _chk(self, t: torch.Tensor, dtype, name: str):
@@ -265,7 +271,7 @@ class CBackend:
                  epi_shift=None, epi_act=ACT_NONE, slope=0.01, residual=None, res_act=ACT_NONE,
                  epi2_scale=None, epi2_shift=None, split=None, in_split: Optional[torch.Tensor] = None,
                  emit_split=None, want_out: bool = True,
-                 out: Optional[torch.Tensor] = None, win=None):
+                 out: Optional[torch.Tensor] = None, win=None, in_split_has_prologue: bool = False):
         """out = epilogue(sum_k gather(prologue(x))[k] @ W[k]) - one `ph_conv_fwd` launch (include/pasco_hip.h).
 
         `split` selects the split-precision products: (w_hi, w_lo, unscale) from `split_weight_f16` = mode 1
@@ -342,6 +348,12 @@ class CBackend:
                 w_split, unscale = split
                 if in_split is None:
                     in_split = self.split_rows(x, pro_scale=pro_scale, pro_shift=pro_shift, pro_act=pro_act, slope=slope)
+                elif not x.is_meta and (pro_scale is not None or pro_shift is not None or pro_act != ACT_NONE) and \
+                        not in_split_has_prologue:
+                    # the device library never applies a prologue in mode 2: a caller-made operand must already carry it
+                    raise ValueError("conv: in_split given together with a prologue - pass in_split_has_prologue=True if "
+                                     "the operand was built with split_rows(x, pro_scale=..., pro_shift=..., pro_act=...), "
+                                     "else drop in_split")
                 cpad = (cin + 31) // 32 * 32
                 if in_split.dtype != torch.float16 or in_split.numel() != x.shape[0] * 2 * cpad:
                     raise ValueError("conv: in_split does not match the input rows")
@@ -359,7 +371,7 @@ class CBackend:
             d.status = _ptr(self.status_word(dev))
             if n_out * cout <= (1 << 23):          # few-row layer: offer scratch for a split over the offsets
                 need = 8 * n_out * cout * 4
-                key = ("splitk", dev)
+                key = ("splitk",) + self._stream_key(dev)
                 sk = self._ws.get(key)
                 if sk is None or sk.numel() < need:
                     sk = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -625,7 +637,7 @@ class CBackend:
         assert k.shape == (b, n, h * dh) and v.shape == k.shape
         out = torch.empty((b, qn, h * dh), dtype=torch.float32, device=q.device)
         need = int(self.fn["attn_workspace_bytes"](n, b, h, qn, dh))
-        key = ("attn", q.device)
+        key = ("attn",) + self._stream_key(q.device)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=q.device)

@@ -246,7 +246,7 @@ def test_sine_pe_matches_oracle_and_torch(hip, oracle):
     assert torch.equal(got, direct)
 
 
-def test_gram_batched_matches_matmul():
+def test_gram_batched_matches_matmul(hip):
     from pasco_amd.graph.ensemble import _gram
     g = torch.Generator().manual_seed(91)
     a, b = torch.rand(100003, 100, generator=g).cuda(), torch.rand(100003, 100, generator=g).cuda()
