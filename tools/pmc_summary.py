@@ -1,5 +1,5 @@
 """Summarise rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE) for the conv kernels.
-usage: pmc_summary.py <fetch_counter_csv> <write_counter_csv> <out.json>
+usage: pmc_summary.py <fetch_counter_csv> <write_counter_csv> <out.json> [commit-id]
 HBM bytes = FETCH_SIZE * 2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md "HBM") + WRITE_SIZE,
 both reported by rocprofv3 in KiB."""
 import csv, json, sys
@@ -17,8 +17,8 @@ def per_kernel(path, counter):
             per[key] += float(r["Counter_Value"])
             names[key] = r.get("Kernel_Name", "")
     out = {}
-    for kern in ("k_conv_h2", "k_conv_f16x3", "k_conv_mfma", "k_split_rows"):
-        vals = [v for k, v in per.items() if kern in names[k]]
+    for kern in ("k_conv_dma", "k_conv_win", "k_conv_h2", "k_conv_f16x3", "k_conv_mfma", "k_conv_rl", "k_split_rows", "k_win_build"):
+        vals = [v for k, v in per.items() if kern + "<" in names[k] or kern + "(" in names[k] or names[k].startswith("_Z") and kern in names[k]]
         if vals:
             out[kern] = (sum(vals) / len(vals), len(vals))
     return out
@@ -26,7 +26,7 @@ def per_kernel(path, counter):
 
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
-res = {"kernels": {}, "note": "FETCH_SIZE doubled (gfx950 128-B requests tallied at 64 B); Infinity-Cache hits are counted, "
+res = {"commit": sys.argv[4] if len(sys.argv) > 4 else None, "kernels": {}, "note": "FETCH_SIZE doubled (gfx950 128-B requests tallied at 64 B); Infinity-Cache hits are counted, "
                                "not excluded"}
 for kern in fetch:
     if kern in write:
