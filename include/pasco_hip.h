@@ -179,6 +179,15 @@ typedef struct ph_conv_desc {
   const int32_t *win_cnt;    /* [ntiles] */
   const uint16_t *win_slots; /* [ntiles][27][128] */
   const int32_t *win_stats;  /* [4] */
+  /* mode 2, optional per-axis TABLE residual (the sine position encoding of the mask transformer,
+   * position_encoding.py:90-135 via transformer_predictor_v2.py:143,150, without materialising it): the row
+   *     axis_table[0][x - lo] + axis_table[1][y - lo] + axis_table[2][z - lo]      (each [cout])
+   * with (x, y, z) = axis_coords[o][1..3] is added where `residual` is added (coordinate values are clamped to the
+   * table).  axis_table is fp32 [3][axis_rows][cout]; axis_coords int32 [n_out][4]. */
+  const float *axis_table;
+  const int32_t *axis_coords;
+  int32_t axis_lo;
+  int32_t axis_rows;
 } ph_conv_desc;
 
 int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);

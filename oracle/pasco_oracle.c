@@ -383,9 +383,19 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
           float v = acc[(int64_t)r * cout + n] + (d->bias ? d->bias[n] : 0.f);
           v = v * (d->epi_scale ? d->epi_scale[n] : 1.f) + (d->epi_shift ? d->epi_shift[n] : 0.f);
           v = act_apply(v, d->epi_act, d->epi_slope);
-          if (d->residual || d->epi2_scale || d->epi2_shift || d->res_act != PH_ACT_NONE) {
+          if (d->residual || d->epi2_scale || d->epi2_shift || d->res_act != PH_ACT_NONE || d->axis_table) {
             v = v * (d->epi2_scale ? d->epi2_scale[n] : 1.f) + (d->epi2_shift ? d->epi2_shift[n] : 0.f);
-            if (d->residual) v += d->residual[o * cout + n];
+            float r = d->residual ? d->residual[o * cout + n] : 0.f;
+            if (d->axis_table) {   /* per-axis table residual: t0[x] + t1[y] + t2[z], then the dense residual */
+              float t = 0.f;
+              for (int ax = 0; ax < 3; ++ax) {
+                int idx = d->axis_coords[o * 4 + 1 + ax] - d->axis_lo;
+                idx = idx < 0 ? 0 : (idx >= d->axis_rows ? d->axis_rows - 1 : idx);
+                t += d->axis_table[((int64_t)ax * d->axis_rows + idx) * cout + n];
+              }
+              r += t;
+            }
+            v += r;
             v = act_apply(v, d->res_act, d->epi_slope);
           }
           outp[o * cout + n] = v;

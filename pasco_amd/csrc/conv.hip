@@ -356,6 +356,7 @@ extern "C" int ph_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   PH_REQUIRE((d->out || (d->mma_mode == 2 && d->out_split)) && (d->mma_mode == 2 || (d->in && d->weight)), "conv_fwd: null tensor");
   if (d->mma_mode == 1 || d->mma_mode == 2) return ph_conv_fwd_f16x3(d, ph_stream(stream));
   PH_REQUIRE(d->mma_mode == 0, "conv_fwd: unknown mma_mode %d", d->mma_mode);
+  PH_REQUIRE(d->axis_table == nullptr, "conv_fwd: axis_table is served by mma_mode 2");
   ConvArgs a;
   a.in = d->in;
   a.w = d->weight;

@@ -503,6 +503,10 @@ __global__ void __launch_bounds__(256) k_splitk_epilogue(ConvArgsH a) {
   const float av[4] = {acc.x, acc.y, acc.z, acc.w};
   float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.has_tail && a.residual) rs = *reinterpret_cast<const float4 *>(a.residual + t);
+  if (a.has_tail && a.axis_table) {
+    const float4 tb = ph_axis_residual4(a, row, col);
+    rs = make_float4(tb.x + rs.x, tb.y + rs.y, tb.z + rs.z, tb.w + rs.w);
+  }
   const float r4[4] = {rs.x, rs.y, rs.z, rs.w};
   float v[4];
 #pragma unroll
@@ -669,7 +673,16 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.res_neg = neg_of(d->res_act);
   a.w_unscale = d->w_unscale;
   a.has_pro = (d->pro_scale || d->pro_shift || d->pro_act != PH_ACT_NONE) ? 1 : 0;   // mode 2: already applied by ph_split_rows
-  a.has_tail = (d->residual || d->epi2_scale || d->epi2_shift || d->res_act != PH_ACT_NONE) ? 1 : 0;
+  a.has_tail = (d->residual || d->epi2_scale || d->epi2_shift || d->res_act != PH_ACT_NONE || d->axis_table) ? 1 : 0;
+  a.axis_table = d->axis_table;
+  a.axis_coords = d->axis_coords;
+  a.axis_lo = d->axis_lo;
+  a.axis_rows = d->axis_rows;
+  if (d->axis_table) {
+    PH_REQUIRE(pre, "conv_fwd: axis_table needs mma_mode 2");
+    PH_REQUIRE(d->axis_coords && d->axis_rows > 0 && d->cout % 4 == 0 && (((uintptr_t)d->axis_table | (uintptr_t)d->axis_coords) & 15) == 0,
+               "conv_fwd: axis_table needs axis_coords, axis_rows > 0, 16-byte alignment");
+  }
   a.n_row_tiles = a.n_col_tiles = 0;
   a.status = d->status;
   a.zero = nullptr;

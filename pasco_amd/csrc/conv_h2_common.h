@@ -48,7 +48,26 @@ struct ConvArgsH {
   const uint16_t *win_slots;
   int win_which;              // statistics slot of the tile shape (0: 64-wide / 416 rows, 1: 128-wide / 512 rows)
   int win_gather;             // 1 on the gather kernel of the pair (inverted predicate)
+  // per-axis table residual (ph_conv_desc.axis_table): [3][axis_rows][cout], coordinates [n_out][4]
+  const float *axis_table;
+  const int32_t *axis_coords;
+  int axis_lo, axis_rows;
 };
+
+// t0[x] + t1[y] + t2[z] for 4 consecutive channels of one output row (coordinates clamped to the table)
+__device__ __forceinline__ float4 ph_axis_residual4(const ConvArgsH &a, int64_t row, int col) {
+  const int4 c = *reinterpret_cast<const int4 *>(a.axis_coords + row * 4);
+  const int v[3] = {c.y, c.z, c.w};
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    int idx = v[ax] - a.axis_lo;
+    idx = idx < 0 ? 0 : (idx >= a.axis_rows ? a.axis_rows - 1 : idx);
+    const float4 t = *reinterpret_cast<const float4 *>(a.axis_table + ((int64_t)ax * a.axis_rows + idx) * a.cout + col);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+  return s;
+}
 
 // mean window passes per tile <= 1.25 -> the window kernel serves the map (which: bit 8 / 9 = test override:
 // always / never windows)
@@ -170,6 +189,10 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
           if (a.has_tail) {
             float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.residual && rok && cok[u]) rs = *reinterpret_cast<const float4 *>(a.residual + row * cout + col);
+            if (a.axis_table && rok && cok[u]) {   // table rows first, then the dense residual (as the C restatement)
+              const float4 t = ph_axis_residual4(a, row, col);
+              rs = make_float4(t.x + rs.x, t.y + rs.y, t.z + rs.z, t.w + rs.w);
+            }
             const float r4[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[u][q] = h_act(v[u][q] * es2[u][q] + eb2[u][q] + r4[q], a.res_neg);

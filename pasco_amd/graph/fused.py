@@ -143,12 +143,14 @@ def split_rows_2d(x2d: torch.Tensor):
 
 def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_owner, cache_key: str,
                 min_rows: Optional[int] = None, in_split=None, residual: Optional[torch.Tensor] = None,
-                emit: bool = False, want_out: bool = True):
+                emit: bool = False, want_out: bool = True, axis=None):
     """y = x @ weight.T + bias for a tall [N, cin] operand (`weight` is an nn.Linear-style [cout, cin] tensor
     or a row slice of one).  Large N on the GPU goes through the convolution kernel as an identity-map k=1
     convolution - the same split-precision MFMA GEMM with fused bias - instead of an fp32 library GEMM;
     everything else (small N, CPU checker backend, odd shapes) is torch.nn.functional.linear.
-    `residual` [N, cout] (optional) is added in the same launch (y + residual).
+    `residual` [N, cout] (optional) is added in the same launch (y + residual); `axis` = (table [3, T, cout], coords
+    int32 [N, 4], lo) adds the per-axis table rows table[0][x - lo] + table[1][y - lo] + table[2][z - lo] the same way
+    (the sine position encoding without materialising it).
     `x2d` may be None when `in_split` (its pre-split operand) is given.
     `emit`: also return the pre-split operand of y for a following linear_rows / batched_rows_matmul -> (y, y_split);
     y_split is None when the split path did not apply, and with `want_out=False` y is None when it did."""
@@ -166,6 +168,8 @@ def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_o
         assert x2d is not None, "linear_rows: a pre-split operand needs the split path"
         y = torch.nn.functional.linear(x2d, weight, bias)
         y = y if residual is None else y + residual
+        if axis is not None:
+            y = y + axis_rows(axis)
         return (y, None) if emit else y
     ver = (weight._version, weight.device, weight.data_ptr(), _PRESPLIT)
     hit = cache_owner.__dict__.get("_ph_lin_" + cache_key)
@@ -179,10 +183,18 @@ def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_o
                       xshape=(n, cin) if x2d is None else None, bias=b, split=split,
                       in_split=in_split if _PRESPLIT else None,
                       residual=None if residual is None else residual.contiguous(),
-                      emit_split=(None, None, ACT_NONE) if do_emit else None, want_out=want_out or not do_emit)
+                      emit_split=(None, None, ACT_NONE) if do_emit else None, want_out=want_out or not do_emit,
+                      axis=axis)
     if not emit:
         return out
     return out if do_emit else (out, None)
+
+
+def axis_rows(axis) -> torch.Tensor:
+    """The rows the per-axis table residual stands for (torch formulation: reference / fallback paths)."""
+    tab, coords, lo = axis
+    idx = (coords[:, 1:4].long() - lo).clamp(0, tab.shape[1] - 1)
+    return tab[0][idx[:, 0]] + tab[1][idx[:, 1]] + tab[2][idx[:, 2]]
 
 
 def linear_bn_act(x2d: Optional[torch.Tensor], lin: nn.Linear, *, pro_bn=None, epi_bn=None, epi_act: int = ACT_NONE,

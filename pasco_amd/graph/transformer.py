@@ -60,17 +60,37 @@ class PositionEmbeddingSineSparse(nn.Module):
             self.__dict__["_dim_t"] = hit
         return hit
 
+    def table(self, device) -> torch.Tensor:
+        """[T, f] encodings of one axis for the integer values TABLE_LO .. TABLE_HI - 1 (the encoding of an axis depends
+        on that axis' integer value only; evaluated by the same entry point as the rows, so a lookup returns exactly
+        what the evaluation would)."""
+        tab = self.__dict__.get("_table")
+        if tab is None or tab.device != device:      # 2.6 MB, built once
+            tab = backend_for(device).sine_pe_table(self.dim_t(device), self.scale, self.TABLE_LO, self.TABLE_HI)
+            self.__dict__["_table"] = tab
+        return tab
+
+    def block_table(self, device) -> torch.Tensor:
+        """[3, T, 3 f]: axis a's table in channel block a, zeros elsewhere - the encoding itself as a per-axis table
+        residual (ph_conv_desc.axis_table)."""
+        bt = self.__dict__.get("_block_table")
+        if bt is None or bt.device != device:
+            tab = self.table(device)
+            T, f = tab.shape
+            bt = torch.zeros((3, T, 3 * f), dtype=tab.dtype, device=device)
+            for a in range(3):
+                bt[a, :, a * f:(a + 1) * f] = tab
+            self.__dict__["_block_table"] = bt.contiguous()
+            bt = self.__dict__["_block_table"]
+        return bt
+
     def forward(self, coords, coff: int = 0):
         """coords [N, >=3] integer rows with x,y,z from column `coff`.  On a device with a backend: one kernel
         (ph_sine_pe); otherwise the torch formula."""
         if coords.dtype == torch.int32 and coords.is_contiguous() and (coords.is_cuda or _has_checker()):
             be = backend_for(coords.device)
             dim_t = self.dim_t(coords.device)
-            tab = self.__dict__.get("_table")
-            if tab is None or tab.device != coords.device:      # one axis, values -1024 .. 4095: 2.6 MB, built once
-                tab = be.sine_pe_table(dim_t, self.scale, self.TABLE_LO, self.TABLE_HI)
-                self.__dict__["_table"] = tab
-            return be.sine_pe(coords, dim_t, self.scale, coff, table=tab, tab_lo=self.TABLE_LO)
+            return be.sine_pe(coords, dim_t, self.scale, coff, table=self.table(coords.device), tab_lo=self.TABLE_LO)
         return sine_position_encoding(coords[:, coff:coff + 3], self.num_pos_feats, self.temperature, self.scale)
 
 
@@ -149,6 +169,46 @@ class CrossAttentionLayer(nn.Module):
         return q + mha.out_proj(o)
 
 
+    def attend(self, q_embed, kk, vv, query_pos, mask_bits):
+        """The layer with keys / values already projected ([B, N, D] each): query projection, masked attention
+        (ph_attn_cross_fwd), output projection, residual."""
+        q = self.norm(q_embed)
+        mha = self.multihead_attn
+        B, Q, D = q.shape
+        H = self.nhead
+        w, b = mha.in_proj_weight, mha.in_proj_bias
+        qq = F.linear(q if query_pos is None else q + query_pos, w[:D], b[:D]).view(B, Q, H, D // H).transpose(1, 2)
+        be = backend_for(q.device)
+        q4 = (qq * (float(D // H) ** -0.5)).contiguous()
+        o = be.attn_cross_fwd(q4, kk.contiguous(), vv.contiguous(), mask_bits[0], mask_bits[1])
+        return q + mha.out_proj(o)
+
+    def composed_kv(self, lin: nn.Linear, tab: torch.Tensor):
+        """K and V projections composed with the level's input projection `lin` and with the position table:
+            K = (x W_p^T + b_p + pos) W_k^T + b_k = x (W_k W_p)^T + (W_k b_p + b_k) + pos W_k^T,
+        pos = [tab[x] | tab[y] | tab[z]]  =>  pos W_k^T = sum over the axes of (tab W_k[:, axis block]^T)[coordinate].
+        -> dict(wk, bk, tk, wv, bv, tv): weights [D, cin], biases [D], tables [3, T, D]; cached per parameter version.
+        (Products in fp64, rounded once: the composed map is the same linear map as the sequence, to fp32 rounding.)"""
+        mha = self.multihead_attn
+        w, b = mha.in_proj_weight, mha.in_proj_bias
+        ver = tuple((p._version, p.data_ptr()) for p in (w, b, lin.weight, lin.bias)) + (tab.data_ptr(),)
+        hit = self.__dict__.get("_ph_composed")
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        D = w.shape[1]
+        f = tab.shape[1]
+        out = {}
+        with torch.no_grad():
+            wp, bp, t64 = lin.weight.double(), lin.bias.double(), tab.double()
+            for name, sl in (("k", slice(D, 2 * D)), ("v", slice(2 * D, 3 * D))):
+                wx, bx = w[sl].double(), b[sl].double()
+                out["w" + name] = (wx @ wp).float().contiguous()
+                out["b" + name] = (wx @ bp + bx).float().contiguous()
+                out["t" + name] = torch.stack([t64 @ wx[:, a * f:(a + 1) * f].t() for a in range(3)]).float().contiguous()
+        self.__dict__["_ph_composed"] = (ver, out)
+        return out
+
+
 class FFNLayer(nn.Module):
     def __init__(self, d_model, dim_feedforward=2048, dropout=0.0):
         super().__init__()
@@ -175,6 +235,28 @@ class MLP(nn.Module):
             if i < self.num_layers - 1:
                 x = F.relu(x)
         return x
+
+
+class LazyRows:
+    """A sparse tensor whose feature rows are a row selection of a bigger matrix, gathered on first access
+    (`.F` / `.C` / `.features` / `.coordinates`, or `.materialize()` for the ME.SparseTensor itself)."""
+
+    def __init__(self, src: torch.Tensor, rows: torch.Tensor, key, mgr):
+        self._src, self._rows = src, rows
+        self.coordinate_map_key, self.coordinate_manager = key, mgr
+        self._st = None
+
+    def materialize(self):
+        if self._st is None:
+            self._st = ME.SparseTensor(self._src.index_select(0, self._rows), coordinate_map_key=self.coordinate_map_key,
+                                       coordinate_manager=self.coordinate_manager)
+            self._src = self._rows = None
+        return self._st
+
+    def __getattr__(self, name):          # F, C, features, coordinates, dense(), ...: whatever SparseTensor offers
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
 
 
 class TransformerPredictorV2(nn.Module):
@@ -356,21 +438,42 @@ class TransformerPredictorV2(nn.Module):
             output, query_embed = output[sel], query_embed[sel]
             min_Cs = [min_Cs[i] for i in subnets]
             max_Cs = [max_Cs[i] for i in subnets]
-        srcs, src_Cs, pos = [], [], []
+        srcs, src_Cs = [], []
         for s in self.src_scales:
             f, c = xs[s]
             srcs.append(f)
             src_Cs.append(c)
-            pos.append(self.pe_layer(c.reshape(-1, 4), coff=1).reshape(B, -1, D))
+        pos_cache = {}
+
+        def pos_of(i):          # materialised only on the paths that need the encoding as a tensor
+            if i not in pos_cache:
+                pos_cache[i] = self.pe_layer(src_Cs[i].reshape(-1, 4), coff=1).reshape(B, -1, D)
+            return pos_cache[i]
+
         voxel_coord = xs[1][1]
         x1 = xs[1][0]
+        dev = x1.device
+        # with the convolution kernel the position encoding is never materialised: it enters the projections' epilogues
+        # as three table rows per voxel (ph_conv_desc.axis_table)
+        use_tables = fused_mod.fusion() and fused_mod._kernel_device(dev) and fused_mod.conv_precision() == "f16x3" and \
+            os.environ.get("PASCO_PE_TABLE", "1") != "0"
+        tab = self.pe_layer.table(dev) if use_tables else None
         # voxel features of the mask heads: read only as the operand of `voxel_feat @ mask_embed^T`, so with the
         # split kernel the projection writes that operand directly (no fp32 copy, no separate split pass)
         P = x1.shape[1]
         heads_split = self.num_queries % 4 == 0
-        voxel_feat, vf_split = linear_rows(x1.reshape(-1, x1.shape[-1]), self.mask_feat_proj.weight,
-                                           self.mask_feat_proj.bias, self.mask_feat_proj, "w",
-                                           residual=pos[-1].reshape(-1, D), emit=True, want_out=not heads_split)
+        c1 = src_Cs[-1].reshape(-1, 4)
+        tables_ok = use_tables and c1.dtype == torch.int32 and x1.shape[0] * P >= fused_mod.MIN_ROWS_LINEAR
+        if tables_ok:
+            voxel_feat, vf_split = linear_rows(x1.reshape(-1, x1.shape[-1]), self.mask_feat_proj.weight,
+                                               self.mask_feat_proj.bias, self.mask_feat_proj, "w",
+                                               axis=(self.pe_layer.block_table(dev), c1.contiguous(), self.pe_layer.TABLE_LO),
+                                               emit=True, want_out=not heads_split)
+        else:
+            voxel_feat, vf_split = linear_rows(x1.reshape(-1, x1.shape[-1]), self.mask_feat_proj.weight,
+                                               self.mask_feat_proj.bias, self.mask_feat_proj, "w",
+                                               residual=pos_of(len(self.src_scales) - 1).reshape(-1, D), emit=True,
+                                               want_out=not heads_split)
         if not heads_split:
             vf_split = None
         if voxel_feat is not None:
@@ -389,25 +492,39 @@ class TransformerPredictorV2(nn.Module):
             N_i, Qn = srcs[i].shape[1], om.shape[2]
             be = backend_for(srcs[i].device)
             fused_attn = be.attn_supported(Qn, D // self.nheads)
-            # with the fused attention kernel src + pos is read only by the K / V projections: emit it as their
-            # operand (no fp32 copy)
-            src_F, src_split = linear_rows(srcs[i].reshape(-1, srcs[i].shape[-1]), lin.weight, lin.bias, lin, "w",
-                                           residual=pos[i].reshape(-1, D), emit=True, want_out=not fused_attn)
-            if src_F is not None:
-                src_F = src_F.view(B, -1, D)
+            ca = self.transformer_cross_attention_layers[i]
+            ci = src_Cs[i].reshape(-1, 4)
             bits, any_ = self.compute_mask_bits(om, voxel_coord, src_Cs[i], self.src_scales[i], min_Cs, max_Cs,
                                                 cache=mask_cache)
-            if fused_attn:
-                output = self.transformer_cross_attention_layers[i](output, src_F, pos=None, query_pos=query_embed,
-                                                                    mask_bits=(bits, any_), feats_split=src_split,
-                                                                    feats_shape=(B, N_i, D))
+            if fused_attn and use_tables and ci.dtype == torch.int32 and B * N_i >= fused_mod.MIN_ROWS_LINEAR:
+                # K and V straight from the level's features: input projection, position term and K / V projection
+                # composed into one launch each (CrossAttentionLayer.composed_kv)
+                cm = ca.composed_kv(lin, tab)
+                x2 = srcs[i].reshape(-1, srcs[i].shape[-1])
+                x_split = split_rows_2d(x2)
+                ci = ci.contiguous()
+                kk = linear_rows(x2, cm["wk"], cm["bk"], ca, "ck", in_split=x_split,
+                                 axis=(cm["tk"], ci, self.pe_layer.TABLE_LO)).view(B, N_i, D)
+                vv = linear_rows(x2, cm["wv"], cm["bv"], ca, "cv", in_split=x_split,
+                                 axis=(cm["tv"], ci, self.pe_layer.TABLE_LO)).view(B, N_i, D)
+                output = ca.attend(output, kk, vv, query_embed, (bits, any_))
+            elif fused_attn:
+                # with the fused attention kernel src + pos is read only by the K / V projections: emit it as their
+                # operand (no fp32 copy)
+                src_F, src_split = linear_rows(srcs[i].reshape(-1, srcs[i].shape[-1]), lin.weight, lin.bias, lin, "w",
+                                               residual=pos_of(i).reshape(-1, D), emit=True, want_out=False)
+                if src_F is not None:
+                    src_F = src_F.view(B, -1, D)
+                output = ca(output, src_F, pos=None, query_pos=query_embed, mask_bits=(bits, any_),
+                            feats_split=src_split, feats_shape=(B, N_i, D))
             else:   # shapes outside the fused kernel: torch attention with the materialised bool mask
+                src_F = linear_rows(srcs[i].reshape(-1, srcs[i].shape[-1]), lin.weight, lin.bias, lin, "w",
+                                    residual=pos_of(i).reshape(-1, D)).view(B, -1, D)
                 q_idx = torch.arange(Qn, device=bits.device)
                 allow = (bits[:, :, (q_idx >> 5).long()] >> (q_idx & 31).to(torch.int32)) & 1      # [B,N,Q]
                 attn_mask = ~(allow != 0).permute(0, 2, 1)
                 attn_mask = attn_mask & ~attn_mask.all(dim=-1, keepdim=True)   # all-masked -> unmasked
-                output = self.transformer_cross_attention_layers[i](output, src_F, attn_mask=attn_mask,
-                                                                    pos=None, query_pos=query_embed)
+                output = ca(output, src_F, attn_mask=attn_mask, pos=None, query_pos=query_embed)
             output, *qs = self.query_step(i, output.contiguous(), query_embed, vf_split is not None)
             oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape, query_side=qs)
             predictions_class.append(oc)
@@ -419,13 +536,16 @@ class TransformerPredictorV2(nn.Module):
             key, mgr = first.coordinate_map_key, first.coordinate_manager
             idx = first.unique_index        # None unless coordinates repeat
             rows = kept if idx is None else kept.index_select(0, idx.long())
-            masks = [first]
-            for m in predictions_mask[1:]:
-                masks.append(ME.SparseTensor(m[b].index_select(0, rows), coordinate_map_key=key, coordinate_manager=mgr))
+            # Only the LAST prediction's voxel logits feed the inference path (ensembling, panoptic_inference); the
+            # auxiliary ones exist for the training loss (net_panoptic_sparse.py:437-451).  Each is an 84 MB row gather
+            # at S10, so they are gathered when somebody asks for them, not per step.
+            aux_masks = [first] + [LazyRows(m[b], rows, key, mgr) for m in predictions_mask[1:-1]]
+            last = ME.SparseTensor(predictions_mask[-1][b].index_select(0, rows), coordinate_map_key=key,
+                                   coordinate_manager=mgr) if len(predictions_mask) > 1 else first
             classes = [c[b].unsqueeze(0) for c in predictions_class]
             panop_predictions.append({
                 "query_logits": classes[-1],
-                "voxel_logits": masks[-1],
-                "aux_outputs": [{"query_logits": a, "voxel_logits": m} for a, m in zip(classes[:-1], masks[:-1])],
+                "voxel_logits": last,
+                "aux_outputs": [{"query_logits": a, "voxel_logits": m} for a, m in zip(classes[:-1], aux_masks)],
             })
         return panop_predictions

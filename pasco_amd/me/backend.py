@@ -47,6 +47,7 @@ class ConvDesc(C.Structure):
         ("in_split", _vp), ("w_split", _vp),
         ("out_split", _vp), ("osp_scale", _vp), ("osp_shift", _vp), ("osp_act", _i32), ("reserved2", _i32),
         ("win_rows", _vp), ("win_cnt", _vp), ("win_slots", _vp), ("win_stats", _vp),
+        ("axis_table", _vp), ("axis_coords", _vp), ("axis_lo", _i32), ("axis_rows", _i32),
     ]
 
 
@@ -271,7 +272,7 @@ class CBackend:
                  epi_shift=None, epi_act=ACT_NONE, slope=0.01, residual=None, res_act=ACT_NONE,
                  epi2_scale=None, epi2_shift=None, split=None, in_split: Optional[torch.Tensor] = None,
                  emit_split=None, want_out: bool = True,
-                 out: Optional[torch.Tensor] = None, win=None, in_split_has_prologue: bool = False):
+                 out: Optional[torch.Tensor] = None, win=None, in_split_has_prologue: bool = False, axis=None):
         """out = epilogue(sum_k gather(prologue(x))[k] @ W[k]) - one `ph_conv_fwd` launch (include/pasco_hip.h).
 
         `split` selects the split-precision products: (w_hi, w_lo, unscale) from `split_weight_f16` = mode 1
@@ -282,7 +283,9 @@ class CBackend:
         of act(out * scale + shift) for the next convolution and return (out, out_split); `want_out=False` then
         skips the fp32 result (returns (None, out_split)).
         `win` = `win_build(nbr)` (3x3x3 maps, mode 2): lets the library serve the launch from LDS-resident input windows
-        where the map is local enough (decided on the device)."""
+        where the map is local enough (decided on the device).
+        `axis` = (table fp32 [3, T, cout], coords int32 [n_out, 4], lo) (mode 2): the per-axis table residual
+        table[0][x - lo] + table[1][y - lo] + table[2][z - lo] is added where `residual` is added."""
         if x is None:          # rows that exist only as a pre-split operand (mode 2): `xshape` = (n_in, cin)
             if xshape is None or in_split is None or split is None or len(split) != 2 or not self.split_capable():
                 raise ValueError("conv: x=None needs xshape, in_split and a mode-2 split on the device backend")
@@ -343,6 +346,15 @@ class CBackend:
             if tuple(residual.shape) != (n_out, cout):
                 raise ValueError("conv: residual shape mismatch")
         d.residual = _ptr(residual)
+        if axis is not None:
+            tab, acoords, lo = axis
+            self._chk(tab, torch.float32, "axis table")
+            self._chk(acoords, torch.int32, "axis coords")
+            if tab.dim() != 3 or tab.shape[0] != 3 or tab.shape[2] != cout or tuple(acoords.shape) != (n_out, 4):
+                raise ValueError("conv: axis = (table [3, T, cout], coords [n_out, 4], lo)")
+            if self.device_type == "cuda" and (split is None or len(split) != 2):
+                raise ValueError("conv: the axis-table residual is served by the pre-split (mode 2) path")
+            d.axis_table, d.axis_coords, d.axis_lo, d.axis_rows = _ptr(tab), _ptr(acoords), int(lo), int(tab.shape[1])
         if split is not None:      # opt-in f16x3 products
             if len(split) == 2:    # (w_split, unscale) from split_weight_rows + in_split from split_rows: mode 2
                 w_split, unscale = split

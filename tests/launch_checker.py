@@ -106,12 +106,16 @@ class LaunchChecker:
             ref = ref + kw["epi_shift"].double()
         mag = float(ref.abs().mean())
         ref = act64(ref, kw.get("epi_act", 0), slope)
-        tail = any(kw.get(k) is not None for k in ("residual", "epi2_scale", "epi2_shift")) or kw.get("res_act", 0) != 0
+        tail = any(kw.get(k) is not None for k in ("residual", "epi2_scale", "epi2_shift", "axis")) or kw.get("res_act", 0) != 0
         if tail:
             if kw.get("epi2_scale") is not None:
                 ref = ref * kw["epi2_scale"].double()
             if kw.get("epi2_shift") is not None:
                 ref = ref + kw["epi2_shift"].double()
+            if kw.get("axis") is not None:          # per-axis table rows (the position encoding of the transformer)
+                tab, acoords, lo = kw["axis"]
+                ai = (acoords[rows][:, 1:4].long() - lo).clamp(0, tab.shape[1] - 1)
+                ref = ref + tab[0][ai[:, 0]].double() + tab[1][ai[:, 1]].double() + tab[2][ai[:, 2]].double()
             if kw.get("residual") is not None:
                 ref = ref + kw["residual"][rows].double()
             mag = max(mag, float(ref.abs().mean()))
@@ -133,6 +137,9 @@ class LaunchChecker:
                 okw[name] = kw[name]
         if kw.get("residual") is not None:
             okw["residual"] = kw["residual"][rows].cpu().contiguous()
+        if kw.get("axis") is not None:
+            tab, acoords, lo = kw["axis"]
+            okw["axis"] = (tab.cpu(), acoords[rows].cpu().contiguous(), lo)
         if fp32_x:
             okw.update(pro_scale=None if ps is None else ps.cpu(), pro_shift=None if pb is None else pb.cpu(), pro_act=pact)
         exp = self.oracle_fwd(x_raw.cpu(), w.cpu().contiguous(), nb_sub.int().cpu().contiguous(), S, **okw)
