@@ -1,5 +1,6 @@
 """Wall-clock breakdown of one bench step by phase (synchronising; diagnostic only)."""
 import os, sys, time, json
+os.environ["PASCO_QUERY_GRAPH"] = "0"     # the synchronising timers cannot sit inside a stream capture
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -43,7 +44,9 @@ tp = net.transformer_predictor
 tp.compute_mask_bits = timed("    attn_mask", tp.compute_mask_bits)
 for i, l in enumerate(tp.transformer_cross_attention_layers):
     l.forward = timed(f"    xattn{i}", l.forward)
+    l.attend = timed(f"    xattn{i}.attend", l.attend)
 tp.pred_heads = timed("    pred_heads", tp.pred_heads)
+tp.query_step = timed("    query_step(self-attn, ffn, head MLPs)", tp.query_step)
 tp.pe_layer.forward = timed("    pos_enc", tp.pe_layer.forward)
 for i, l in enumerate(tp.transformer_self_attention_layers):
     l.forward = timed("    self_attn", l.forward)
