@@ -255,6 +255,26 @@ int PH_FN(scatter_add_rows)(const float *src, int32_t c, const int32_t *rows, in
                             float *dst, ph_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Semantic ensembling on the canonical grid in one pass (Ensembler.ensemble_sem_compl + the confidence map of
+ * Net.forward: pasco/models/ensembler.py:159-187, net_panoptic_sparse.py:252-310).  For every canonical site s and every
+ * subnet i (m <= 8):  p_i = softmax(logits_i[rows_i[s], :])   or the one-hot of class 0 when rows_i[s] < 0
+ * (the reference resamples the probabilities densely and sets class 0 to 1 where nothing lands);
+ *   out[i][s, :] = p_i,  out[m][s, :] = (p_0 + ... + p_{m-1}) / m,  conf[i][s] = max_c out[i][s, c]   (conf optional).
+ * logits_i fp32 [n_i, c]; rows_i int32 [n_sites] (row of the subnet's voxel that the site samples, ph_map_find of the
+ * transformed site); out[i] fp32 [n_sites, c] channels-last rows (the returned dense [c, X, Y, Z] tensors are views). */
+typedef struct ph_sem_ens_desc {
+  int32_t m;
+  int32_t c;
+  int64_t n_sites;
+  const float *logits[8];
+  const int32_t *rows[8];
+  float *out[9];
+  float *conf[9]; /* each may be NULL */
+} ph_sem_ens_desc;
+
+int PH_FN(sem_ensemble)(const ph_sem_ens_desc *desc, ph_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Dense <-> sparse (SparseTensor.dense augmenter.py:17-18, unet3d_sparse_v2.py:196-198,
  * transformer_predictor_v2.py:263-274; ME.to_sparse augmenter.py:22, unet3d_sparse_v2.py:202,
  * ensembler.py:117).

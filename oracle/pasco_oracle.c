@@ -476,6 +476,46 @@ int pho_win_build(const int32_t *nbr, int32_t kvol, int64_t n_out, int32_t *win_
   return 0;
 }
 
+/* semantic ensembling in one pass (include/pasco_hip.h ph_sem_ensemble; ensembler.py:159-187) */
+int pho_sem_ensemble(const ph_sem_ens_desc *d, ph_stream_t stream) {
+  (void)stream;
+  if (!d || d->m < 1 || d->m > 8 || d->c < 1 || d->c > 64) return fail("sem_ensemble: bad desc");
+  const int m = d->m, c = d->c;
+#pragma omp parallel for schedule(static)
+  for (int64_t s = 0; s < d->n_sites; ++s) {
+    float mean[64], p[64];
+    for (int ch = 0; ch < c; ++ch) mean[ch] = 0.f;
+    for (int i = 0; i < m; ++i) {
+      const int r = d->rows[i][s];
+      if (r >= 0) {
+        const float *x = d->logits[i] + (int64_t)r * c;
+        float mx = x[0];
+        for (int ch = 1; ch < c; ++ch) mx = x[ch] > mx ? x[ch] : mx;
+        float sum = 0.f;
+        for (int ch = 0; ch < c; ++ch) { p[ch] = expf(x[ch] - mx); sum += p[ch]; }
+        for (int ch = 0; ch < c; ++ch) p[ch] = p[ch] / sum;
+      } else {
+        for (int ch = 0; ch < c; ++ch) p[ch] = ch == 0 ? 1.f : 0.f;
+      }
+      float best = p[0];
+      for (int ch = 0; ch < c; ++ch) {
+        d->out[i][s * c + ch] = p[ch];
+        mean[ch] += p[ch];
+        best = p[ch] > best ? p[ch] : best;
+      }
+      if (d->conf[i]) d->conf[i][s] = best;
+    }
+    float best = 0.f;
+    for (int ch = 0; ch < c; ++ch) {
+      const float v = mean[ch] / (float)m;
+      d->out[m][s * c + ch] = v;
+      best = (ch == 0 || v > best) ? v : best;
+    }
+    if (d->conf[m]) d->conf[m][s] = best;
+  }
+  return 0;
+}
+
 /* a10 */
 int pho_maxpool_fwd(const float *in, int32_t c, const int32_t *nbr, int32_t kvol, int64_t n_out,
                     float *out, ph_stream_t stream) {

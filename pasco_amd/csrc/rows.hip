@@ -255,3 +255,101 @@ extern "C" int ph_sine_pe(const int32_t *coords, int64_t n, int32_t cstride, int
   PH_LAUNCH_CHECK();
   return 0;
 }
+
+
+// ---- semantic ensembling in one pass (ph_sem_ensemble) ---------------------------------------------------------------
+// One thread per canonical site: for every subnet gather its logits row (or take the one-hot of class 0), softmax in
+// registers, write the subnet's row, accumulate the mean, keep the row maxima.  HBM bound: per site 4 B of row index and
+// up to 4 C bytes of logits per subnet in, 4 C (m + 1) bytes out (one pass instead of softmax / gather / column fix-up /
+// stack / mean / max passes of 168 MB tensors each).
+template <int C, bool VEC>
+__global__ void __launch_bounds__(256) k_sem_ensemble(ph_sem_ens_desc d) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.n_sites) return;
+  float mean[C];
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) mean[ch] = 0.f;
+  for (int i = 0; i < d.m; ++i) {
+    float p[C];
+    const int r = d.rows[i][s];
+    if (r >= 0) {
+      const float *x = d.logits[i] + (int64_t)r * C;
+      if (VEC) {
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+          const float4 v = reinterpret_cast<const float4 *>(x)[q];
+          p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) p[ch] = x[ch];
+      }
+      float mx = p[0];
+#pragma unroll
+      for (int ch = 1; ch < C; ++ch) mx = fmaxf(mx, p[ch]);
+      float sum = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
+        p[ch] = expf(p[ch] - mx);
+        sum += p[ch];
+      }
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) p[ch] = p[ch] / sum;
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) p[ch] = ch == 0 ? 1.f : 0.f;
+    }
+    float best = p[0];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+      mean[ch] += p[ch];
+      best = fmaxf(best, p[ch]);
+    }
+    float *o = d.out[i] + s * C;
+    if (VEC) {
+#pragma unroll
+      for (int q = 0; q < C / 4; ++q) reinterpret_cast<float4 *>(o)[q] = make_float4(p[4 * q], p[4 * q + 1], p[4 * q + 2], p[4 * q + 3]);
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) o[ch] = p[ch];
+    }
+    if (d.conf[i]) d.conf[i][s] = best;
+  }
+  const float inv_m = (float)d.m;
+  float best = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) {
+    mean[ch] = mean[ch] / inv_m;
+    best = ch == 0 ? mean[ch] : fmaxf(best, mean[ch]);
+  }
+  float *o = d.out[d.m] + s * C;
+  if (VEC) {
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) reinterpret_cast<float4 *>(o)[q] = make_float4(mean[4 * q], mean[4 * q + 1], mean[4 * q + 2], mean[4 * q + 3]);
+  } else {
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) o[ch] = mean[ch];
+  }
+  if (d.conf[d.m]) d.conf[d.m][s] = best;
+}
+
+extern "C" int ph_sem_ensemble(const ph_sem_ens_desc *desc, ph_stream_t stream) {
+  PH_REQUIRE(desc != nullptr && desc->m >= 1 && desc->m <= 8, "sem_ensemble: 1 <= m <= 8");
+  PH_REQUIRE(desc->c == 20 || desc->c == 19, "sem_ensemble: serves 20 (SemanticKITTI) or 19 (SSCBench-KITTI360) classes, got %d", desc->c);
+  if (desc->n_sites == 0) return 0;
+  for (int i = 0; i < desc->m; ++i) PH_REQUIRE(desc->logits[i] && desc->rows[i] && desc->out[i], "sem_ensemble: null buffer");
+  PH_REQUIRE(desc->out[desc->m] != nullptr, "sem_ensemble: null mean buffer");
+  hipStream_t st = ph_stream(stream);
+  const dim3 grid((unsigned)((desc->n_sites + 255) / 256));
+  bool al = true;
+  for (int i = 0; i <= desc->m; ++i) al = al && (((uintptr_t)desc->out[i]) & 15) == 0;
+  for (int i = 0; i < desc->m; ++i) al = al && (((uintptr_t)desc->logits[i]) & 15) == 0;
+  if (desc->c == 20 && al)
+    hipLaunchKernelGGL((k_sem_ensemble<20, true>), grid, dim3(256), 0, st, *desc);
+  else if (desc->c == 20)
+    hipLaunchKernelGGL((k_sem_ensemble<20, false>), grid, dim3(256), 0, st, *desc);
+  else
+    hipLaunchKernelGGL((k_sem_ensemble<19, false>), grid, dim3(256), 0, st, *desc);
+  PH_LAUNCH_CHECK();
+  return 0;
+}

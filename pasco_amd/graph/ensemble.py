@@ -119,6 +119,15 @@ class Ensembler(torch.nn.Module):
         dev = logits_1[0].device
         cache = {} if cache is None else cache
         X, Y, Z = self.scene_size
+        be = backend_for(dev)
+        c = logits_1[0].F.shape[1]
+        if c in (19, 20) and len(logits_1) <= 8 and (dev.type == "cuda" or be.has("sem_ensemble")):
+            # softmax, resampling, class-0 fill, mean and the confidence maps in ONE pass (ph_sem_ensemble)
+            rows = [_lookup_rows(st, self.projected(Ts[i], dev, cache)) for i, st in enumerate(logits_1)]
+            outs, confs = be.sem_ensemble([st.F.contiguous() for st in logits_1], rows)
+            cache["sem_rows"] = outs
+            cache["sem_conf"] = confs
+            return [o.reshape(X, Y, Z, -1).permute(3, 0, 1, 2) for o in outs]
         outs = []
         for i, st in enumerate(logits_1):
             probs = F.softmax(st.F, dim=-1)

@@ -219,7 +219,10 @@ class PascoNet(nn.Module):
                                               iou_threshold=self.iou_threshold, cache=cache)
         # max over classes on the channels-last rows the dense views are made of (contiguous reduction)
         X, Y, Z = self.ensembler.scene_size
-        ssc_confidences = [r.max(dim=1)[0].reshape(X, Y, Z) for r in cache["sem_rows"]]
+        if cache.get("sem_conf") is not None:      # written by the same pass that made the probabilities
+            ssc_confidences = [r.reshape(X, Y, Z) for r in cache["sem_conf"]]
+        else:
+            ssc_confidences = [r.max(dim=1)[0].reshape(X, Y, Z) for r in cache["sem_rows"]]
         return ssc_confidences, sem_prob_denses, panop
 
     def step_inference(self, in_feats, in_coords, Ts, global_min_coords, global_max_coords, min_Cs, max_Cs,

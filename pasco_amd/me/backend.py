@@ -51,6 +51,13 @@ class ConvDesc(C.Structure):
     ]
 
 
+class SemEnsDesc(C.Structure):
+    """Mirror of `ph_sem_ens_desc` (include/pasco_hip.h)."""
+
+    _fields_ = [("m", _i32), ("c", _i32), ("n_sites", _i64), ("logits", _vp * 8), ("rows", _vp * 8),
+                ("out", _vp * 9), ("conf", _vp * 9)]
+
+
 # name -> argtypes (everything returns int unless listed in _RESTYPES)
 _SIGNATURES = {
     "abi_version": [],
@@ -65,6 +72,7 @@ _SIGNATURES = {
     "conv_fwd": [C.POINTER(ConvDesc), _vp],
     "conv_last_config": [_vp],
     "win_build": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
+    "sem_ensemble": [C.POINTER(SemEnsDesc), _vp],
     "split_rows": [_vp, _i64, _i32, _vp, _vp, _i32, C.c_float, _i32, _vp, _vp, _vp],
     "maxpool_fwd": [_vp, _i32, _vp, _i32, _i64, _vp, _vp],
     "mask_compact": [_vp, _i64, _vp, _vp, _vp, _i64, _vp],
@@ -531,6 +539,31 @@ class CBackend:
                                          self.stream(src.device))
         self._check(rc, "scatter_add_rows")
         return dst
+
+    def sem_ensemble(self, logits, rows, want_conf: bool = True):
+        """One-pass semantic ensembling (include/pasco_hip.h ph_sem_ensemble): logits[i] fp32 [n_i, c], rows[i] int32
+        [n_sites] -> (outs: list of m + 1 fp32 [n_sites, c] rows - per subnet softmax resampled, then their mean;
+        confs: list of m + 1 fp32 [n_sites] row maxima, or None)."""
+        m = len(logits)
+        c = logits[0].shape[1]
+        n = rows[0].shape[0]
+        dev = logits[0].device
+        d = SemEnsDesc()
+        d.m, d.c, d.n_sites = m, c, n
+        outs = [torch.empty((n, c), dtype=torch.float32, device=dev) for _ in range(m + 1)]
+        confs = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(m + 1)] if want_conf else None
+        for i in range(m):
+            self._chk(logits[i], torch.float32, "logits")
+            self._chk(rows[i], torch.int32, "rows")
+            if logits[i].shape[1] != c or rows[i].shape[0] != n:
+                raise ValueError("sem_ensemble: shape mismatch between subnets")
+            d.logits[i], d.rows[i] = _ptr(logits[i]), _ptr(rows[i])
+        for i in range(m + 1):
+            d.out[i] = _ptr(outs[i])
+            d.conf[i] = _ptr(confs[i]) if want_conf else None
+        rc = self.fn["sem_ensemble"](C.byref(d), self.stream(dev))
+        self._check(rc, "sem_ensemble")
+        return outs, confs
 
     # -- dense <-> sparse --------------------------------------------------------------------------
     def to_dense(self, feats, coords, min3, ts: int, dims4) -> torch.Tensor:

@@ -252,3 +252,33 @@ def test_gram_batched_matches_matmul(hip):
     a, b = torch.rand(100003, 100, generator=g).cuda(), torch.rand(100003, 100, generator=g).cuda()
     ref = (a.double().t() @ b.double()).float()
     assert torch.allclose(_gram(a, b), ref, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("c,m", [(20, 3), (19, 3), (20, 1), (20, 8)])
+def test_sem_ensemble_matches_oracle_and_torch(hip, oracle, c, m):
+    """ph_sem_ensemble: softmax + resampling + class-0 fill + mean + confidences in one pass, against the oracle and the
+    torch formulation of Ensembler.ensemble_sem_compl (ensembler.py:159-187)."""
+    g = torch.Generator().manual_seed(70 + c + m)
+    n_sites = 50001
+    logits, rows = [], []
+    for i in range(m):
+        n_i = 3000 + 517 * i
+        logits.append(torch.randn(n_i, c, generator=g) * 3)
+        r = torch.randint(-n_i // 2, n_i, (n_sites,), generator=g).clamp(min=-1).int()
+        rows.append(r)
+    o_out, o_conf = oracle.sem_ensemble(logits, rows)
+    h_out, h_conf = hip.sem_ensemble([t.cuda() for t in logits], [t.cuda() for t in rows])
+    ref = []
+    for i in range(m):
+        p = torch.softmax(logits[i], dim=-1)
+        d = torch.zeros(n_sites, c)
+        ok = rows[i] >= 0
+        d[ok] = p[rows[i][ok].long()]
+        d[~ok, 0] = 1.0
+        ref.append(d)
+    ref.append(torch.stack(ref).mean(0))
+    for i in range(m + 1):
+        assert torch.allclose(h_out[i].cpu(), o_out[i], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(o_out[i], ref[i], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(h_conf[i].cpu(), ref[i].max(dim=1)[0], rtol=1e-5, atol=1e-6)
+        assert torch.allclose(o_conf[i], ref[i].max(dim=1)[0], rtol=1e-5, atol=1e-6)

@@ -14,7 +14,8 @@ for grid in (256,):
     for mode, name in ((0, "mixed: every wave 3 DMA + 12 MFMA"), (1, "specialised: 4 loader waves x 6 DMA, 4 matrix waves x 24 MFMA"),
                        (2, "DMA only"), (3, "MFMA only"), (4, "specialised, matrix waves on SIMDs {0,2}, loaders on {1,3}"),
                        (5, "specialised, loaders use REGISTER loads"), (6, "mixed, REGISTER loads"),
-                       (7, "specialised, loaders at s_setprio 3"), (8, "specialised, prio 3 + s_sleep between MFMAs")):
+                       (7, "specialised, loaders at s_setprio 3"), (8, "specialised, prio 3 + s_sleep between MFMAs"),
+                       (9, "every wave 12 ds_read_b128 (issued first) + 12 MFMA"), (10, "every wave 12 ds_read_b128 only")):
         ts = []
         for _ in range(4):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(512, 2) k_spec(const char *src, float *sink, i
     const bool loader = SPEC ? !is_matrix_wave : true;
     const bool matrix = SPEC ? is_matrix_wave : true;
     const int ndma = SPEC ? 6 : 3, nmma = SPEC ? 24 : 12;
-    if (loader && MODE != 3) {
+    if (loader && MODE != 3 && MODE < 9) {
       if (MODE == 5 || MODE == 6) {
         u32x4 r[6];
 #pragma unroll
@@ -46,7 +46,20 @@ __global__ void __launch_bounds__(512, 2) k_spec(const char *src, float *sink, i
           }
       }
     }
-    if (matrix && MODE != 2) {
+    if (MODE == 9 || MODE == 10) {
+      f16x8 fr[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) fr[q] = *reinterpret_cast<const f16x8 *>(lds + ((q * 64 + lane + it) & 2047) * 16);
+      if (MODE == 9) {
+#pragma unroll
+        for (int q = 0; q < 12; q += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 12; ++q) a += fr[q];
+    } else if (matrix && MODE != 2) {
 #pragma unroll
       for (int q = 0; q < 24; q += 2)
         if (q < nmma) {
@@ -73,6 +86,8 @@ extern "C" int ub_spec(const void *src, void *sink, int iters, int mode, int gri
   if (mode == 5) hipLaunchKernelGGL(k_spec<5>, dim3(grid), dim3(512), 0, st, (const char *)src, (float *)sink, iters);
   if (mode == 7) hipLaunchKernelGGL(k_spec<7>, dim3(grid), dim3(512), 0, st, (const char *)src, (float *)sink, iters);
   if (mode == 8) hipLaunchKernelGGL(k_spec<8>, dim3(grid), dim3(512), 0, st, (const char *)src, (float *)sink, iters);
+  if (mode == 9) hipLaunchKernelGGL(k_spec<9>, dim3(grid), dim3(512), 0, st, (const char *)src, (float *)sink, iters);
+  if (mode == 10) hipLaunchKernelGGL(k_spec<10>, dim3(grid), dim3(512), 0, st, (const char *)src, (float *)sink, iters);
   if (mode == 6) hipLaunchKernelGGL(k_spec<6>, dim3(grid), dim3(512), 0, st, (const char *)src, (float *)sink, iters);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
