@@ -318,6 +318,225 @@ def main():
     ap.add_argument("--n-classes", type=int, default=20)
     ap.add_argument("--heavy", action="store_true")
     ap.add_argument("--scenes", type=int, default=4, help="different scenes the timed loop rotates over")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="scenes in flight per GPU: worker threads, each with its own HIP stream, take the steps from a shared "
+                         "counter (a step's ~60 host synchronisations then overlap with the other scene's kernels); 1 = one "
+                         "scene at a time, also measured and reported as `in_flight_1`")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events")
+    ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short rows of the other configurations")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--conv-precision", choices=["f32", "f16x3"], default="f16x3",
+                    help="f16x3 (default) = conv products as 3 x f16 split MFMA with fp32 accumulation (error vs fp64 <= "
+                         "the fp32-MFMA path); f32 = every product on the exact fp32 MFMA")
+    args = ap.parse_args()
+    if args.n_infers is None:
+        args.n_infers = 8 if args.mode == "subnet-heads" else 3
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (MI355X); the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from pasco_amd.me.backend import hip_backend
+    from pasco_amd.graph.synth import make_scene, TeacherKeep
+    from pasco_amd.graph.profiling import ConvProfiler
+
+    be = hip_backend()   # raises if libpascohip.so is missing
+    from pasco_amd.graph import fused
+    fused.set_conv_precision(args.conv_precision)
+    net = build_net(args.n_infers, args.in_channels, device, heavy=args.heavy, n_classes=args.n_classes)
+    heads = args.mode == "subnet-heads"
+    # scenes-mode: rank r owns its own scenes; subnet-heads: every rank works on the SAME scene sequence
+    seeds = [(0 if heads else rank * args.scenes) + i for i in range(args.scenes)]
+    scenes = [make_scene(seed=s, n_infers=args.n_infers, in_channels=args.in_channels).to(device) for s in seeds]
+    teachers = [TeacherKeep(sc, device) for sc in scenes]
+    step_fn = run_scene_subnet_heads if (heads and world > 1) else (lambda n, s, t, w=None: run_scene(n, s, t, w))
+    prof = ConvProfiler()
+    prof.wrap(be)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    import gc
+    import threading
+
+    streams = [torch.cuda.Stream(device=device) for _ in range(max(args.in_flight, 1))]
+
+    def run_steps(first, count, in_flight, window=None, marks=None):
+        """Steps first .. first + count - 1 (scene = step mod #scenes).  in_flight == 1: on the current stream, one after the
+        other.  Else: `in_flight` worker threads, each bound to its own stream, draw step numbers from a shared counter;
+        returns after every worker's stream has drained."""
+        last = {}
+        if in_flight <= 1:
+            with torch.no_grad():
+                for i in range(first, first + count):
+                    j = i % len(scenes)
+                    if heads and world > 1:
+                        last["out"], last["panop"] = step_fn(net, scenes[j], teachers[j])
+                    else:
+                        last["out"], last["panop"] = run_scene(net, scenes[j], teachers[j], window)
+                    if marks is not None:
+                        marks.append(time.perf_counter())
+            return last
+        lock = threading.Lock()
+        state = {"next": first}
+        errors = []
+
+        def worker(w):
+            try:
+                torch.cuda.set_device(device)
+                with torch.cuda.stream(streams[w]), torch.no_grad():
+                    while True:
+                        with lock:
+                            i = state["next"]
+                            state["next"] += 1
+                        if i >= first + count:
+                            break
+                        j = i % len(scenes)
+                        if heads and world > 1:
+                            o = step_fn(net, scenes[j], teachers[j])
+                        else:
+                            o = run_scene(net, scenes[j], teachers[j], window)
+                        with lock:
+                            last["out"], last["panop"] = o
+                            if marks is not None:
+                                marks.append(time.perf_counter())
+                streams[w].synchronize()
+            except BaseException as e:      # surface worker failures in the main thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(w,)) for w in range(in_flight)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return last
+
+    for s_ in streams:                      # the scenes / weights were uploaded on the default stream
+        s_.wait_stream(torch.cuda.current_stream(device))
+    # warm-up: every scene once on the main stream (kernel maps' shapes, operand caches), then on the worker streams
+    # (their query-side graphs and scratch buffers)
+    last = run_steps(0, args.warmup, 1)
+    if args.in_flight > 1:
+        run_steps(0, max(args.warmup, 2 * args.in_flight), args.in_flight)
+    out = last["out"]
+    n1 = int(out["sem_logits_at_scales"][1][0].F.shape[0])
+    window = []
+    if heads and world > 1:
+        args.in_flight = 1                  # one communicator: collectives are issued from one thread
+    # per-launch HIP events only mean something when one scene runs at a time (kernels of two streams share the GPU):
+    # with several scenes in flight the roofline comes from the one-at-a-time pass below
+    prof.enabled = (not args.no_profile) and args.in_flight <= 1
+    # the cyclic garbage collector is paused over the timed steps (as a serving loop would): a generation-2
+    # pass over the step's many small Python objects costs ~27 ms whenever it lands inside a step; the same
+    # loop with the collector running is reported beside it (`gc_enabled`)
+    gc.collect()
+    gc.freeze()              # model / caches built during warm-up: out of the collector's reach from here on
+    gc_was_on = gc.isenabled()
+    if os.environ.get("PASCO_BENCH_GC", "0") != "1":
+        gc.disable()
+    barrier()
+    t0 = time.perf_counter()
+    marks = [t0]
+    last = run_steps(0, args.steps, args.in_flight, window, marks)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    out, panop = last["out"], last["panop"]
+    prof.enabled = False
+    if rank == 0:
+        per = [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])]
+        print(f"[bench] per-step host ms: {per}", file=sys.stderr, flush=True)
+    one_in_flight = None
+    if args.in_flight > 1 and world == 1:          # the same K steps, one scene at a time on one stream
+        window = []
+        prof.enabled = not args.no_profile
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(0, args.steps, 1, window)
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t0) / args.steps
+        prof.enabled = False
+        one_in_flight = {"value": round(1.0 / dt1, 4), "unit": "scenes/s", "ms_per_step": round(dt1 * 1e3, 3),
+                         "steps": args.steps}
+    if gc_was_on:
+        gc.enable()
+
+    per_rank = [elapsed]
+    if world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, elapsed)
+        per_rank = box
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (launcher self-test, no compute)", "value": world * args.steps / elapsed,
+                          "unit": "steps/s", "n_gpus": world, "n_ranks": dist.get_world_size() if world > 1 else 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "per_rank_ms_per_step": [p / args.steps * 1e3 for p in per_rank],
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "dry-run (no compute)", "config": {"workload": "sleep"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False):
+    """Short timed row of another BASELINE.json configuration on this GPU (1 warm-up + `steps` scenes)."""
+    from pasco_amd.graph import fused
+    from pasco_amd.graph.synth import make_scene, TeacherKeep
+    net = build_net(n_infers, in_channels, device, n_classes=n_classes)
+    scene = make_scene(seed=0, n_infers=n_infers, in_channels=in_channels).to(device)
+    teacher = TeacherKeep(scene, device)
+    if unfused:                 # INTEGRATION.md route (a): reference-style module sequence, exact fp32 products
+        fused.set_fusion(False)
+        fused.set_conv_precision("f32")
+    try:
+        with torch.no_grad():
+            run_scene(net, scene, teacher)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run_scene(net, scene, teacher)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+    finally:
+        if unfused:
+            fused.set_fusion(True)
+            fused.set_conv_precision("f16x3")
+    return {"scenes_per_s": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": 1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--mode", choices=["scenes", "subnet-heads"], default="scenes")
+    ap.add_argument("--n-infers", type=int, default=None, help="MIMO subnets (default 3; 8 with --mode subnet-heads)")
+    ap.add_argument("--in-channels", type=int, default=283)
+    ap.add_argument("--n-classes", type=int, default=20)
+    ap.add_argument("--heavy", action="store_true")
+    ap.add_argument("--scenes", type=int, default=4, help="different scenes the timed loop rotates over")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="scenes in flight per GPU: worker threads, each with its own HIP stream, take the steps from a shared "
+                         "counter (a step's ~60 host synchronisations then overlap with the other scene's kernels); 1 = one "
+                         "scene at a time, also measured and reported as `in_flight_1`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events")
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing")
@@ -414,16 +633,13 @@ def main():
     single = world == 1
     gc_row = None
     if single:                    # the same loop with Python's collector running (what an unmanaged serving loop pays)
-        import gc
         k3 = max(4, args.steps // 3)
-        with torch.no_grad():
-            gc.enable()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(k3):
-                run_scene(net, scenes[i % len(scenes)], teachers[i % len(scenes)])
-            torch.cuda.synchronize()
-            gc_row = {"ms_per_step": round((time.perf_counter() - t0) / k3 * 1e3, 3), "steps": k3}
+        gc.enable()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(0, k3, args.in_flight)
+        torch.cuda.synchronize()
+        gc_row = {"ms_per_step": round((time.perf_counter() - t0) / k3 * 1e3, 3), "steps": k3, "in_flight": args.in_flight}
 
     # the same step with every product on the exact fp32 MFMA, reported next to the headline
     exact = None
@@ -482,6 +698,9 @@ def main():
             per_kernel, classes = prof.summary(by_class=True)
             if per_kernel:
                 res["roofline"] = roofline_object(per_kernel, args.steps, classes)
+        res["config"]["in_flight"] = args.in_flight
+        if one_in_flight is not None:
+            res["in_flight_1"] = one_in_flight
         if gc_row is not None:
             res["gc_enabled"] = gc_row
         if exact is not None:

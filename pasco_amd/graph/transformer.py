@@ -318,7 +318,7 @@ class TransformerPredictorV2(nn.Module):
             output = self.transformer_ffn_layers[layer](output)
         return (output,) + tuple(self.heads_query_side(output, want_operand))
 
-    _QGRAPH_MAX = 16     # captured graphs kept per module (3 layers + heads, a few batch shapes); oldest evicted
+    _QGRAPH_MAX = 48     # captured graphs kept per module (4 per shape and stream; a few shapes, a few streams); oldest evicted
 
     def query_step(self, layer: int, output, query_embed, want_operand: bool):
         if not output.is_cuda or self.training or torch.is_grad_enabled() or \
@@ -329,7 +329,10 @@ class TransformerPredictorV2(nn.Module):
         # address of each (load_state_dict(assign=True), .cpu().cuda() round trips, param.data = ... change the
         # address without bumping the version)
         vers = tuple((p._version, p.data_ptr()) for p in self.parameters())
-        key = (layer, tuple(output.shape), tuple(query_embed.shape), output.device, want_operand)
+        # one graph per launch stream: a serving loop with several scenes in flight replays them concurrently, and a
+        # graph's static input / output buffers must not be shared between streams
+        key = (layer, tuple(output.shape), tuple(query_embed.shape), output.device, want_operand,
+               torch.cuda.current_stream(output.device).cuda_stream)
         hit = graphs.get(key)
         if hit is None or hit["vers"] != vers:
             try:
@@ -361,7 +364,7 @@ class TransformerPredictorV2(nn.Module):
                 self._query_step(layer, x, qe, want_operand)
         torch.cuda.current_stream(output.device).wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(g):
+        with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads may be launching
             outs = self._query_step(layer, x, qe, want_operand)
         return {"graph": g, "x": x, "qe": qe, "outs": outs}
 
