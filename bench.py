@@ -481,149 +481,6 @@ def main():
 
     per_rank = [elapsed]
     if world > 1:
-        box = [None] * world
-        dist.all_gather_object(box, elapsed)
-        per_rank = box
-    if rank == 0:
-        print(json.dumps({"metric": "dry-run (launcher self-test, no compute)", "value": world * args.steps / elapsed,
-                          "unit": "steps/s", "n_gpus": world, "n_ranks": dist.get_world_size() if world > 1 else 1,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                          "per_rank_ms_per_step": [p / args.steps * 1e3 for p in per_rank],
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
-                          "data": "dry-run (no compute)", "config": {"workload": "sleep"}}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False):
-    """Short timed row of another BASELINE.json configuration on this GPU (1 warm-up + `steps` scenes)."""
-    from pasco_amd.graph import fused
-    from pasco_amd.graph.synth import make_scene, TeacherKeep
-    net = build_net(n_infers, in_channels, device, n_classes=n_classes)
-    scene = make_scene(seed=0, n_infers=n_infers, in_channels=in_channels).to(device)
-    teacher = TeacherKeep(scene, device)
-    if unfused:                 # INTEGRATION.md route (a): reference-style module sequence, exact fp32 products
-        fused.set_fusion(False)
-        fused.set_conv_precision("f32")
-    try:
-        with torch.no_grad():
-            run_scene(net, scene, teacher)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                run_scene(net, scene, teacher)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
-    finally:
-        if unfused:
-            fused.set_fusion(True)
-            fused.set_conv_precision("f16x3")
-    return {"scenes_per_s": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": 1}
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--mode", choices=["scenes", "subnet-heads"], default="scenes")
-    ap.add_argument("--n-infers", type=int, default=None, help="MIMO subnets (default 3; 8 with --mode subnet-heads)")
-    ap.add_argument("--in-channels", type=int, default=283)
-    ap.add_argument("--n-classes", type=int, default=20)
-    ap.add_argument("--heavy", action="store_true")
-    ap.add_argument("--scenes", type=int, default=4, help="different scenes the timed loop rotates over")
-    ap.add_argument("--in-flight", type=int, default=2,
-                    help="scenes in flight per GPU: worker threads, each with its own HIP stream, take the steps from a shared "
-                         "counter (a step's ~60 host synchronisations then overlap with the other scene's kernels); 1 = one "
-                         "scene at a time, also measured and reported as `in_flight_1`")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true", help="skip per-launch HIP events")
-    ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing")
-    ap.add_argument("--no-configs", action="store_true", help="skip the short rows of the other configurations")
-    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--conv-precision", choices=["f32", "f16x3"], default="f16x3",
-                    help="f16x3 (default) = conv products as 3 x f16 split MFMA with fp32 accumulation (error vs fp64 <= "
-                         "the fp32-MFMA path); f32 = every product on the exact fp32 MFMA")
-    args = ap.parse_args()
-    if args.n_infers is None:
-        args.n_infers = 8 if args.mode == "subnet-heads" else 3
-
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(args))
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if args.dry_run:
-        return dry_run(args, world, rank)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (MI355X); the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
-
-    from pasco_amd.me.backend import hip_backend
-    from pasco_amd.graph.synth import make_scene, TeacherKeep
-    from pasco_amd.graph.profiling import ConvProfiler
-
-    be = hip_backend()   # raises if libpascohip.so is missing
-    from pasco_amd.graph import fused
-    fused.set_conv_precision(args.conv_precision)
-    net = build_net(args.n_infers, args.in_channels, device, heavy=args.heavy, n_classes=args.n_classes)
-    heads = args.mode == "subnet-heads"
-    # scenes-mode: rank r owns its own scenes; subnet-heads: every rank works on the SAME scene sequence
-    seeds = [(0 if heads else rank * args.scenes) + i for i in range(args.scenes)]
-    scenes = [make_scene(seed=s, n_infers=args.n_infers, in_channels=args.in_channels).to(device) for s in seeds]
-    teachers = [TeacherKeep(sc, device) for sc in scenes]
-    step_fn = run_scene_subnet_heads if (heads and world > 1) else (lambda n, s, t, w=None: run_scene(n, s, t, w))
-    prof = ConvProfiler()
-    prof.wrap(be)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    with torch.no_grad():
-        for i in range(args.warmup):
-            out, _ = (step_fn(net, scenes[i % len(scenes)], teachers[i % len(scenes)]))
-        n1 = int(out["sem_logits_at_scales"][1][0].F.shape[0])
-        window = []
-        prof.enabled = not args.no_profile
-        # the cyclic garbage collector is paused over the timed steps (as a serving loop would): a generation-2
-        # pass over the step's many small Python objects costs ~27 ms whenever it lands inside a step; the same
-        # loop with the collector running is reported beside it (`gc_enabled`)
-        import gc
-        gc.collect()
-        gc.freeze()              # model / caches built during warm-up: out of the collector's reach from here on
-        gc_was_on = gc.isenabled()
-        if os.environ.get("PASCO_BENCH_GC", "0") != "1":
-            gc.disable()
-        barrier()
-        t0 = time.perf_counter()
-        marks = [t0]
-        for i in range(args.steps):
-            j = i % len(scenes)
-            if heads and world > 1:
-                out, panop = step_fn(net, scenes[j], teachers[j])
-            else:
-                out, panop = run_scene(net, scenes[j], teachers[j], window)
-            marks.append(time.perf_counter())      # host-side enqueue clock of each step (diagnostic, stderr only)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if gc_was_on:
-            gc.enable()
-        prof.enabled = False
-        if rank == 0:
-            per = [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])]
-            print(f"[bench] per-step host ms: {per}", file=sys.stderr, flush=True)
-
-    per_rank = [elapsed]
-    if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         box = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(box, t)
