@@ -436,7 +436,11 @@ def main():
     # (their query-side graphs and scratch buffers)
     last = run_steps(0, args.warmup, 1)
     if args.in_flight > 1:
-        run_steps(0, max(args.warmup, 2 * args.in_flight), args.in_flight)
+        for s_ in streams[:args.in_flight]:          # one stream at a time: graph captures do not overlap other launches
+            with torch.cuda.stream(s_):
+                run_steps(0, max(args.warmup, len(scenes)), 1)
+            s_.synchronize()
+        run_steps(0, 2 * args.in_flight, args.in_flight)
     out = last["out"]
     n1 = int(out["sem_logits_at_scales"][1][0].F.shape[0])
     window = []

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import math
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -28,6 +29,9 @@ from .. import me as ME
 from ..me.backend import backend_for
 from . import fused as fused_mod
 from .fused import batched_rows_matmul, linear_rows, prepare_batched_weights, split_rows_2d
+
+# torch registers generator / allocator state per capture in process-wide tables: one capture at a time
+_CAPTURE_LOCK = threading.Lock()
 
 
 def sine_position_encoding(coords: torch.Tensor, num_pos_feats: int, temperature: float = 10000.0,
@@ -336,7 +340,8 @@ class TransformerPredictorV2(nn.Module):
         hit = graphs.get(key)
         if hit is None or hit["vers"] != vers:
             try:
-                hit = self._capture_query_step(layer, output, query_embed, want_operand)
+                with _CAPTURE_LOCK:
+                    hit = self._capture_query_step(layer, output, query_embed, want_operand)
                 hit["vers"] = vers
                 graphs.pop(key, None)
                 graphs[key] = hit
