@@ -20,6 +20,7 @@
 // the register-staged two-barrier loop serialises load, LDS store and MFMA phases instead of overlapping them.
 //
 // Same tile algebra, accumulation order and epilogue as k_conv_h2 (conv_h2_common.h): results are bit-identical.
+#include <mutex>
 #include "conv_h2_common.h"
 
 constexpr int DMA_KMAX = 32;   // kernel offsets one workgroup walks (its slice of the split over the offsets)
@@ -291,6 +292,8 @@ static int launch_dma(const ConvArgsH &a, hipStream_t st) {
 // (allocated at the first launch on a device, never inside a stream capture: convolutions are not captured)
 const char *ph_dma_zero_line() {
   static const char *zero[64] = {nullptr};
+  static std::mutex mu;                     // serving loops launch from several threads
+  std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   if (zero[dev] == nullptr) {

@@ -184,3 +184,56 @@ def test_subnet_parallel_forward_nccl_world1(hip):
             assert torch.allclose(a["query_logits"], b["query_logits"], rtol=1e-4, atol=1e-5)
     finally:
         dist.destroy_process_group()
+
+
+def test_two_scenes_in_flight_match_one_at_a_time(hip):
+    """bench.py's default serving shape: worker threads, each bound to its own HIP stream, run different scenes at
+    the same time through ONE net (shared weights / operand caches; per-stream workspaces and query-side graphs).
+    Every scene's outputs must equal what the same scene gives alone on the default stream."""
+    import threading
+    from pasco_amd.graph import PascoNet
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(21)
+    net = PascoNet(n_classes=20, n_infers=2, in_channels=16, f=32, num_queries=20, heavy_decoder=False).eval().to(dev)
+    scenes = [make_scene(40 + i, n_infers=2, in_channels=16, grid=(96, 96, 16), occupancy=0.12).to(dev) for i in range(2)]
+    teachers = [TeacherKeep(sc, dev) for sc in scenes]
+
+    def step(j):
+        sc = scenes[j]
+        x = net.prepare_input(sc.in_feats, sc.in_coords)
+        ret = net(x, sc.global_min_Cs, sc.global_max_Cs, sc.min_Cs, sc.max_Cs, keep_override=teachers[j])
+        conf, sem, panop = net.ensemble(ret, sc.Ts)
+        return [p["voxel_logits"].F.clone() for p in ret["panop_predictions"]] + \
+               [p["query_logits"].clone() for p in ret["panop_predictions"]] + [t.clone() for t in sem] + [t.clone() for t in conf]
+
+    with torch.no_grad():
+        ref = [step(j) for j in range(2)]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        for j, s in enumerate(streams):          # graph captures happen here, one stream at a time
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                step(j)
+            s.synchronize()
+    got, errors = {}, []
+
+    def worker(j):
+        try:
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[j]), torch.no_grad():
+                for _ in range(4):
+                    got[j] = step(j)
+            streams[j].synchronize()
+        except BaseException as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(j,)) for j in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for j in range(2):
+        assert len(got[j]) == len(ref[j])
+        for a, b in zip(got[j], ref[j]):
+            assert a.shape == b.shape and torch.equal(a, b)
