@@ -324,6 +324,14 @@ int PH_FN(attn_cross_fwd)(const float *q, const float *k, const float *v, const 
                           const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h,
                           int32_t qn, int32_t dh, void *ws, int64_t ws_bytes, ph_stream_t stream);
 
+/* attn_cross_fwd with K and V as split f16 operands [B*N, H*Dh/32, 2, 32] (hi + lo = value * 2^exp2: what a projection
+ * launched with ph_conv_desc.out_split writes, so K and V never exist in fp32): every product runs as three f16 MFMAs
+ * with fp32 accumulation.  `status` (or NULL): bit 0 is raised when a query value leaves the f16 range after the
+ * kernel's own 2^8 scaling (the caller then reruns attn_cross_fwd on fp32 K / V). */
+int PH_FN(attn_cross_split)(const float *q, const void *k_split, const void *v_split, int32_t exp2,
+                            const uint32_t *bits, const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h,
+                            int32_t qn, int32_t dh, void *ws, int64_t ws_bytes, int32_t *status, ph_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -698,6 +698,21 @@ int pho_attn_cross_fwd(const float *q, const float *k, const float *v, const uin
 }
 
 
+/* The same attention with K and V given as the split f16 operands the projections emit (hi + lo = value * 2^exp2):
+ * recombine, undo the power of two, run the fp32 restatement above.  `status` is never raised here (no f16 Q split). */
+int pho_attn_cross_split(const float *q, const void *k_split, const void *v_split, int32_t exp2, const uint32_t *bits,
+                         const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h, int32_t qn, int32_t dh,
+                         void *ws, int64_t ws_bytes, int32_t *status, ph_stream_t stream) {
+  (void)status;
+  if ((h * dh) % 32 != 0) return fail("attn_cross_split: model width is not a multiple of 32");
+  float *k = unsplit_rows(k_split, (int64_t)b * n, h * dh, ldexpf(1.f, -exp2));
+  float *v = unsplit_rows(v_split, (int64_t)b * n, h * dh, ldexpf(1.f, -exp2));
+  int rc = pho_attn_cross_fwd(q, k, v, bits, any, out, n, b, h, qn, dh, ws, ws_bytes, stream);
+  free(k);
+  free(v);
+  return rc;
+}
+
 int pho_bits_orpool(const uint32_t *bits_in, const int32_t *nbr, int32_t kvol, int64_t n_out, uint32_t *bits_out,
                     ph_stream_t stream) {
   (void)stream;

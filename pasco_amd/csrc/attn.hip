@@ -242,6 +242,325 @@ __global__ void __launch_bounds__(256) k_attn_merge(AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same attention on split f16 operands (what the K / V projections emit: ph_conv_desc.out_split):
+// every product is three v_mfma_f32_32x32x16_f16 (hi hi + hi lo + lo hi, fp32 accumulate), 16x the fp32 MFMA rate, so
+// the kernel is bound by streaming K and V once instead of by the matrix pipe.
+//
+//   workgroup = 4 waves = the 4 query tiles (32 queries each) of one (subnet b, head h, key range); the waves share the
+//   K / V / mask tiles of 32 keys, which arrive by LDS-DMA (global_load_lds) into a ring of 3 stages, one barrier per tile
+//   S^T[32 keys x 32 q] = K Q^T        A = K fragment (ds_read_b128: key = lane & 31, 8 dims), B = Q hi / lo in registers
+//   online softmax per lane            lane (q = lane & 31, h2 = lane >> 5) owns keys 8g + 4 h2 + r of its query: one
+//                                      exchange with lane ^ 32 for the row max, none for P
+//   O^T[dims x 32 q] += V^T P          B = P straight from the S registers (k-slot i of key chunk c <-> key
+//                                      16c + 8 (i >> 2) + 4 h2 + (i & 3)); A = V^T through ds_read_b64_tr_b16, the LDS
+//                                      transpose read of gfx950, with the same key order.  dims are tiled 0..31 | 32..63:
+//                                      the second tile's upper half is beyond the 48-dim head and never stored.
+// Heads of one key range sit on the same XCD (blockIdx -> (range, head) below): the 128-byte operand groups two heads
+// share are fetched once per L2.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct AttnSplitArgs {
+  AttnArgs a;                 // k / v unused; part / out / bits / any / shapes / splits (tiles_per_wave = 32-key tiles per range)
+  const _Float16 *ks, *vs;    // split operands [B*N, D/32, 2, 32]
+  float kv_unscale;           // 2^-exp2 of the K and V operands
+  int *status;                // |Q * 2^8| beyond the f16 range -> bit 1 (the caller reruns in fp32), or null
+  int groups;                 // B * splits
+};
+
+constexpr int AS_KT = 32;                     // keys per tile
+constexpr int AS_K_BYTES = 12 * 32 * 16;      // [granule (chunk, plane, half)][key] 16-byte granules
+constexpr int AS_V_BYTES = 48 * 128;          // [(plane, key quad, chunk)] blocks of [4 keys][16 dims]
+constexpr int AS_M_BYTES = 4 * 32 * 4;        // [word][key]
+constexpr int AS_STAGE = AS_K_BYTES + AS_V_BYTES + AS_M_BYTES;
+constexpr int AS_STAGES = 3;
+constexpr float AS_QSCALE = 256.f;            // Q is split as q * 2^8
+constexpr float AS_PSCALE = 4096.f;           // P is split as p * 2^12 (cancels between O and l)
+
+// LDS reads of the tile loop go through inline asm: the compiler cannot tell them from the LDS-DMA writes in flight for the
+// next tiles and would wait vmcnt(0) in front of them (the counted waits below are the synchronisation)
+__device__ __forceinline__ h16x8 as_rd128(uint32_t addr) {
+  h16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 as_rd128u(uint32_t addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ s16x4 as_rdtr(uint32_t addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+template <bool MASK>
+__global__ void __launch_bounds__(256) k_attn_split(AttnSplitArgs s) {
+  const AttnArgs &a = s.a;
+  __shared__ __attribute__((aligned(16))) char lds[AS_STAGE * AS_STAGES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, h2 = lane >> 5;
+  // blockIdx -> (key range group, head): the H heads of a group are consecutive on one XCD
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int group = (j / a.H) * 8 + xcd, h = j % a.H;
+  if (group >= s.groups) return;
+  const int b = group / a.splits, split = group - b * a.splits;
+  const int D = a.H * 48;
+  const int rowb = (D >> 5) * 128;            // bytes per operand row
+  const int64_t ntile_all = (a.n + AS_KT - 1) / AS_KT;
+  const int64_t t0 = (int64_t)split * a.tiles_per_wave;
+  int64_t t1 = t0 + a.tiles_per_wave;
+  if (t1 > ntile_all) t1 = ntile_all;
+  const int ntile = (int)(t1 - t0);
+
+  // ---- DMA plan: 12 sixteen-byte instructions per tile (K 0..5, V 0..5; 64 granules each, lane-linear in LDS), three per
+  // wave (e = wave, wave + 4, wave + 8), + the two mask-word instructions on waves 0 and 1 ----------------------------------
+  // K instr i: granule gid = 2i + h2 of key l31;  V instr i: block 8i + (lane >> 3), granule (key in quad, dim half) = lane & 7
+  int d_key[3], d_off[3], d_dst[3];
+  const char *d_base[3];
+  const char *kbase = (const char *)s.ks + (int64_t)b * a.n * rowb;
+  const char *vbase = (const char *)s.vs + (int64_t)b * a.n * rowb;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int e = wave + 4 * k;                 // wave-uniform
+    if (e < 6) {
+      const int gid = 2 * e + h2;
+      const int c = gid >> 2, plane = (gid >> 1) & 1, half = gid & 1;
+      const int ch = 3 * h + c;
+      d_key[k] = l31;
+      d_off[k] = (ch >> 1) * 128 + plane * 64 + (ch & 1) * 32 + half * 16;
+      d_dst[k] = e * 1024;
+      d_base[k] = kbase;
+    } else {
+      const int i = e - 6;
+      const int blk = 8 * i + (lane >> 3);
+      const int vc = blk % 3, pk = blk / 3;
+      const int vplane = pk >> 3, kq = pk & 7;
+      const int vch = 3 * h + vc;
+      d_key[k] = 4 * kq + ((lane & 7) >> 1);
+      d_off[k] = (vch >> 1) * 128 + vplane * 64 + (vch & 1) * 32 + (lane & 1) * 16;
+      d_dst[k] = AS_K_BYTES + i * 1024;
+      d_base[k] = vbase;
+    }
+  }
+  constexpr bool has_bits = MASK;
+  const bool mask_wave = has_bits && wave < 2;          // mask words [w][key]: instr m = wave: w = 2m + h2
+  const char *mbase = has_bits ? (const char *)a.bits + (int64_t)b * a.n * 16 + (2 * wave + h2) * 4 : nullptr;
+
+  auto fire = [&](int tile_local) {
+    const int64_t nb = (t0 + tile_local) * AS_KT;
+    char *st = lds + (tile_local % AS_STAGES) * AS_STAGE;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int64_t key = nb + d_key[k];
+      if (key >= a.n) key = a.n - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(d_base[k] + key * rowb + d_off[k]),
+                                       (__attribute__((address_space(3))) void *)(st + d_dst[k]), 16, 0, 0);
+    }
+    if (mask_wave) {
+      int64_t key = nb + l31;
+      if (key >= a.n) key = a.n - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(mbase + key * 16),
+                                       (__attribute__((address_space(3))) void *)(st + AS_K_BYTES + AS_V_BYTES + wave * 256), 4, 0, 0);
+    }
+  };
+  const int per_tile = mask_wave ? 4 : 3;
+
+  // ---- Q fragments of this wave's query tile: B[k = dim][n = q]: lane (q = l31, dims 8 h2 .. + 7 of chunk c) --------------
+  const int qt = wave;
+  const int qq = qt * 32 + l31;
+  const bool qv = qq < a.Qn;
+  const bool wave_live = qt * 32 < a.Qn;
+  h16x8 qh[3], ql[3];
+  bool qbad = false;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v8[i] = 0.f;
+    if (qv) {
+      const float *src = a.q + (((int64_t)b * a.H + h) * a.Qn + qq) * 48 + 16 * c + 8 * h2;
+      const float4 x0 = *reinterpret_cast<const float4 *>(src), x1 = *reinterpret_cast<const float4 *>(src + 4);
+      v8[0] = x0.x; v8[1] = x0.y; v8[2] = x0.z; v8[3] = x0.w; v8[4] = x1.x; v8[5] = x1.y; v8[6] = x1.z; v8[7] = x1.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float t = v8[i] * AS_QSCALE;
+      qbad |= !(fabsf(t) <= 65504.f);
+      const _Float16 th = (_Float16)t;
+      qh[c][i] = th;
+      ql[c][i] = (_Float16)(t - (float)th);
+    }
+  }
+  if (s.status != nullptr && qbad) atomicOr(s.status, 1);
+  unsigned force = 1u;
+  if (has_bits) {
+    force = 0u;
+    if (a.any != nullptr && qv) force = ((a.any[b * 4 + qt] >> l31) & 1u) ? 0u : 1u;
+  }
+  const float s_unscale = s.kv_unscale * (1.f / AS_QSCALE);
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 oacc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) oacc[0][i] = oacc[1][i] = 0.f;
+
+  // fragment read addresses (LDS byte addresses within stage 0)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+  const uint32_t k_rd = lds0 + (h2 * 32 + l31) * 16;                             // + (c * 2 + plane) * 1024
+  const int i16 = lane & 15, dsel = (lane >> 4) & 1;
+  uint32_t v_rd[2];                                                               // per dim tile: + ((plane * 8 + kq) * 3) * 128
+  v_rd[0] = lds0 + AS_K_BYTES + dsel * 128 + (i16 >> 2) * 32 + (i16 & 3) * 8;
+  v_rd[1] = lds0 + AS_K_BYTES + 2 * 128 + (i16 >> 2) * 32 + (i16 & 3) * 8;       // chunk 2 for both halves (dims 48..63 do not
+                                                                                  // exist: any finite operand, rows never stored)
+  const uint32_t m_rd = lds0 + AS_K_BYTES + AS_V_BYTES + (qt * 32 + 4 * h2) * 4; // + 32 g
+  const unsigned lanebit = 1u << l31;
+
+  if (ntile > 0) fire(0);
+  if (ntile > 1) fire(1);
+  for (int t = 0; t < ntile; ++t) {
+    // stage t landed (this wave's part), everybody past tile t - 1: then refill the stage tile t - 1 used
+    if (t + 1 < ntile) {
+      if (per_tile == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < ntile) fire(t + 2);
+    if (!wave_live) continue;
+    const uint32_t so = (uint32_t)((t % AS_STAGES) * AS_STAGE);
+    const int64_t nb = (t0 + t) * AS_KT;
+    const int nvalid = a.n - nb < AS_KT ? (int)(a.n - nb) : AS_KT;
+
+    // ---- S^T = K Q^T ---------------------------------------------------------------------------------------------------
+    h16x8 kh[3], kl[3];
+    u32x4 mw[4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      kh[c] = as_rd128(so + k_rd + (c * 2 + 0) * 1024);
+      kl[c] = as_rd128(so + k_rd + (c * 2 + 1) * 1024);
+    }
+    if (MASK) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) mw[g] = as_rd128u(so + m_rd + 32 * g);
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(kh[0]), "+v"(kh[1]), "+v"(kh[2]), "+v"(kl[0]), "+v"(kl[1]), "+v"(kl[2]), "+v"(mw[0]), "+v"(mw[1]),
+                     "+v"(mw[2]), "+v"(mw[3])::"memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(kh[0]), "+v"(kh[1]), "+v"(kh[2]), "+v"(kl[0]), "+v"(kl[1]), "+v"(kl[2])::"memory");
+    }
+    // V^T fragments of the whole tile: in flight under the score MFMAs and the softmax
+    s16x4 vt[2][2][2][2];                        // [dim tile][key chunk][plane][r]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int plane = 0; plane < 2; ++plane)
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+            vt[mt][kc][plane][r] = as_rdtr(so + v_rd[mt] + (uint32_t)(((plane * 8 + 4 * kc + 2 * r) * 3) * 128) + (uint32_t)(h2 * 384));
+    f32x16 sacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[c], qh[c], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[c], ql[c], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[c], qh[c], sacc, 0, 0, 0);
+    }
+    // ---- mask + online softmax: this lane's query is qq; register 4g + r is key nb + 8g + 4 h2 + r ----------------------
+    float sv[16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const unsigned wr[4] = {mw[g][0], mw[g][1], mw[g][2], mw[g][3]};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        bool ok = 8 * g + r + 4 * h2 < nvalid;
+        if (MASK) ok = ok && (force || (wr[r] & lanebit));
+        const float x = ok ? sacc[4 * g + r] * s_unscale : -INFINITY;
+        sv[4 * g + r] = x;
+        tmax = fmaxf(tmax, x);
+      }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __expf(m_run - m_safe);      // m_run = -inf -> 0 (nothing accumulated yet)
+    m_run = m_new;
+    h16x8 ph[2], pl[2];
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = __expf(sv[i] - m_safe) * AS_PSCALE;
+      psum += p;
+      const _Float16 th = (_Float16)p;
+      ph[i >> 3][i & 7] = th;
+      pl[i >> 3][i & 7] = (_Float16)(p - (float)th);
+    }
+    l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.f)) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        oacc[0][i] *= alpha;
+        oacc[1][i] *= alpha;
+      }
+    }
+    // ---- O^T += V^T P ---------------------------------------------------------------------------------------------------
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vt[0][0][0][0]), "+v"(vt[0][0][0][1]), "+v"(vt[0][0][1][0]), "+v"(vt[0][0][1][1]), "+v"(vt[0][1][0][0]),
+                   "+v"(vt[0][1][0][1]), "+v"(vt[0][1][1][0]), "+v"(vt[0][1][1][1]), "+v"(vt[1][0][0][0]), "+v"(vt[1][0][0][1]),
+                   "+v"(vt[1][0][1][0]), "+v"(vt[1][0][1][1]), "+v"(vt[1][1][0][0]), "+v"(vt[1][1][0][1]), "+v"(vt[1][1][1][0]),
+                   "+v"(vt[1][1][1][1])::"memory");
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        h16x8 vh, vl;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const h16x4 yh = __builtin_bit_cast(h16x4, vt[mt][kc][0][r]);
+          const h16x4 yl = __builtin_bit_cast(h16x4, vt[mt][kc][1][r]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vh[4 * r + e] = yh[e];
+            vl[4 * r + e] = yl[e];
+          }
+        }
+        oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[kc], oacc[mt], 0, 0, 0);
+        oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kc], oacc[mt], 0, 0, 0);
+        oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[kc], oacc[mt], 0, 0, 0);
+      }
+  }
+
+  // ---- partial record of this (b, h, range): per query O[48], m, l (k_attn_merge's format) -------------------------------
+  if (!wave_live) return;
+  const int64_t w = ((int64_t)b * a.H + h) * a.splits + split;
+  float *row = a.part + (w * a.qp + qq) * (48 + 4);
+  float lt = l_run + __shfl_xor(l_run, 32);
+  if (h2 == 0) {
+    row[48] = m_run;
+    row[49] = lt;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = 32 * mt + 8 * g + 4 * h2;
+      if (d >= 48) continue;
+      *reinterpret_cast<float4 *>(row + d) = make_float4(oacc[mt][4 * g] * s.kv_unscale, oacc[mt][4 * g + 1] * s.kv_unscale,
+                                                         oacc[mt][4 * g + 2] * s.kv_unscale, oacc[mt][4 * g + 3] * s.kv_unscale);
+    }
+}
+
 // vals [R, Qn] -> bits [R, 4] ; any[b, 4] |= bits (R = B * N, b = row / N).  One wave64 per row: two
 // coalesced 256-byte loads, two ballots.
 __global__ void __launch_bounds__(256)
@@ -369,6 +688,45 @@ extern "C" int ph_attn_cross_fwd(const float *q, const float *k, const float *v,
   const unsigned grid = (unsigned)((waves + 3) / 4);
   a.qp = qn <= 64 ? 64 : 128;   // 2-tile query blocks were measured slower (K / V re-read by four waves)
   hipLaunchKernelGGL((k_attn_cross<4, 3>), dim3(grid, a.qp / 64), dim3(256), 0, st, a);
+  PH_LAUNCH_CHECK();
+  hipLaunchKernelGGL((k_attn_merge<4, 3>), dim3(bh, (qn + 15) / 16), dim3(256), 0, st, a);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ph_attn_cross_split(const float *q, const void *k_split, const void *v_split, int32_t exp2, const uint32_t *bits,
+                                   const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h, int32_t qn, int32_t dh,
+                                   void *ws, int64_t ws_bytes, int32_t *status, ph_stream_t stream) {
+  PH_REQUIRE(q && k_split && v_split && out, "attn_cross_split: null tensor");
+  PH_REQUIRE(dh == 48, "attn_cross_split: head dim %d not served (48)", dh);
+  PH_REQUIRE((h * dh) % 32 == 0, "attn_cross_split: model width %d is not a multiple of 32", h * dh);
+  PH_REQUIRE(qn >= 1 && qn <= 128, "attn_cross_split: %d queries not served (1..128)", qn);
+  PH_REQUIRE(b >= 1 && h >= 1 && n >= 1, "attn_cross_split: bad shape");
+  PH_REQUIRE(exp2 >= -14 && exp2 <= 14, "attn_cross_split: operand exponent %d", exp2);
+  PH_REQUIRE(ws_bytes >= ph_attn_workspace_bytes(n, b, h, qn, dh), "attn_cross_split: workspace too small");
+  AttnSplitArgs s;
+  AttnArgs &a = s.a;
+  a.q = q; a.k = nullptr; a.v = nullptr; a.bits = bits; a.any = any; a.part = (float *)ws; a.out = out;
+  a.n = n; a.B = b; a.H = h; a.Qn = qn; a.Dh = dh;
+  s.ks = (const _Float16 *)k_split; s.vs = (const _Float16 *)v_split;
+  s.kv_unscale = ldexpf(1.f, -exp2);
+  s.status = status;
+  const int64_t ntile = (n + AS_KT - 1) / AS_KT;
+  const int bh = b * h;
+  // ~1536 workgroups (256 CUs x 3 resident x 2) in total, at most the 2048 + 4 b h partial records the workspace holds
+  int64_t splits = 1536 / bh;
+  if (splits < 1) splits = 1;
+  if (splits > ntile) splits = ntile;
+  int64_t tpw = (ntile + splits - 1) / splits;
+  splits = (ntile + tpw - 1) / tpw;
+  a.splits = (int)splits;
+  a.tiles_per_wave = (int)tpw;
+  a.qp = qn <= 64 ? 64 : 128;
+  s.groups = b * (int)splits;
+  hipStream_t st = ph_stream(stream);
+  const int64_t groups8 = ((int64_t)s.groups + 7) / 8;       // groups per XCD
+  if (bits != nullptr) hipLaunchKernelGGL(k_attn_split<true>, dim3((unsigned)(groups8 * h * 8)), dim3(256), 0, st, s);
+  else hipLaunchKernelGGL(k_attn_split<false>, dim3((unsigned)(groups8 * h * 8)), dim3(256), 0, st, s);
   PH_LAUNCH_CHECK();
   hipLaunchKernelGGL((k_attn_merge<4, 3>), dim3(bh, (qn + 15) / 16), dim3(256), 0, st, a);
   PH_LAUNCH_CHECK();

@@ -30,6 +30,13 @@ from ..me.backend import backend_for
 from . import fused as fused_mod
 from .fused import batched_rows_matmul, linear_rows, prepare_batched_weights, split_rows_2d
 
+def _unsplit_rows(op: torch.Tensor, c: int) -> torch.Tensor:
+    """fp32 rows a split operand [n, c/32, 2, 32] stands for (diagnostic / fallback path)."""
+    from ..me.backend import SPLIT_ACT_EXP2
+    x = op.float()
+    return (x[:, :, 0] + x[:, :, 1]).reshape(op.shape[0], -1)[:, :c] * float(2.0 ** -SPLIT_ACT_EXP2)
+
+
 # torch registers generator / allocator state per capture in process-wide tables: one capture at a time
 _CAPTURE_LOCK = threading.Lock()
 
@@ -173,9 +180,10 @@ class CrossAttentionLayer(nn.Module):
         return q + mha.out_proj(o)
 
 
-    def attend(self, q_embed, kk, vv, query_pos, mask_bits):
-        """The layer with keys / values already projected ([B, N, D] each): query projection, masked attention
-        (ph_attn_cross_fwd), output projection, residual."""
+    def attend(self, q_embed, kk, vv, query_pos, mask_bits, split=None):
+        """The layer with keys / values already projected ([B, N, D] each, or `split` = (K operand, V operand, N): the
+        split f16 operands their projections emitted): query projection, masked attention (ph_attn_cross_fwd /
+        ph_attn_cross_split), output projection, residual."""
         q = self.norm(q_embed)
         mha = self.multihead_attn
         B, Q, D = q.shape
@@ -184,7 +192,10 @@ class CrossAttentionLayer(nn.Module):
         qq = F.linear(q if query_pos is None else q + query_pos, w[:D], b[:D]).view(B, Q, H, D // H).transpose(1, 2)
         be = backend_for(q.device)
         q4 = (qq * (float(D // H) ** -0.5)).contiguous()
-        o = be.attn_cross_fwd(q4, kk.contiguous(), vv.contiguous(), mask_bits[0], mask_bits[1])
+        if split is not None:
+            o = be.attn_cross_split(q4, split[0], split[1], split[2], mask_bits[0], mask_bits[1])
+        else:
+            o = be.attn_cross_fwd(q4, kk.contiguous(), vv.contiguous(), mask_bits[0], mask_bits[1])
         return q + mha.out_proj(o)
 
     def composed_kv(self, lin: nn.Linear, tab: torch.Tensor):
@@ -511,11 +522,17 @@ class TransformerPredictorV2(nn.Module):
                 x2 = srcs[i].reshape(-1, srcs[i].shape[-1])
                 x_split = split_rows_2d(x2)
                 ci = ci.contiguous()
-                kk = linear_rows(x2, cm["wk"], cm["bk"], ca, "ck", in_split=x_split,
-                                 axis=(cm["tk"], ci, self.pe_layer.TABLE_LO)).view(B, N_i, D)
-                vv = linear_rows(x2, cm["wv"], cm["bv"], ca, "cv", in_split=x_split,
-                                 axis=(cm["tv"], ci, self.pe_layer.TABLE_LO)).view(B, N_i, D)
-                output = ca.attend(output, kk, vv, query_embed, (bits, any_))
+                # ... written only as split f16 operands, which the attention kernel streams (ph_attn_cross_split)
+                kk, k_op = linear_rows(x2, cm["wk"], cm["bk"], ca, "ck", in_split=x_split, emit=True, want_out=False,
+                                       axis=(cm["tk"], ci, self.pe_layer.TABLE_LO))
+                vv, v_op = linear_rows(x2, cm["wv"], cm["bv"], ca, "cv", in_split=x_split, emit=True, want_out=False,
+                                       axis=(cm["tv"], ci, self.pe_layer.TABLE_LO))
+                if k_op is not None and v_op is not None and os.environ.get("PASCO_ATTN_SPLIT", "1") != "0":
+                    output = ca.attend(output, None, None, query_embed, (bits, any_), split=(k_op, v_op, N_i))
+                else:
+                    kk = kk if kk is not None else _unsplit_rows(k_op, D)
+                    vv = vv if vv is not None else _unsplit_rows(v_op, D)
+                    output = ca.attend(output, kk.view(B, N_i, D), vv.view(B, N_i, D), query_embed, (bits, any_))
             elif fused_attn:
                 # with the fused attention kernel src + pos is read only by the K / V projections: emit it as their
                 # operand (no fp32 copy)

@@ -87,6 +87,7 @@ _SIGNATURES = {
     "bits_orpool": [_vp, _vp, _i32, _i64, _vp, _vp],
     "bits_or_reduce": [_vp, _i64, _i32, _vp, _vp],
     "attn_cross_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
+    "attn_cross_split": [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
 }
 _RESTYPES = {"last_error": C.c_char_p, "workspace_bytes": _i64, "attn_workspace_bytes": _i64}
 _OPTIONAL = {}
@@ -690,6 +691,29 @@ class CBackend:
         rc = self.fn["attn_cross_fwd"](_ptr(q), _ptr(k), _ptr(v), _ptr(bits), _ptr(any_), _ptr(out), n, b, h, qn, dh,
                                        _ptr(ws), ws.numel(), self.stream(q.device))
         self._check(rc, "attn_cross_fwd")
+        return out
+
+
+    def attn_cross_split(self, q, k_split, v_split, n: int, bits=None, any_=None, exp2=None) -> torch.Tensor:
+        """attn_cross_fwd on split f16 K / V operands ([B*N, H*Dh/32, 2, 32] f16 each, value * 2^exp2; what
+        conv_fwd(..., out_split=) wrote): q [B,H,Qn,Dh] (pre-scaled) -> out [B,Qn,H*Dh]."""
+        self._chk(q, torch.float32, "q")
+        b, h, qn, dh = q.shape
+        d = h * dh
+        for t, nm in ((k_split, "k_split"), (v_split, "v_split")):
+            assert t.dtype == torch.float16 and t.is_contiguous() and t.numel() == b * n * d * 2, nm
+        exp2 = SPLIT_ACT_EXP2 if exp2 is None else int(exp2)
+        out = torch.empty((b, qn, d), dtype=torch.float32, device=q.device)
+        need = int(self.fn["attn_workspace_bytes"](n, b, h, qn, dh))
+        key = ("attn",) + self._stream_key(q.device)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+            self._ws[key] = ws
+        rc = self.fn["attn_cross_split"](_ptr(q), _ptr(k_split), _ptr(v_split), exp2, _ptr(bits), _ptr(any_), _ptr(out),
+                                         n, b, h, qn, dh, _ptr(ws), ws.numel(), _ptr(self.status_word(q.device)),
+                                         self.stream(q.device))
+        self._check(rc, "attn_cross_split")
         return out
 
 

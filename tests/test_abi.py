@@ -22,7 +22,7 @@ def declared():
 def test_header_declares_expected_entry_points():
     names = declared()
     for must in ("map_insert", "nbr_build", "kmap_compact", "conv_fwd", "maxpool_fwd", "mask_compact",
-                 "to_dense", "to_sparse_coords", "attn_cross_fwd"):
+                 "to_dense", "to_sparse_coords", "attn_cross_fwd", "attn_cross_split"):
         assert must in names
 
 

@@ -89,3 +89,60 @@ def test_attn_workspace_is_large_enough(hip, Q):
     ref = torch.nn.functional.scaled_dot_product_attention(
         q, k.view(B, N, H, Dh).transpose(1, 2), v.view(B, N, H, Dh).transpose(1, 2), scale=1.0)
     assert torch.allclose(out, ref.transpose(1, 2).reshape(B, Q, H * Dh), rtol=1e-4, atol=1e-4)
+
+
+def _unsplit(op, c, exp2):
+    """split operand [rows, c/32, 2, 32] f16 -> the fp32 values it stands for."""
+    x = op.float()
+    return ((x[:, :, 0] + x[:, :, 1]).reshape(op.shape[0], c) * float(2.0 ** -exp2))
+
+
+@pytest.mark.parametrize("B,H,Q,N", [(1, 8, 100, 1), (2, 8, 100, 31), (2, 8, 100, 32), (3, 8, 100, 33),
+                                      (3, 8, 100, 4097), (2, 8, 128, 3000), (1, 2, 5, 70000), (3, 8, 100, 60000),
+                                      (2, 4, 64, 2500)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attn_cross_split_matches_torch(hip, B, H, Q, N, masked):
+    """ph_attn_cross_split: K and V arrive as the split f16 operands a projection emits; the kernel's three-product f16
+    MFMAs must reproduce fp64 attention on the values those operands stand for to fp32 accuracy."""
+    g = torch.Generator().manual_seed(N + Q + 1)
+    Dh = 48
+    q = (torch.randn(B, H, Q, Dh, generator=g) * Dh ** -0.5).cuda()
+    k = (torch.randn(B, N, H * Dh, generator=g) * 1.7).cuda()
+    v = torch.randn(B, N, H * Dh, generator=g).cuda()
+    ks = hip.split_rows(k.reshape(B * N, -1).contiguous())
+    vs = hip.split_rows(v.reshape(B * N, -1).contiguous())
+    from pasco_amd.me.backend import SPLIT_ACT_EXP2
+    k2 = _unsplit(ks, H * Dh, SPLIT_ACT_EXP2).view(B, N, -1)
+    v2 = _unsplit(vs, H * Dh, SPLIT_ACT_EXP2).view(B, N, -1)
+    bits = any_ = allow = None
+    if masked:
+        allow = torch.rand(B, N, Q, generator=g) > 0.7
+        allow[:, :, 3] = False                                  # a query with nothing allowed
+        if N > 40:
+            allow[0, : N // 2, Q - 1] = False                   # whole tiles masked for one query
+        allow = allow.cuda()
+        bits, any_ = hip.attn_mask_pack(allow.reshape(B * N, Q).float().contiguous(), B, N)
+    got = hip.attn_cross_split(q, ks, vs, N, bits, any_)
+    exp = torch_ref(q, k2, v2, allow)
+    assert torch.isfinite(got).all()
+    assert torch.allclose(got, exp, rtol=1e-4, atol=2e-5), float((got - exp).abs().max())
+    # and it agrees with the fp32 kernel on the same values
+    ref32 = hip.attn_cross_fwd(q, k2.contiguous(), v2.contiguous(), bits, any_)
+    assert torch.allclose(got, ref32, rtol=1e-4, atol=2e-5)
+
+
+def test_attn_cross_split_vs_oracle_and_peaked_scores(hip, oracle):
+    """Oracle parity on the same operands, with score magnitudes up to ~60 (peaked softmax: the running maximum moves)."""
+    g = torch.Generator().manual_seed(5)
+    B, N, Q, H, Dh = 2, 1777, 100, 8, 48
+    q = torch.randn(B, H, Q, Dh, generator=g) * 1.5
+    k = torch.randn(B, N, H * Dh, generator=g)
+    v = torch.randn(B, N, H * Dh, generator=g) * 3
+    allow = torch.rand(B, N, Q, generator=g) > 0.5
+    bits_o, any_o = oracle.attn_mask_pack(allow.reshape(B * N, Q).float(), B, N)
+    ks_o, vs_o = oracle.split_rows(k.reshape(B * N, -1)), oracle.split_rows(v.reshape(B * N, -1))
+    exp = oracle.attn_cross_split(q, ks_o, vs_o, N, bits_o, any_o)
+    ks, vs = hip.split_rows(k.reshape(B * N, -1).cuda()), hip.split_rows(v.reshape(B * N, -1).cuda())
+    assert torch.equal(ks.cpu(), ks_o)
+    got = hip.attn_cross_split(q.cuda(), ks, vs, N, bits_o.cuda(), any_o.cuda()).cpu()
+    assert torch.allclose(got, exp, rtol=2e-4, atol=1e-4), float((got - exp).abs().max())
