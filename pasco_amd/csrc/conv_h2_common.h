@@ -85,6 +85,8 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st);
 
 // conv_f16x3.hip: reduction + epilogue of a split over the kernel offsets (after a launch with args.ksplit > 1)
 int ph_launch_splitk_epilogue(const ConvArgsH &args, hipStream_t st);
+// conv_lin.hip: tall linear layers with the kernel resident in LDS; -1 = shape not served
+int ph_conv_lin_try(const ConvArgsH &a, hipStream_t st);
 // conv_dma.hip: the LDS-DMA pipelined kernel; -1 = shape not served (caller falls back to k_conv_h2)
 int ph_conv_dma_try(const ConvArgsH &a, int bn, hipStream_t st);
 
