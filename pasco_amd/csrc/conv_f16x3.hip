@@ -595,10 +595,8 @@ struct ConvHKnobs {
   bool dma_all = false;
   bool win_on = true;      // PASCO_CONV_WIN=0: no LDS-window kernel
   bool win_wide = false;   // PASCO_CONV_WIN=2: also on 128-wide tiles
-  bool lin_on = true;      // PASCO_CONV_LIN=0: no streaming kernel for tall linear layers
   bool dma_on = true;      // PASCO_CONV_DMA=0: keep every launch on the register-staged k_conv_h2 (A/B comparisons)
   ConvHKnobs() {
-    if (const char *e = getenv("PASCO_CONV_LIN")) lin_on = atoi(e) != 0;
     if (const char *e = getenv("PASCO_CONV_DMA")) {
       dma_on = atoi(e) != 0;
       dma_all = atoi(e) == 2;      // 2: every tile width on the DMA kernel
@@ -646,6 +644,12 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.osp_neg = d->osp_act == PH_ACT_RELU ? 0.f : (d->osp_act == PH_ACT_LEAKY ? d->epi_slope : 1.f);
   PH_REQUIRE(d->split_exp2 >= -16 && d->split_exp2 <= 16, "conv_fwd(f16x3): split_exp2 out of range (%d)", d->split_exp2);
   a.act_pow2 = ldexpf(1.f, d->split_exp2);
+  {   // the epilogue reads the per-channel vectors as float4 when all of them allow it
+    uintptr_t bits = 0;
+    const float *vecs[] = {d->bias, d->epi_scale, d->epi_shift, d->epi2_scale, d->epi2_shift, d->osp_scale, d->osp_shift};
+    for (const float *v : vecs) bits |= (uintptr_t)v;
+    a.par_vec = ((bits & 15) == 0 && d->cout % 4 == 0) ? 1 : 0;
+  }
   if (d->out_split) {
     PH_REQUIRE(pre, "conv_fwd(f16x3): out_split needs mma_mode 2");
     PH_REQUIRE(d->cout % 32 == 0 && (((uintptr_t)d->out_split) & 15) == 0, "conv_fwd(f16x3): out_split needs cout %% 32 == 0");
@@ -758,12 +762,6 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
     if (bm != 128) bm = 128;   // pairs are only formed on big maps: the gather side keeps its 128-row tile
   }
   auto gather_launch = [&]() -> int {
-    // tall linear layers (kernel volume 1, identity map, 64 / 128 input channels): weights resident in LDS, rows streamed
-    // (conv_lin.hip); PASCO_CONV_LIN=0 keeps them on the tile kernels
-    if (pre && knobs.lin_on && !env) {
-      const int rc = ph_conv_lin_try(a, st);
-      if (rc >= 0) return rc;
-    }
   // default for pre-split operands: the LDS-DMA pipelined kernel (conv_dma.hip; 128-row tiles, parallelism of few-row
     // layers from the split over the offsets chosen above); it declines slices of more than 32 offsets
     // measured (profiles/README.md, round 2): 6-9 % faster than k_conv_h2 on 128-channel-wide tiles, a few % slower on 64-wide

@@ -52,21 +52,46 @@ struct ConvArgsH {
   const float *axis_table;
   const int32_t *axis_coords;
   int axis_lo, axis_rows;
+  int par_vec;                // every per-channel vector (bias, epi*, osp*) is 16-byte aligned: the epilogue loads them as float4
 };
 
-// t0[x] + t1[y] + t2[z] for 4 consecutive channels of one output row (coordinates clamped to the table)
-__device__ __forceinline__ float4 ph_axis_residual4(const ConvArgsH &a, int64_t row, int col) {
+// element offsets of the three table rows (x, y, z) of one output row (coordinates clamped to the table)
+__device__ __forceinline__ void ph_axis_offsets(const ConvArgsH &a, int64_t row, int64_t (&off)[3]) {
   const int4 c = *reinterpret_cast<const int4 *>(a.axis_coords + row * 4);
   const int v[3] = {c.y, c.z, c.w};
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax) {
     int idx = v[ax] - a.axis_lo;
     idx = idx < 0 ? 0 : (idx >= a.axis_rows ? a.axis_rows - 1 : idx);
-    const float4 t = *reinterpret_cast<const float4 *>(a.axis_table + ((int64_t)ax * a.axis_rows + idx) * a.cout + col);
+    off[ax] = ((int64_t)ax * a.axis_rows + idx) * a.cout;
+  }
+}
+// t0[x] + t1[y] + t2[z] for 4 consecutive channels of one output row
+__device__ __forceinline__ float4 ph_axis_residual4(const ConvArgsH &a, const int64_t (&off)[3], int col) {
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const float4 t = *reinterpret_cast<const float4 *>(a.axis_table + off[ax] + col);
     s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
   }
   return s;
+}
+__device__ __forceinline__ float4 ph_axis_residual4(const ConvArgsH &a, int64_t row, int col) {
+  int64_t off[3];
+  ph_axis_offsets(a, row, off);
+  return ph_axis_residual4(a, off, col);
+}
+// 4 consecutive entries of a per-channel vector (or `dflt` when the vector is absent / the run is past the last channel)
+__device__ __forceinline__ void ph_par4(const ConvArgsH &a, const float *p, int col, bool ok, float dflt, float (&dst)[4]) {
+  dst[0] = dst[1] = dst[2] = dst[3] = dflt;
+  if (p == nullptr || !ok) return;
+  if (a.par_vec) {
+    const float4 v = *reinterpret_cast<const float4 *>(p + col);
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = p[col + q];
+  }
 }
 
 // mean window passes per tile <= 1.25 -> the window kernel serves the map (which: bit 8 / 9 = test override:
@@ -85,8 +110,6 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st);
 
 // conv_f16x3.hip: reduction + epilogue of a split over the kernel offsets (after a launch with args.ksplit > 1)
 int ph_launch_splitk_epilogue(const ConvArgsH &args, hipStream_t st);
-// conv_lin.hip: tall linear layers with the kernel resident in LDS; -1 = shape not served
-int ph_conv_lin_try(const ConvArgsH &a, hipStream_t st);
 // conv_dma.hip: the LDS-DMA pipelined kernel; -1 = shape not served (caller falls back to k_conv_h2)
 int ph_conv_dma_try(const ConvArgsH &a, int bn, hipStream_t st);
 
@@ -116,12 +139,26 @@ __device__ __forceinline__ bool emit_split4(const float v[4], const float *sc, c
 
 
 
+// Where the epilogue reads the per-channel vectors from: global memory (default), or a copy the kernel staged in LDS
+// (a persistent kernel whose waves must not wait on vector-memory loads between their stores).  `which`: 0 bias,
+// 1 epi_scale, 2 epi_shift, 3 epi2_scale, 4 epi2_shift, 5 osp_scale, 6 osp_shift.
+struct ParGlobal {
+  __device__ __forceinline__ void get(const ConvArgsH &a, int which, const float *p, int col, bool ok, float dflt,
+                                      float (&dst)[4]) const {
+    (void)which;
+    ph_par4(a, p, col, ok, dflt, dst);
+  }
+};
+
 // Epilogue of the transposed-accumulator tile (shared by k_conv_h2 and k_conv_dma): raw partial sums for a split over
 // the kernel offsets, else bias / BN / activation / residual tail as float4 stores and, with EMIT, the next
 // convolution's split operand.
-template <int TM, int TN, bool EMIT>
+// `axis_vals` (optional): the table residual already summed by the caller, float4 per [i][j][m][u] (for a caller that
+// fetches the table rows ahead of its stores).
+template <int TM, int TN, bool EMIT, class PAR = ParGlobal>
 __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm,
-                                              int wn, int h, int l31) {
+                                              int wn, int h, int l31, const int64_t (*axis_pre)[3] = nullptr,
+                                              const PAR &par = PAR(), const float4 *axis_vals = nullptr) {
   const int cout = a.cout;
   // accumulator layout (transposed block): acc[i][j][4g + q] = out[row = m0 + (wm*TM+i)*32 + l31]
   //                                                          [col = n0 + (wn*TN+j)*32 + 8g + 4h + q]
@@ -144,6 +181,21 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
     return;
   }
 
+  // table residual: the three table rows of each of this lane's rows, found once per tile (or by the caller: axis_pre)
+  int64_t axis_off[TM][3];
+  if (a.axis_table && axis_vals == nullptr) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int64_t row = m0 + (wm * TM + i) * 32 + l31;
+      if (axis_pre) {
+        axis_off[i][0] = axis_pre[i][0]; axis_off[i][1] = axis_pre[i][1]; axis_off[i][2] = axis_pre[i][2];
+      } else if (row < a.n_out) {
+        ph_axis_offsets(a, row, axis_off[i]);
+      } else {
+        axis_off[i][0] = axis_off[i][1] = axis_off[i][2] = 0;
+      }
+    }
+  }
   bool obad = false;
 #pragma unroll
   for (int j = 0; j < TN; ++j)
@@ -157,23 +209,28 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
       for (int u = 0; u < 2; ++u) {
         const int col = cbase + 8 * u + 4 * h;
         cok[u] = col < cout;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c = cok[u] ? col + q : 0;
-          bias[u][q] = a.bias ? a.bias[c] : 0.f;
-          es[u][q] = a.epi_scale ? a.epi_scale[c] : 1.f;
-          eb[u][q] = a.epi_shift ? a.epi_shift[c] : 0.f;
-          es2[u][q] = a.epi2_scale ? a.epi2_scale[c] : 1.f;
-          eb2[u][q] = a.epi2_shift ? a.epi2_shift[c] : 0.f;
-        }
+        par.get(a, 0, a.bias, col, cok[u], 0.f, bias[u]);
+        par.get(a, 1, a.epi_scale, col, cok[u], 1.f, es[u]);
+        par.get(a, 2, a.epi_shift, col, cok[u], 0.f, eb[u]);
+        par.get(a, 3, a.epi2_scale, col, cok[u], 1.f, es2[u]);
+        par.get(a, 4, a.epi2_shift, col, cok[u], 0.f, eb2[u]);
       }
       // operand emission: after a half-wave exchange this lane owns 8 consecutive channels cbase + 8h .. + 7
       float sc[8], sh[8];
       if (EMIT) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          sc[q] = a.osp_scale ? a.osp_scale[cbase + 8 * h + q] : 1.f;
-          sh[q] = a.osp_shift ? a.osp_shift[cbase + 8 * h + q] : 0.f;
+        for (int q = 0; q < 8; ++q) sc[q] = 1.f, sh[q] = 0.f;
+        if (a.osp_has) {
+          float t4[4];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            par.get(a, 5, a.osp_scale, cbase + 8 * h + 4 * u, true, 1.f, t4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sc[4 * u + q] = t4[q];
+            par.get(a, 6, a.osp_shift, cbase + 8 * h + 4 * u, true, 0.f, t4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sh[4 * u + q] = t4[q];
+          }
         }
       }
 #pragma unroll
@@ -192,7 +249,7 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
             float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.residual && rok && cok[u]) rs = *reinterpret_cast<const float4 *>(a.residual + row * cout + col);
             if (a.axis_table && rok && cok[u]) {   // table rows first, then the dense residual (as the C restatement)
-              const float4 t = ph_axis_residual4(a, row, col);
+              const float4 t = axis_vals ? axis_vals[((i * TN + j) * 2 + m) * 2 + u] : ph_axis_residual4(a, axis_off[i], col);
               rs = make_float4(t.x + rs.x, t.y + rs.y, t.z + rs.z, t.w + rs.w);
             }
             const float r4[4] = {rs.x, rs.y, rs.z, rs.w};
