@@ -322,3 +322,17 @@ int ph_conv_dma_try(const ConvArgsH &a_in, int bn, hipStream_t st) {
   if (bn == 64) return tall ? launch_dma<8, 8, 1, 1, 2>(a, st) : launch_dma<4, 4, 1, 1, 2>(a, st);
   return tall ? launch_dma<8, 4, 2, 2, 2>(a, st) : launch_dma<4, 2, 2, 2, 2>(a, st);
 }
+
+// development hook (tools/occupancy.py): resident workgroups per CU of the main instantiations
+extern "C" int ph_conv_dma_occupancy(int which) {
+  int n = -1;
+  hipError_t e = hipSuccess;
+  switch (which) {
+    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_dma<4, 2, 2, 2, 2, false>, 256, 0); break;
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_dma<4, 2, 2, 2, 2, true>, 256, 0); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_dma<4, 4, 1, 1, 2, false>, 256, 0); break;
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_conv_dma<4, 4, 1, 1, 1, false>, 256, 0); break;
+    default: break;
+  }
+  return e == hipSuccess ? n : -1;
+}
