@@ -332,6 +332,24 @@ int PH_FN(attn_cross_split)(const float *q, const void *k_split, const void *v_s
                             const uint32_t *bits, const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h,
                             int32_t qn, int32_t dh, void *ws, int64_t ws_bytes, int32_t *status, ph_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Panoptic ensembling on the compacted union of occupied canonical sites (reference: pasco/models/ensembler.py:20-131,
+ * which works on dense [100, 256, 256, 32] tensors per subnet).  sel [U] = canonical site id of every union row.
+ *   ens_resample: out[u, :] = sigmoid(logits[rows[sel[u]], :]) (rows [n_sites]: the subnet's voxel row of a canonical
+ *                 site or -1 -> zeros) = sigmoid + grid_sample(nearest, zero padding) of ensembler.py:44-62;
+ *                 flag[u] = the row has a non-zero entry (what ME.to_sparse keeps, misc.py:46-57)
+ *   ens_merge   : anchor = (anchor * i + m[:, perm]) / (i + 1), the running mean of the Hungarian-matched query masks
+ *                 (ensembler.py:86-98), in place, fp32 operations in that order
+ *   ens_finish  : out[u, j] = anchor[u, keep[j]] * (argmax_c sem[sel[u], c] != 0) (matched-IoU filter of the queries and
+ *                 the "empty class" zeroing, ensembler.py:100-118); flag as above.  sem [n_sites, c] channels last.
+ * ------------------------------------------------------------------------------------------- */
+int PH_FN(ens_resample)(const float *logits, int64_t n, int32_t q, const int32_t *rows, const int32_t *sel, int64_t u,
+                        float *out, uint8_t *flag, ph_stream_t stream);
+int PH_FN(ens_merge)(float *anchor, const float *m, const int32_t *perm, int64_t u, int32_t q, int32_t i,
+                     ph_stream_t stream);
+int PH_FN(ens_finish)(const float *anchor, int64_t u, int32_t q, const int32_t *keep, int32_t qk, const float *sem,
+                      int32_t c, const int32_t *sel, float *out, uint8_t *flag, ph_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

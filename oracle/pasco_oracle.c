@@ -768,3 +768,59 @@ int pho_sine_pe(const int32_t *coords, int64_t n, int32_t cstride, int32_t coff,
   }
   return 0;
 }
+
+/* ---- panoptic ensembling rows (ensembler.py:44-62, 86-98, 100-118; misc.py:46-57) ---------------------------------- */
+int pho_ens_resample(const float *logits, int64_t n, int32_t q, const int32_t *rows, const int32_t *sel, int64_t u,
+                     float *out, uint8_t *flag, ph_stream_t stream) {
+  (void)stream; (void)n;
+  if (q < 1 || q > 128) return fail("ens_resample: bad shape");
+  for (int64_t s = 0; s < u; ++s) {
+    const int r = rows[sel[s]];
+    int any = 0;
+    for (int c = 0; c < q; ++c) {
+      const float v = r >= 0 ? 1.f / (1.f + expf(-logits[(int64_t)r * q + c])) : 0.f;
+      out[s * q + c] = v;
+      any |= v != 0.f;
+    }
+    flag[s] = (uint8_t)any;
+  }
+  return 0;
+}
+
+int pho_ens_merge(float *anchor, const float *m, const int32_t *perm, int64_t u, int32_t q, int32_t i, ph_stream_t stream) {
+  (void)stream;
+  if (q < 1 || q > 128 || i < 1) return fail("ens_merge: bad shape");
+  const float fi = (float)i, den = fi + 1.f;
+  float *tmp = (float *)malloc(sizeof(float) * (size_t)q);
+  for (int64_t s = 0; s < u; ++s) {
+    for (int c = 0; c < q; ++c) {
+      volatile float t = anchor[s * q + c] * fi;      /* rounded product, then sum, then quotient (no fused multiply-add) */
+      volatile float w = t + m[s * q + perm[c]];
+      tmp[c] = w / den;
+    }
+    memcpy(anchor + s * q, tmp, sizeof(float) * (size_t)q);
+  }
+  free(tmp);
+  return 0;
+}
+
+int pho_ens_finish(const float *anchor, int64_t u, int32_t q, const int32_t *keep, int32_t qk, const float *sem, int32_t c,
+                   const int32_t *sel, float *out, uint8_t *flag, ph_stream_t stream) {
+  (void)stream;
+  if (q < 1 || q > 128 || qk < 0 || qk > q || c < 1) return fail("ens_finish: bad shape");
+  for (int64_t s = 0; s < u; ++s) {
+    const float *sr = sem + (int64_t)sel[s] * c;
+    int best = 0;
+    for (int k = 1; k < c; ++k)
+      if (sr[k] > sr[best]) best = k;                  /* first maximum */
+    const float nz = best != 0 ? 1.f : 0.f;
+    int any = 0;
+    for (int j = 0; j < qk; ++j) {
+      const float v = anchor[s * q + keep[j]] * nz;
+      out[s * qk + j] = v;
+      any |= v != 0.f;
+    }
+    flag[s] = (uint8_t)any;
+  }
+  return 0;
+}

@@ -353,3 +353,114 @@ extern "C" int ph_sem_ensemble(const ph_sem_ens_desc *desc, ph_stream_t stream) 
   PH_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- panoptic ensembling on the compacted union of occupied canonical sites (ensembler.py:20-131; graph/ensemble.py) ----
+// One wave64 per union site (a row of <= 128 query columns: lanes l and l + 64), grid-stride over the sites.  Each kernel
+// replaces a chain of elementwise / gather passes over [U, Q] tensors (~100 MB each at S10) by one pass.
+
+// out[u] = sigmoid(logits[rows[sel[u]]]) or zeros when the subnet has no voxel there; flag[u] = any non-zero entry
+__global__ void __launch_bounds__(256)
+    k_ens_resample(const float *__restrict__ logits, int q, const int32_t *__restrict__ rows, const int32_t *__restrict__ sel,
+                   int64_t u, float *__restrict__ out, uint8_t *__restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < u; s += nwaves) {
+    const int r = rows[sel[s]];
+    float v0 = 0.f, v1 = 0.f;
+    if (r >= 0) {
+      const float *x = logits + (int64_t)r * q;
+      if (lane < q) v0 = 1.f / (1.f + expf(-x[lane]));
+      if (lane + 64 < q) v1 = 1.f / (1.f + expf(-x[lane + 64]));
+    }
+    float *o = out + s * q;
+    if (lane < q) o[lane] = v0;
+    if (lane + 64 < q) o[lane + 64] = v1;
+    const unsigned long long any = __ballot(v0 != 0.f || v1 != 0.f);
+    if (lane == 0) flag[s] = any != 0ull ? 1 : 0;
+  }
+}
+
+// anchor[u][c] = (anchor[u][c] * i + m[u][perm[c]]) / (i + 1): the running mean of the matched query masks
+__global__ void __launch_bounds__(256)
+    k_ens_merge(float *__restrict__ anchor, const float *__restrict__ m, const int32_t *__restrict__ perm, int64_t u, int q,
+                float fi) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63;
+  const int p0 = lane < q ? perm[lane] : 0, p1 = lane + 64 < q ? perm[lane + 64] : 0;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const float den = fi + 1.f;
+  for (int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < u; s += nwaves) {
+    float *a = anchor + s * q;
+    const float *b = m + s * q;
+    if (lane < q) {
+      const float t = a[lane] * fi;
+      a[lane] = (t + b[p0]) / den;
+    }
+    if (lane + 64 < q) {
+      const float t = a[lane + 64] * fi;
+      a[lane + 64] = (t + b[p1]) / den;
+    }
+  }
+}
+
+// out[u][j] = anchor[u][keep[j]] * (argmax_c sem[sel[u]][c] != 0); flag[u] = any non-zero entry
+__global__ void __launch_bounds__(256)
+    k_ens_finish(const float *__restrict__ anchor, int q, const int32_t *__restrict__ keep, int qk, const float *__restrict__ sem,
+                 int c, const int32_t *__restrict__ sel, int64_t u, float *__restrict__ out, uint8_t *__restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int k0 = lane < qk ? keep[lane] : 0, k1 = lane + 64 < qk ? keep[lane + 64] : 0;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); s < u; s += nwaves) {
+    // class 0 wins the argmax iff no later class is strictly larger (first maximum, as torch.argmax on ties)
+    const float *sr = sem + (int64_t)sel[s] * c;
+    const float p0 = sr[0];
+    const bool larger = lane >= 1 && lane < c && sr[lane] > p0;
+    const float nz = __ballot(larger) != 0ull ? 1.f : 0.f;
+    const float *a = anchor + s * q;
+    float v0 = 0.f, v1 = 0.f;
+    if (lane < qk) v0 = a[k0] * nz;
+    if (lane + 64 < qk) v1 = a[k1] * nz;
+    float *o = out + s * qk;
+    if (lane < qk) o[lane] = v0;
+    if (lane + 64 < qk) o[lane + 64] = v1;
+    const unsigned long long any = __ballot(v0 != 0.f || v1 != 0.f);
+    if (lane == 0) flag[s] = any != 0ull ? 1 : 0;
+  }
+}
+
+static unsigned ens_grid(int64_t u) {
+  int64_t g = (u + 3) / 4;
+  if (g > 16384) g = 16384;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+extern "C" int ph_ens_resample(const float *logits, int64_t n, int32_t q, const int32_t *rows, const int32_t *sel, int64_t u,
+                               float *out, uint8_t *flag, ph_stream_t stream) {
+  PH_REQUIRE(q >= 1 && q <= 128 && n >= 0 && u >= 0, "ens_resample: bad shape");
+  if (u == 0) return 0;
+  PH_REQUIRE(logits && rows && sel && out && flag, "ens_resample: null buffer");
+  hipLaunchKernelGGL(k_ens_resample, dim3(ens_grid(u)), dim3(256), 0, ph_stream(stream), logits, q, rows, sel, u, out, flag);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ph_ens_merge(float *anchor, const float *m, const int32_t *perm, int64_t u, int32_t q, int32_t i,
+                            ph_stream_t stream) {
+  PH_REQUIRE(q >= 1 && q <= 128 && u >= 0 && i >= 1, "ens_merge: bad shape");
+  if (u == 0) return 0;
+  PH_REQUIRE(anchor && m && perm, "ens_merge: null buffer");
+  hipLaunchKernelGGL(k_ens_merge, dim3(ens_grid(u)), dim3(256), 0, ph_stream(stream), anchor, m, perm, u, q, (float)i);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ph_ens_finish(const float *anchor, int64_t u, int32_t q, const int32_t *keep, int32_t qk, const float *sem,
+                             int32_t c, const int32_t *sel, float *out, uint8_t *flag, ph_stream_t stream) {
+  PH_REQUIRE(q >= 1 && q <= 128 && qk >= 0 && qk <= q && c >= 1 && c <= 64 && u >= 0, "ens_finish: bad shape");
+  if (u == 0) return 0;
+  PH_REQUIRE(anchor && sem && sel && flag && (qk == 0 || (keep && out)), "ens_finish: null buffer");
+  hipLaunchKernelGGL(k_ens_finish, dim3(ens_grid(u)), dim3(256), 0, ph_stream(stream), anchor, q, keep, qk, sem, c, sel, u, out,
+                     flag);
+  PH_LAUNCH_CHECK();
+  return 0;
+}

@@ -159,7 +159,8 @@ class DecoderGenerativeSepConvV2(nn.Module):
         batched = {s: batch_sparse_tensor(v, pad_to[s]) for s, v in xs_infers.items()}
         sem_F, sem_C = batch_sparse_tensor(sem_logits_pruneds, pad_to[1])
         keep_pad = ((sem_F != 0).sum(-1) + (sem_C != 0).sum(-1)) != 0
-        panop = self.transformer_predictor(batched, (sem_F, sem_C), min_Cs, max_Cs, keep_pad, subnets=subnets)
+        panop = self.transformer_predictor(batched, (sem_F, sem_C), min_Cs, max_Cs, keep_pad, subnets=subnets,
+                                           sem_tensors=sem_logits_pruneds)
         return panop, sem_logits_pruneds
 
     def forward(self, x, features, global_min_coords, global_max_coords, min_Cs, max_Cs,

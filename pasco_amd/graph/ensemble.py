@@ -157,66 +157,69 @@ class Ensembler(torch.nn.Module):
 
     def ensemble_panop(self, panop_predictions, ensemble_sem_prob_denses, Ts, iou_threshold=0.2, cache: dict = None):
         """-> one dict per subnet + the ensemble: {"sem_probs", "voxel_probs" (SparseTensors on the
-        canonical grid), "query_probs"} (ensembler.py:20-131)."""
+        canonical grid), "query_probs"} (ensembler.py:20-131).
+        The [U, Q] passes run as three fused row kernels (ph_ens_resample / ph_ens_merge / ph_ens_finish): sigmoid +
+        resampling + "row is non-zero" flag; running mean of the matched masks; matched-IoU column filter + empty-class
+        zeroing + flag."""
         n_sub = len(panop_predictions)
         dev = panop_predictions[0]["query_logits"].device
         be = backend_for(dev)
         sites = self.sites(dev)
         cache = {} if cache is None else cache
-        rows_per_subnet, probs_per_subnet, query_probs = [], [], []
+        rows_per_subnet, query_probs = [], []
         occupied = None
         for i in range(n_sub):
             vl = panop_predictions[i]["voxel_logits"]
             rows = _lookup_rows(vl, self.projected(Ts[i], dev, cache))
             rows_per_subnet.append(rows)
-            probs_per_subnet.append(torch.sigmoid(vl.F))
             occupied = (rows >= 0) if occupied is None else (occupied | (rows >= 0))
             query_probs.append(F.softmax(panop_predictions[i]["query_logits"], dim=-1))
-        union_sites = be.mask_compact(occupied.contiguous())                # canonical site ids, lexicographic
+        union_sites = be.mask_compact(occupied.contiguous())                # canonical site ids (int32), lexicographic
         union_long = union_sites.long()
         site_coords = sites.index_select(0, union_long)                     # [U, 3]
-        masks = []                                                          # per subnet [U, Q] (0 where absent)
+        masks, flags = [], []                                               # per subnet [U, Q] (0 where absent), [U] uint8
         for i in range(n_sub):
-            r = rows_per_subnet[i].index_select(0, union_long)
-            masks.append(be.gather_rows(probs_per_subnet[i].contiguous(), r))
+            m, fl = be.ens_resample(panop_predictions[i]["voxel_logits"].F.contiguous(), rows_per_subnet[i].contiguous(),
+                                    union_sites)
+            masks.append(m)
+            flags.append(fl)
         anchor_q = query_probs[0].clone()
-        anchor_m = masks[0].clone()
+        anchor_m = masks[0].clone() if n_sub > 1 else masks[0]
         ious = []
         for i in range(1, n_sub):
             a_idx, b_idx, iou = self.match_queries(anchor_m, masks[i], iou_threshold)
             # the assignment of a square cost matrix lists every anchor query once, in order (a_idx = 0..Q-1)
             anchor_q = (anchor_q * i + query_probs[i][:, b_idx, :]) / (i + 1)
-            anchor_m = (anchor_m * i + masks[i][:, b_idx]) / (i + 1)
+            be.ens_merge(anchor_m, masks[i], b_idx.to(torch.int32).contiguous(), i)
             ious.append(iou)
+        Q = anchor_m.shape[1]
         if ious:
             keep = torch.stack(ious, dim=0).mean(0) > iou_threshold
-            anchor_m = anchor_m[:, keep]
+            keep_cols = keep.nonzero().reshape(-1)
             anchor_q = anchor_q[:, keep, :]
+        else:
+            keep_cols = torch.arange(Q, device=dev)
         # zero the ensemble where the ensembled semantic class is "empty"
         sem_rows = cache.get("sem_rows")
         if sem_rows is not None and (len(sem_rows) != len(ensemble_sem_prob_denses) or any(
                 r.data_ptr() != d.data_ptr() for r, d in zip(sem_rows, ensemble_sem_prob_denses))):
             sem_rows = None                      # denses did not come from this cache's ensemble_sem_compl
-        if sem_rows is not None:                 # rows of the same tensors, channels last: contiguous reads
-            ens_class = sem_rows[-1].index_select(0, union_long).argmax(dim=1)
-        else:
-            ens_class = ensemble_sem_prob_denses[-1].argmax(0).reshape(-1)[union_long]
-        anchor_m = anchor_m * (ens_class != 0).float()[:, None]
-        masks.append(anchor_m)
+        if sem_rows is None:                     # channels-last rows of the dense [C, X, Y, Z] tensors
+            sem_rows = [d.permute(1, 2, 3, 0).reshape(-1, d.shape[0]).contiguous() for d in ensemble_sem_prob_denses]
+        ens_m, ens_flag = be.ens_finish(anchor_m, keep_cols.to(torch.int32).contiguous(), sem_rows[-1].contiguous(), union_sites)
+        masks.append(ens_m)
+        flags.append(ens_flag)
         query_probs.append(anchor_q)
         out = []
         coords4 = torch.cat([torch.zeros((site_coords.shape[0], 1), dtype=torch.int32, device=dev), site_coords], dim=1)
         for i, m in enumerate(masks):
-            nz = be.mask_compact((m != 0).any(dim=1).contiguous()).long()     # ME.to_sparse keeps non-zero sites
-            c = coords4.index_select(0, nz)
+            nz32 = be.mask_compact(flags[i])                                  # ME.to_sparse keeps non-zero sites
+            c = be.gather_rows(coords4, nz32)
             mgr = ME.CoordinateManager(D=3, device=dev)
             key = mgr.insert_unique(c, 1)                                     # canonical sites are unique
-            voxel_prob = ME.SparseTensor(m.index_select(0, nz), coordinate_map_key=key, coordinate_manager=mgr)
-            if sem_rows is not None:
-                sem_f = sem_rows[i].index_select(0, union_long.index_select(0, nz))
-            else:
-                cl = c.long()
-                sem_f = ensemble_sem_prob_denses[i][:, cl[:, 1], cl[:, 2], cl[:, 3]].t().contiguous()
+            vf = be.gather_rows(m, nz32) if m.shape[1] > 0 else m.new_zeros((nz32.shape[0], 0))   # no query survived
+            voxel_prob = ME.SparseTensor(vf, coordinate_map_key=key, coordinate_manager=mgr)
+            sem_f = be.gather_rows(sem_rows[i], be.gather_rows(union_sites.reshape(-1, 1), nz32).reshape(-1))
             sem_prob = ME.SparseTensor(sem_f, coordinate_map_key=key, coordinate_manager=mgr)
             out.append({"sem_probs": sem_prob, "voxel_probs": voxel_prob, "query_probs": query_probs[i]})
         return out

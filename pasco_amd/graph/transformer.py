@@ -440,8 +440,11 @@ class TransformerPredictorV2(nn.Module):
         return bits, be.bits_or_reduce(bits)
 
     # -- forward ------------------------------------------------------------------------------------
-    def forward(self, xs, sem_logits, min_Cs, max_Cs, keep_pad, subnets=None):
+    def forward(self, xs, sem_logits, min_Cs, max_Cs, keep_pad, subnets=None, sem_tensors=None):
         """xs[scale] = (feats [B,N,C], coords [B,N,4]); returns one dict per subnet.
+        `sem_tensors` (optional): the per-subnet sparse tensors the padded batch rows were made of (same rows, same
+        order) - when every row of a subnet is kept its voxel logits reuse that tensor's coordinate map instead of
+        hashing the same coordinates again.
         `subnets` (optional list of subnet indices): the batch rows hold only those subnets' voxels and
         only their query sets run (subnet-parallel heads)."""
         sem_F, sem_C = sem_logits
@@ -557,7 +560,13 @@ class TransformerPredictorV2(nn.Module):
         panop_predictions = []
         for b in range(B):
             kept = keep_pad[b].nonzero().reshape(-1)          # one compaction per subnet, reused by every mask
-            first = ME.SparseTensor(predictions_mask[0][b].index_select(0, kept), voxel_coord[b].index_select(0, kept))
+            src = sem_tensors[b] if sem_tensors is not None else None
+            if src is not None and kept.shape[0] == src.F.shape[0] and src.F.shape[0] <= voxel_coord.shape[1]:
+                # kept = 0 .. n-1 (ascending, distinct, all below n): the rows ARE the source tensor's rows
+                first = ME.SparseTensor(predictions_mask[0][b].index_select(0, kept),
+                                        coordinate_map_key=src.coordinate_map_key, coordinate_manager=src.coordinate_manager)
+            else:
+                first = ME.SparseTensor(predictions_mask[0][b].index_select(0, kept), voxel_coord[b].index_select(0, kept))
             key, mgr = first.coordinate_map_key, first.coordinate_manager
             idx = first.unique_index        # None unless coordinates repeat
             rows = kept if idx is None else kept.index_select(0, idx.long())

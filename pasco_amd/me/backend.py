@@ -87,6 +87,9 @@ _SIGNATURES = {
     "bits_orpool": [_vp, _vp, _i32, _i64, _vp, _vp],
     "bits_or_reduce": [_vp, _i64, _i32, _vp, _vp],
     "attn_cross_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
+    "ens_resample": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp],
+    "ens_merge": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    "ens_finish": [_vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp],
     "attn_cross_split": [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
 }
 _RESTYPES = {"last_error": C.c_char_p, "workspace_bytes": _i64, "attn_workspace_bytes": _i64}
@@ -715,6 +718,49 @@ class CBackend:
                                          self.stream(q.device))
         self._check(rc, "attn_cross_split")
         return out
+
+
+    # ---- panoptic ensembling rows (include/pasco_hip.h ens_*) ----------------------------------------------------------
+    def ens_resample(self, logits: torch.Tensor, rows: torch.Tensor, sel: torch.Tensor):
+        """-> (probs [U, Q], flag uint8 [U]): sigmoid of the subnet's voxel logits resampled on the union sites `sel`
+        (int32 canonical site ids) through `rows` (int32 [n_sites], -1 = no voxel -> zero row)."""
+        self._chk(logits, torch.float32, "logits")
+        self._chk(rows, torch.int32, "rows")
+        self._chk(sel, torch.int32, "sel")
+        n, q = logits.shape
+        u = sel.shape[0]
+        out = torch.empty((u, q), dtype=torch.float32, device=logits.device)
+        flag = torch.empty((u,), dtype=torch.uint8, device=logits.device)
+        rc = self.fn["ens_resample"](_ptr(logits), n, q, _ptr(rows), _ptr(sel), u, _ptr(out), _ptr(flag), self.stream(logits.device))
+        self._check(rc, "ens_resample")
+        return out, flag
+
+    def ens_merge(self, anchor: torch.Tensor, m: torch.Tensor, perm: torch.Tensor, i: int) -> torch.Tensor:
+        """anchor <- (anchor * i + m[:, perm]) / (i + 1), in place."""
+        self._chk(anchor, torch.float32, "anchor")
+        self._chk(m, torch.float32, "m")
+        self._chk(perm, torch.int32, "perm")
+        u, q = anchor.shape
+        assert m.shape == anchor.shape and perm.numel() == q
+        rc = self.fn["ens_merge"](_ptr(anchor), _ptr(m), _ptr(perm), u, q, int(i), self.stream(anchor.device))
+        self._check(rc, "ens_merge")
+        return anchor
+
+    def ens_finish(self, anchor: torch.Tensor, keep: torch.Tensor, sem: torch.Tensor, sel: torch.Tensor):
+        """-> (out [U, len(keep)], flag uint8 [U]): anchor's kept query columns, zeroed where the ensembled semantic class
+        (argmax of sem[sel]) is 0."""
+        self._chk(anchor, torch.float32, "anchor")
+        self._chk(keep, torch.int32, "keep")
+        self._chk(sem, torch.float32, "sem")
+        self._chk(sel, torch.int32, "sel")
+        u, q = anchor.shape
+        qk = keep.numel()
+        out = torch.empty((u, qk), dtype=torch.float32, device=anchor.device)
+        flag = torch.empty((u,), dtype=torch.uint8, device=anchor.device)
+        rc = self.fn["ens_finish"](_ptr(anchor), u, q, _ptr(keep), qk, _ptr(sem), sem.shape[1], _ptr(sel), _ptr(out), _ptr(flag),
+                                   self.stream(anchor.device))
+        self._check(rc, "ens_finish")
+        return out, flag
 
 
 # ---- registry -----------------------------------------------------------------------------------

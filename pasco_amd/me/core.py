@@ -271,6 +271,8 @@ class SparseTensor:
             assert coordinate_manager is not None, "coordinate_map_key needs its coordinate_manager"
             n = coordinate_manager.size(coordinate_map_key)
             assert features.shape[0] == n, f"features have {features.shape[0]} rows, map has {n}"
+            self.unique_index = None
+            self.inverse_mapping = None
         self._F = features
         self._manager = coordinate_manager
         self.coordinate_map_key = coordinate_map_key

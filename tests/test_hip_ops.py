@@ -282,3 +282,46 @@ def test_sem_ensemble_matches_oracle_and_torch(hip, oracle, c, m):
         assert torch.allclose(o_out[i], ref[i], rtol=1e-5, atol=1e-6)
         assert torch.allclose(h_conf[i].cpu(), ref[i].max(dim=1)[0], rtol=1e-5, atol=1e-6)
         assert torch.allclose(o_conf[i], ref[i].max(dim=1)[0], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("q", [100, 128, 5, 64])
+def test_ens_row_kernels_match_oracle_and_torch(hip, oracle, q):
+    """ph_ens_resample / ph_ens_merge / ph_ens_finish against the oracle and the torch formulation they replace
+    (Ensembler.ensemble_panop; reference ensembler.py:44-62, 86-98, 100-118)."""
+    g = torch.Generator().manual_seed(900 + q)
+    n, n_sites, c = 7001, 60000, 20
+    logits = torch.randn(n, q, generator=g) * 4
+    logits[5] = -200.0                                              # sigmoid underflows to exactly 0: flag must be 0
+    rows = torch.randint(-n, n, (n_sites,), generator=g).clamp(min=-1).int()
+    sel = torch.randperm(n_sites, generator=g)[:20011].sort()[0].int()
+    rows[sel[7].item()] = 5
+    # resample
+    o_out, o_flag = oracle.ens_resample(logits, rows, sel)
+    h_out, h_flag = hip.ens_resample(logits.cuda(), rows.cuda(), sel.cuda())
+    r = rows[sel.long()]
+    ref = torch.where((r >= 0)[:, None], torch.sigmoid(logits[r.clamp(min=0).long()]), torch.zeros(1))
+    assert torch.allclose(o_out, ref, rtol=1e-6, atol=1e-7) and torch.allclose(h_out.cpu(), o_out, rtol=2e-6, atol=1e-7)
+    assert torch.equal(o_flag.bool(), (o_out != 0).any(1)) and torch.equal(h_flag.cpu().bool(), (h_out.cpu() != 0).any(1))
+    assert not bool(o_flag[7]) and not bool(h_flag[7])
+    # merge: bit-exact (three rounded fp32 operations)
+    anchor = torch.rand(sel.shape[0], q, generator=g)
+    m = torch.rand(sel.shape[0], q, generator=g)
+    perm = torch.randperm(q, generator=g).int()
+    for i in (1, 2, 5):
+        ref_m = (anchor * i + m[:, perm.long()]) / (i + 1)
+        o = oracle.ens_merge(anchor.clone(), m, perm, i)
+        h = hip.ens_merge(anchor.clone().cuda(), m.cuda(), perm.cuda(), i).cpu()
+        assert torch.equal(o, ref_m) and torch.equal(h, ref_m)
+    # finish
+    sem = torch.softmax(torch.randn(n_sites, c, generator=g), dim=-1)
+    sem[sel[3].item()] = 0.05                                       # a tie: the first maximum (class 0) wins
+    keep = torch.randperm(q, generator=g)[: max(1, q // 3)].sort()[0].int()
+    nzc = (sem[sel.long()].argmax(dim=1) != 0).float()
+    assert nzc[3] == 0
+    ref_f = anchor[:, keep.long()] * nzc[:, None]
+    o_out, o_flag = oracle.ens_finish(anchor, keep, sem, sel)
+    h_out, h_flag = hip.ens_finish(anchor.cuda(), keep.cuda(), sem.cuda(), sel.cuda())
+    assert torch.equal(o_out, ref_f) and torch.equal(h_out.cpu(), ref_f)
+    assert torch.equal(o_flag.bool(), (ref_f != 0).any(1)) and torch.equal(h_flag.cpu().bool(), (ref_f != 0).any(1))
+    e_out, e_flag = hip.ens_finish(anchor.cuda(), keep[:0].cuda(), sem.cuda(), sel.cuda())     # no query kept
+    assert e_out.shape == (sel.shape[0], 0) and not bool(e_flag.any())
