@@ -310,7 +310,7 @@ def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--mode", choices=["scenes", "subnet-heads"], default="scenes")
     ap.add_argument("--n-infers", type=int, default=None, help="MIMO subnets (default 3; 8 with --mode subnet-heads)")
