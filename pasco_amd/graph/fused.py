@@ -264,10 +264,12 @@ def prepare_batched_weights(w: torch.Tensor):
 
 
 def batched_rows_matmul(x: Optional[torch.Tensor], w: Optional[torch.Tensor], x_split: torch.Tensor, shape=None,
-                        prepared=None) -> torch.Tensor:
+                        prepared=None, bias=None, axis=None) -> torch.Tensor:
     """out[b] = x[b] @ w[b].T for tall x [B, P, D] and per-batch w [B, Q, D] (the mask logits of the query heads),
     on the split-precision kernel with `x_split` = split_rows(x) prepared once.  `prepared` =
-    prepare_batched_weights(w) when the caller already has it."""
+    prepare_batched_weights(w) when the caller already has it.  `bias` [B, Q] and `axis` = (tables [B, 3, T, Q],
+    coords int32 [B, P, 4], lo) are added after the product (the absorbed form of the mask heads: per-batch bias and
+    per-axis table rows)."""
     from ..me.backend import backend_for
     dev = x_split.device
     be = backend_for(dev)
@@ -279,7 +281,8 @@ def batched_rows_matmul(x: Optional[torch.Tensor], w: Optional[torch.Tensor], x_
     ws = w_split.reshape(B, Q, -1)
     for b in range(B):
         be.conv_fwd(None, None, None, P, xshape=(P, D), wshape=(1, D, Q), split=(ws[b], 1.0), in_split=xs[b],
-                    epi_scale=unscale, out=out[b])
+                    epi_scale=unscale, out=out[b], epi2_shift=None if bias is None else bias[b],
+                    axis=None if axis is None else (axis[0][b], axis[1][b], axis[2]))
     return out
 
 

@@ -303,16 +303,40 @@ class TransformerPredictorV2(nn.Module):
         self.mask_feat_proj = nn.Linear(mask_dim, hidden_dim)
 
     # -- heads --------------------------------------------------------------------------------------
-    def heads_query_side(self, output, want_operand: bool):
+    def heads_query_side(self, output, want_operand):
         """The part of `pred_heads` that only touches the [B, Q, D] queries: class logits, mask embedding and -
-        for the split kernel - the mask embedding in operand form."""
+        for the split kernel - the mask embedding in operand form.
+        want_operand == 2: the ABSORBED form.  The voxel features of the mask heads are `x W_p^T + b_p + pos` and are
+        read only through `voxel_feat . e_q`, so
+            mask[n, q] = x[n] . (W_p^T e_q) + b_p . e_q + tab[x_n] . e_q[block 0] + tab[y_n] . e_q[block 1] + tab[z_n] . e_q[block 2]
+        i.e. a C -> Q product on the level's own features with a per-subnet bias and three table rows per voxel
+        (ph_conv_desc.axis_table): the [N, D] voxel features are never formed.  Returned: (w_c operand, unscale,
+        bias [B, Q], tables [B, 3, T, Q])."""
         d = self.decoder_norm(output)
         outputs_class = self.class_embed(d)
         mask_embed = self.mask_embed(d)                                   # [B,Q,D]
+        if want_operand == 2:
+            lin = self.mask_feat_proj
+            B, Q, D = mask_embed.shape
+            wc = torch.matmul(mask_embed, lin.weight)                      # [B, Q, C]
+            bc = torch.matmul(mask_embed, lin.bias)                        # [B, Q]
+            tab = self.pe_layer.table(mask_embed.device)                   # [T, f]
+            f = tab.shape[1]
+            tq = torch.matmul(tab, mask_embed.view(B, Q, 3, f).permute(0, 2, 3, 1))      # [B, 3, T, Q]
+            return outputs_class, mask_embed, prepare_batched_weights(wc) + (bc.contiguous(), tq.contiguous())
         prepared = prepare_batched_weights(mask_embed) if want_operand else None
         return outputs_class, mask_embed, prepared
 
-    def pred_heads(self, output, mask_features, mask_features_split=None, shape=None, query_side=None):
+    def pred_heads(self, output, mask_features, mask_features_split=None, shape=None, query_side=None, absorbed=None):
+        """`absorbed` = dict(x_split, coords [B, P, 4], shape (B, P, C)): the heads read the level's features directly
+        (heads_query_side with want_operand == 2)."""
+        if absorbed is not None:
+            outputs_class, _, prep = query_side if query_side is not None else self.heads_query_side(output, 2)
+            w_split, unscale, bc, tq = prep
+            outputs_mask = batched_rows_matmul(None, None, absorbed["x_split"], shape=absorbed["shape"],
+                                               prepared=(w_split, unscale), bias=bc,
+                                               axis=(tq, absorbed["coords"], self.pe_layer.TABLE_LO))
+            return outputs_class, outputs_mask
         outputs_class, mask_embed, prepared = query_side if query_side is not None else \
             self.heads_query_side(output, mask_features_split is not None)
         if mask_features_split is not None:
@@ -486,7 +510,15 @@ class TransformerPredictorV2(nn.Module):
         heads_split = self.num_queries % 4 == 0
         c1 = src_Cs[-1].reshape(-1, 4)
         tables_ok = use_tables and c1.dtype == torch.int32 and x1.shape[0] * P >= fused_mod.MIN_ROWS_LINEAR
-        if tables_ok:
+        # absorbed mask heads (heads_query_side): no [N, D] voxel features at all
+        absorbed = None
+        if tables_ok and heads_split and x1.shape[-1] % 8 == 0 and os.environ.get("PASCO_HEAD_ABSORB", "1") != "0":
+            x1_split = split_rows_2d(x1.reshape(-1, x1.shape[-1]))
+            if x1_split is not None:
+                absorbed = dict(x_split=x1_split, coords=c1.contiguous().view(B, P, 4), shape=(B, P, x1.shape[-1]))
+        if absorbed is not None:
+            voxel_feat, vf_split = None, None
+        elif tables_ok:
             voxel_feat, vf_split = linear_rows(x1.reshape(-1, x1.shape[-1]), self.mask_feat_proj.weight,
                                                self.mask_feat_proj.bias, self.mask_feat_proj, "w",
                                                axis=(self.pe_layer.block_table(dev), c1.contiguous(), self.pe_layer.TABLE_LO),
@@ -503,8 +535,9 @@ class TransformerPredictorV2(nn.Module):
         vf_shape = (B, P, D)
         predictions_class, predictions_mask = [], []
         mask_cache = {}
-        output, *qs = self.query_step(-1, output.contiguous(), query_embed, vf_split is not None)
-        oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape, query_side=qs)
+        head_mode = 2 if absorbed is not None else (vf_split is not None)
+        output, *qs = self.query_step(-1, output.contiguous(), query_embed, head_mode)
+        oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape, query_side=qs, absorbed=absorbed)
         predictions_class.append(oc)
         predictions_mask.append(om)
         for i in range(self.num_layers):
@@ -523,7 +556,8 @@ class TransformerPredictorV2(nn.Module):
                 # composed into one launch each (CrossAttentionLayer.composed_kv)
                 cm = ca.composed_kv(lin, tab)
                 x2 = srcs[i].reshape(-1, srcs[i].shape[-1])
-                x_split = split_rows_2d(x2)
+                # the finest level's features are the mask heads' operand too: split once
+                x_split = absorbed["x_split"] if (absorbed is not None and srcs[i] is x1) else split_rows_2d(x2)
                 ci = ci.contiguous()
                 # ... written only as split f16 operands, which the attention kernel streams (ph_attn_cross_split)
                 kk, k_op = linear_rows(x2, cm["wk"], cm["bk"], ca, "ck", in_split=x_split, emit=True, want_out=False,
@@ -553,8 +587,8 @@ class TransformerPredictorV2(nn.Module):
                 attn_mask = ~(allow != 0).permute(0, 2, 1)
                 attn_mask = attn_mask & ~attn_mask.all(dim=-1, keepdim=True)   # all-masked -> unmasked
                 output = ca(output, src_F, attn_mask=attn_mask, pos=None, query_pos=query_embed)
-            output, *qs = self.query_step(i, output.contiguous(), query_embed, vf_split is not None)
-            oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape, query_side=qs)
+            output, *qs = self.query_step(i, output.contiguous(), query_embed, head_mode)
+            oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape, query_side=qs, absorbed=absorbed)
             predictions_class.append(oc)
             predictions_mask.append(om)
         panop_predictions = []
