@@ -101,3 +101,29 @@ def test_s10_mimo3_split_path_vs_exact_fp32(hip, s10_net):
         assert torch.equal(a["voxel_logits"].C, b["voxel_logits"].C)
         close(a["voxel_logits"].F, b["voxel_logits"].F, f"voxel logits subnet {i}")
         close(a["query_logits"], b["query_logits"], f"query logits subnet {i}")
+
+
+@pytest.mark.parametrize("switch", ["PASCO_HEAD_ABSORB", "PASCO_ATTN_SPLIT", "PASCO_PE_TABLE"])
+def test_s10_transformer_restructurings_vs_plain_forms(hip, s10_net, switch, monkeypatch):
+    """The algebraic restructurings of the mask transformer at the benchmark size, each against the form it replaces
+    (the switch set to 0): mask heads absorbed into the level's features vs voxel features formed and multiplied
+    (transformer_predictor_v2.py:143,150,202-218); attention on split K / V operands vs fp32 K / V; position encoding as
+    table rows vs materialised."""
+    net, scene, teacher = s10_net
+
+    def run():
+        with torch.no_grad():
+            x = net.prepare_input(scene.in_feats, scene.in_coords)
+            return net(x, scene.global_min_Cs, scene.global_max_Cs, scene.min_Cs, scene.max_Cs, keep_override=teacher)
+
+    got = run()
+    monkeypatch.setenv(switch, "0")
+    exp = run()
+    monkeypatch.delenv(switch)
+    for i, (a, b) in enumerate(zip(got["panop_predictions"], exp["panop_predictions"])):
+        assert torch.equal(a["voxel_logits"].C, b["voxel_logits"].C)
+        for key in ("voxel_logits", "query_logits"):
+            x, y = (a[key].F, b[key].F) if key == "voxel_logits" else (a[key], b[key])
+            scale = float(y.abs().mean())
+            err = float((x - y).abs().max())
+            assert err <= 2e-4 * scale, f"{switch}: {key} subnet {i}: max error {err:.3e} vs mean |y| {scale:.3e}"
