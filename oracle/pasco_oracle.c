@@ -259,7 +259,7 @@ int pho_split_rows(const float *in, int64_t n, int32_t c, const float *pro_scale
                    int32_t pro_act, float slope, int32_t exp2, void *out_split, int32_t *status, ph_stream_t stream) {
   (void)stream;
   const float pow2 = ldexpf(1.f, exp2);
-  if (n < 0 || c <= 0) return fail("split_rows: bad shape");
+  if (n < 0 || c <= 0 || c % 8 != 0) return fail("split_rows: needs c % 8 == 0");
   if (n == 0) return 0;
   if (!in || !out_split) return fail("split_rows: null buffer");
   const int cpad = (c + 31) / 32 * 32;

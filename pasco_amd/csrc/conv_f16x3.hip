@@ -444,22 +444,15 @@ __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ in
   const int64_t row = t / segs;
   const int c0 = (int)(t - row * segs) * 8;
   f16x8 hi = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (c0 < c) {   // c % 8 == 0: the segment is entirely inside or entirely padding; else its tail is padding
-    float x[8];
-    if ((c & 7) == 0) {
-      const float4 v0 = *reinterpret_cast<const float4 *>(in + row * c + c0);
-      const float4 v1 = *reinterpret_cast<const float4 *>(in + row * c + c0 + 4);
-      x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
-    } else {        // odd channel counts (283-channel point features, the +3 position channels of `resize`): scalar reads
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = c0 + j < c ? in[row * c + c0 + j] : 0.f;
-    }
+  if (c0 < c) {   // c % 8 == 0: the segment is entirely inside or entirely padding
+    const float4 v0 = *reinterpret_cast<const float4 *>(in + row * c + c0);
+    const float4 v1 = *reinterpret_cast<const float4 *>(in + row * c + c0 + 4);
+    float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = x[j];
-      const bool inside = c0 + j < c;
-      if (has_pro && inside) {   // separate multiply and add (no FMA contraction): bit-identical to the C restatement in oracle/
+      if (has_pro) {   // separate multiply and add (no FMA contraction): bit-identical to the C restatement in oracle/
 #pragma clang fp contract(off)
         const float m = v * (ps ? ps[c0 + j] : 1.f);
         v = h_act(m + (pb ? pb[c0 + j] : 0.f), neg);
@@ -480,11 +473,11 @@ __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ in
 extern "C" int ph_split_rows(const float *in, int64_t n, int32_t c, const float *pro_scale, const float *pro_shift,
                              int32_t pro_act, float slope, int32_t exp2, void *out_split, int32_t *status,
                              ph_stream_t stream) {
-  PH_REQUIRE(n >= 0 && c > 0, "split_rows: bad shape (c=%d)", c);
+  PH_REQUIRE(n >= 0 && c > 0 && c % 8 == 0, "split_rows: needs c %% 8 == 0 (c=%d)", c);
   PH_REQUIRE(exp2 >= -16 && exp2 <= 16, "split_rows: exp2 out of range (%d)", exp2);
   if (n == 0) return 0;
   PH_REQUIRE(in && out_split, "split_rows: null buffer");
-  PH_REQUIRE((((uintptr_t)out_split) & 15) == 0 && (((uintptr_t)in) & (c % 8 == 0 ? 15 : 3)) == 0, "split_rows: alignment");
+  PH_REQUIRE((((uintptr_t)in | (uintptr_t)out_split) & 15) == 0, "split_rows: 16-byte alignment");
   const int cpad = (c + 31) / 32 * 32;
   const int64_t total = n * (cpad / 8);
   const float neg = pro_act == PH_ACT_RELU ? 0.f : (pro_act == PH_ACT_LEAKY ? slope : 1.f);
@@ -628,8 +621,7 @@ static const ConvHKnobs &convh_knobs() {
 // called from ph_conv_fwd (conv.hip) when desc->mma_mode is 1 or 2
 int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   const bool pre = d->mma_mode == 2;
-  // mode 2 reads its operands in 32-channel groups (zero padded by ph_split_rows): any cin; mode 1 splits float4 runs
-  PH_REQUIRE((pre || d->cin % 8 == 0) && d->cout % 4 == 0, "conv_fwd(f16x3): needs cin %% 8 == 0 (mode 1) and cout %% 4 == 0");
+  PH_REQUIRE(d->cin % 8 == 0 && d->cout % 4 == 0, "conv_fwd(f16x3): needs cin %% 8 == 0 and cout %% 4 == 0");
   if (pre) {
     PH_REQUIRE(d->in_split && d->w_split, "conv_fwd(f16x3, mode 2): pre-split operands missing");
     PH_REQUIRE((((uintptr_t)d->in_split | (uintptr_t)d->w_split) & 15) == 0, "conv_fwd(f16x3): 16-byte alignment");

@@ -135,7 +135,7 @@ def split_input(x: SparseTensor, be, ps, pb, pro_act, slope):
 def split_rows_2d(x2d: torch.Tensor):
     """Pre-split operand of a tall [N, cin] matrix for several `linear_rows` calls on it (None when the split
     path does not apply)."""
-    if not (_FUSION and _kernel_device(x2d.device) and _CONV_PRECISION == "f16x3" and _PRESPLIT):
+    if not (_FUSION and _kernel_device(x2d.device) and _CONV_PRECISION == "f16x3" and _PRESPLIT and x2d.shape[1] % 8 == 0):
         return None
     from ..me.backend import backend_for
     return backend_for(x2d.device).split_rows(x2d.contiguous())
@@ -162,7 +162,7 @@ def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_o
     if _FUSION and _kernel_device(dev) and n >= min_rows and _CONV_PRECISION == "f16x3":
         from ..me.backend import backend_for
         be = backend_for(dev)
-        if not be.split_supported(cin, cout, _PRESPLIT):
+        if not be.split_supported(cin, cout):
             be = None
     if be is None:
         assert x2d is not None, "linear_rows: a pre-split operand needs the split path"
@@ -229,7 +229,7 @@ def linear_bn_act(x2d: Optional[torch.Tensor], lin: nn.Linear, *, pro_bn=None, e
     hit = lin.__dict__.get("_ph_lin_w")
     if hit is None or hit[0] != ver:
         wt = w.detach().t().contiguous()                          # [cin, cout]
-        split = _split_of(wt, be) if (_CONV_PRECISION == "f16x3" and be.split_supported(cin, cout, _PRESPLIT)) else None
+        split = _split_of(wt, be) if (_CONV_PRECISION == "f16x3" and be.split_supported(cin, cout)) else None
         hit = (ver, wt, split, lin.bias.detach().contiguous() if lin.bias is not None else None)
         lin.__dict__["_ph_lin_w"] = hit
     _, wt, split, b = hit
@@ -360,7 +360,7 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     else:
         x_rows = x.F if x.F.is_contiguous() else x.F.contiguous()
         xshape = None
-        if _CONV_PRECISION == "f16x3" and be.split_supported(mod.in_channels, mod.out_channels, _PRESPLIT):
+        if _CONV_PRECISION == "f16x3" and be.split_supported(mod.in_channels, mod.out_channels):
             split = split_weight(mod, be)
             if _PRESPLIT and n_out > 0:
                 in_split = split_input(x, be, ps, pb, pro_act, slope)

@@ -459,6 +459,8 @@ class CBackend:
         exp2 = SPLIT_ACT_EXP2 if exp2 is None else int(exp2)
         self._chk(x, torch.float32, "in")
         n, c = x.shape
+        if c % 8 != 0:
+            raise ValueError("split_rows: needs c % 8 == 0")
         cpad = (c + 31) // 32 * 32
         if out is None:
             out = torch.empty((n, cpad // 32, 2, 32), dtype=torch.float16, device=x.device)
@@ -490,10 +492,8 @@ class CBackend:
     def split_capable(self) -> bool:
         return self.device_type == "cuda" or self.checker_split
 
-    def split_supported(self, cin: int, cout: int, presplit: bool = False) -> bool:
-        """Shapes the split-precision kernels serve: cout % 4 == 0 and, unless both operands are pre-split in zero-padded
-        32-channel groups (`presplit`, mma_mode 2), cin % 8 == 0."""
-        return self.split_capable() and (presplit or cin % 8 == 0) and cout % 4 == 0
+    def split_supported(self, cin: int, cout: int) -> bool:
+        return self.split_capable() and cin % 8 == 0 and cout % 4 == 0
 
     def maxpool_fwd(self, x: torch.Tensor, nbr: torch.Tensor) -> torch.Tensor:
         self._chk(x, torch.float32, "in")

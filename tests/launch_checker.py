@@ -172,7 +172,6 @@ class LaunchChecker:
         # accumulation order are what must agree): same x, weights and map through both kernels
         shape_key = key + (kvol, cin, cout)
         if (fp32_x and weight is not None and cfg["mma_mode"] == 2 and cfg["ksplit"] == 1 and cfg["kernel"] != 5
-                and cin % 8 == 0                             # mode 1 splits float4 runs: odd channel counts are mode 2 only
                 and shape_key not in self.mode1_done):       # kernel 5 = window / gather pair: other summation order
             self.mode1_done.add(shape_key)
             p2 = self.inner(x, weight, nbr, n_out, split=split)
