@@ -25,12 +25,13 @@
 
 constexpr int DMA_KMAX = 32;   // kernel offsets one workgroup walks (its slice of the split over the offsets)
 
-// Development hook (tools/dma_ablate.py; results are WRONG with any bit set): 1 = skip the MFMAs, 2 = every gathered
-// row reads the zero line (no gather misses), 4 = every weight row reads row 0 of its slab, 8 = skip the fragment reads
+// Development hook: bit 8 of the mask selects the 256-row / 8-wave tiles (measured no faster: one workgroup per CU convoys).
+// The phase-ablation bits of round 2 (skip MFMAs / gathers / fragment reads; profiles/r2c - r2e) are gone from the kernel:
+// their runtime branches cost ~3 % in the loop.
 static int g_dma_ablate = 0;
-static int g_dma_tall = 0;     // 256-row / 8-wave tiles: measured no faster (one workgroup per CU convoys); kept for experiments
+static int g_dma_tall = 0;
 int ph_dma_ablate_bits() { return g_dma_ablate; }
-extern "C" void ph_conv_dma_set_ablate(int mask) { g_dma_ablate = mask & 0xFF; g_dma_tall = (mask & 0x100) ? 1 : 0; }
+extern "C" void ph_conv_dma_set_ablate(int mask) { g_dma_ablate = 0; g_dma_tall = (mask & 0x100) ? 1 : 0; }
 
 // One workgroup = WAVES (4 or 8) waves as WM x WN, tile BM = WM*TM*32 rows (128 / 256) x BN = WN*TN*32 channels,
 // 32 input channels per stage.  Everything that crosses the vector-memory path (gathered rows AND the weight tile of
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
         const int ix = idx[p];
         uint64_t v = in_base + (uint64_t)(uint32_t)(ix < 0 ? 0 : ix) * rsb + coff;
         asm volatile("" : "+v"(v));            // materialise before the select: a select, not a branch per row
-        src.a[p] = (ix >= 0 && !(a.ablate & 2)) ? v : zero_src;
+        src.a[p] = ix >= 0 ? v : zero_src;
       }
       src.w = w_base + (uint64_t)((int64_t)(k_begin + k) * wslab) + coff;
     };
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
 #pragma unroll
       for (int q = 0; q < B_PASSES; ++q) {
         char *dst = abuf + A_BYTES + (q * RPP + wave * 8) * 128;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(src.w + ((a.ablate & 4) ? 0u : boff[q])),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(src.w + boff[q]),
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
       }
     };
@@ -241,22 +242,22 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
       // BEFORE the matrix work of stage s so that it flies underneath it
       DMA_WAIT_STAGE();
       prep(s + 3, ix, src);
-      if (!(a.ablate & 8)) readfrag(1, f1);
+      readfrag(1, f1);
       DMA_READS_DONE();
       fire(src, 1);
       ix = load_idx(s + 4);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(a.ablate & 1)) mfma(f0);
+      mfma(f0);
       __builtin_amdgcn_sched_barrier(0);
       // stage s + 1 from f1; fragments of stage s + 2 from buffer 0; DMA of stage s + 4 into buffer 0
       DMA_WAIT_STAGE();
       prep(s + 4, ix, src);
-      if (!(a.ablate & 8)) readfrag(0, f0);
+      readfrag(0, f0);
       DMA_READS_DONE();
       fire(src, 0);
       ix = load_idx(s + 5);
       __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < nstages && !(a.ablate & 1)) mfma(f1);
+      if (s + 1 < nstages) mfma(f1);
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail loads: nothing may land after the epilogue starts

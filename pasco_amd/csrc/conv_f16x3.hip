@@ -595,6 +595,7 @@ struct ConvHKnobs {
   bool dma_all = false;
   bool win_on = true;      // PASCO_CONV_WIN=0: no LDS-window kernel
   bool win_wide = false;   // PASCO_CONV_WIN=2: also on 128-wide tiles
+  bool win256 = true;      // PASCO_CONV_WIN256=0: no 256-wide window workgroups
   bool dma_on = true;      // PASCO_CONV_DMA=0: keep every launch on the register-staged k_conv_h2 (A/B comparisons)
   ConvHKnobs() {
     if (const char *e = getenv("PASCO_CONV_DMA")) {
@@ -606,6 +607,7 @@ struct ConvHKnobs {
       win_on = atoi(e) != 0;
       win_wide = atoi(e) == 2;
     }
+    if (const char *e = getenv("PASCO_CONV_WIN256")) win256 = atoi(e) != 0;
     if (const char *e = getenv("PASCO_CONVH_CFG")) has_cfg = sscanf(e, "%d,%d", &cfg_bm, &cfg_kc) >= 1;
     if (const char *e = getenv("PASCO_CONVH_KSPLIT")) {
       has_ksplit = true;
@@ -750,13 +752,17 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   // Measured (profiles/README.md, round 2): 64-wide tiles 638 -> 540 us on the 683 k-row map (two workgroups per CU);
   // 128-wide tiles lose to the gather kernel (one workgroup per CU: 668 vs 567 us) and stay there unless
   // PASCO_CONV_WIN=2.
-  if (pre && knobs.win_on && !env && d->kvol == 27 && (bn == 64 || (bn == 128 && (knobs.win_wide || (ph_win_force_bits() & 0x100)))) &&
+  // 256 output channels: ONE 128 x 256 window workgroup per row tile (8 waves of 64 x 64): window and weight bytes per
+  // MFMA are 0.3x of the gather kernel's (PASCO_CONV_WIN256=0 disables)
+  const bool win256 = bn == 128 && d->cout == 256 && knobs.win256;
+  if (pre && knobs.win_on && !env && d->kvol == 27 &&
+      (bn == 64 || win256 || (bn == 128 && (knobs.win_wide || (ph_win_force_bits() & 0x100)))) &&
       a.ksplit == 1 &&
       d->win_rows && d->win_cnt && d->win_slots && d->win_stats) {
     a.win_stats = d->win_stats;
     a.win_which = (bn == 64 ? 0 : 1) | ph_win_force_bits();
     a.win_gather = 0;
-    if (int rc = ph_conv_win_launch(a, bn, st)) return rc;
+    if (int rc = ph_conv_win_launch(a, win256 ? 256 : bn, st)) return rc;
     a.win_gather = 1;
     win_pair = true;
     if (bm != 128) bm = 128;   // pairs are only formed on big maps: the gather side keeps its 128-row tile

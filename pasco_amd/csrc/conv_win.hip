@@ -283,18 +283,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_win(ConvArgsH a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[ks][j], f.ah[ks][i], acc[i][j], 0, 0, 0);
         }
   };
-#define WIN_WAIT_STAGE()                                                  \
-  do {                                                                    \
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                      \
-    __builtin_amdgcn_s_barrier();                                         \
-  } while (0)
-#define WIN_READS_DONE()                                  \
-  do {                                                    \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
-    __builtin_amdgcn_s_barrier();                         \
-  } while (0)
-  static_assert(L == 2, "vmcnt immediate");
-
   Frag f0, f1;
   for (int pass = 0; pass < npass; ++pass) {
     const int base = pass * WMAX;
@@ -362,8 +350,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_win(ConvArgsH a) {
       __builtin_amdgcn_s_barrier();
     }
   }
-#undef WIN_WAIT_STAGE
-#undef WIN_READS_DONE
 
   h2_store_tile<TM, TN, EMIT>(a, acc, m0, n0, wm, wn, h, l31);
 }
@@ -385,7 +371,7 @@ static int launch_win(const ConvArgsH &a, hipStream_t st) {
   return 0;
 }
 
-// Launches the window kernel (it returns at once on maps the predicate hands to the gather kernel).  bn: 64 or 128.
+// Launches the window kernel (it returns at once on maps the predicate hands to the gather kernel).  bn: 64, 128 or 256.
 int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st) {
   ConvArgsH b = a;
   b.ksplit = 1;
@@ -401,5 +387,7 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st) {
     return launch_win<4, 4, 1, 1, 2, WIN_MAX_64>(b, st);
   }
   b.win_which = 1 | ph_win_force_bits();
+  if (bn == 256)   // all 256 output channels in one workgroup: the window is DMA'd once per chunk for the whole layer width
+    return launch_win<8, 2, 4, 2, 2, WIN_MAX_128>(b, st);
   return launch_win<8, 2, 4, 2, 1, WIN_MAX_128>(b, st);
 }

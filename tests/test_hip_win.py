@@ -107,7 +107,7 @@ def test_window_conv_equals_gather_conv(hip, cin, cout):
     hip.check_status(x.device)
 
 
-@pytest.mark.parametrize("cin,cout,n", [(64, 64, None), (128, 128, None), (64, 64, 129)])
+@pytest.mark.parametrize("cin,cout,n", [(64, 64, None), (128, 128, None), (64, 64, 129), (256, 256, None), (128, 256, 300)])
 def test_window_conv_multi_pass_and_ragged(hip, oracle, cin, cout, n):
     """A shuffled map has no locality (windows of > 1000 rows): forced onto the window kernel it runs 3 - 5 passes
     per tile; the result must still be the convolution (oracle on fp32 operands).  n = 129: a ragged second tile."""

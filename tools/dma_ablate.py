@@ -1,5 +1,5 @@
-"""Phase ablation of k_conv_dma on layers captured from one benchmark step (results are wrong with a bit set; only
-the time matters).  python tools/dma_ablate.py [out.txt]"""
+"""Phase ablation of k_conv_dma on layers captured from one benchmark step.  NOTE: the ablation branches were removed from
+the kernel after round 2 (profiles/r2c - r2e hold the results); only the 256-row tile switch (0x100) still acts.  python tools/dma_ablate.py [out.txt]"""
 import ctypes as C
 import os
 import sys
