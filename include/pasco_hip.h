@@ -62,10 +62,13 @@ int64_t PH_FN(workspace_bytes)(int64_t n);
  *   row2uniq[n]   out: unique-row index of every input row
  *   uniq_rows[n]  out: input row of unique row j (first n_uniq entries valid)
  *   n_uniq        out: device scalar
+ *   status        in/out (or NULL): bit 1 is raised when a coordinate cannot be packed into the 64-bit key (batch index
+ *                 outside 0 .. 1023 or a coordinate outside -2^17 .. 2^17 - 1: it would alias another voxel).  Lookups
+ *                 (map_find, nbr_build) answer -1 for such coordinates.
  * ------------------------------------------------------------------------------------------- */
 int PH_FN(map_insert)(const int32_t *coords, int64_t n, uint64_t *tkeys, int32_t *tvals,
                       int64_t cap, int32_t *row2uniq, int32_t *uniq_rows, int32_t *n_uniq,
-                      void *ws, int64_t ws_bytes, ph_stream_t stream);
+                      void *ws, int64_t ws_bytes, int32_t *status, ph_stream_t stream);
 
 /* Look up `n` query coordinates; out_rows[i] = row or -1.  (Union add decoder_v3.py:163,
  * attention-mask lookup transformer_predictor_v2.py:276-279.) */

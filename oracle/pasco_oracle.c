@@ -71,6 +71,12 @@ static uint64_t pack(int b, int x, int y, int z) {
          ((uint64_t)((uint32_t)(z + COORD_BIAS) & 0x3FFFFu));
 }
 
+/* batch 0 .. 1023, coordinates -2^17 .. 2^17 - 1: what the key can hold */
+static int packable(int b, int x, int y, int z) {
+  return (unsigned)b < 1024u && (unsigned)(x + COORD_BIAS) < (1u << 18) && (unsigned)(y + COORD_BIAS) < (1u << 18) &&
+         (unsigned)(z + COORD_BIAS) < (1u << 18);
+}
+
 static uint64_t mix(uint64_t k) {
   k ^= k >> 33;
   k *= 0xff51afd7ed558ccdull;
@@ -95,9 +101,11 @@ static int find(const uint64_t *tkeys, const int32_t *tvals, uint64_t mask, uint
 /* a1: sequential insert => first occurrence wins, unique rows numbered in input order. */
 int pho_map_insert(const int32_t *coords, int64_t n, uint64_t *tkeys, int32_t *tvals, int64_t cap,
                    int32_t *row2uniq, int32_t *uniq_rows, int32_t *n_uniq, void *ws,
-                   int64_t ws_bytes, ph_stream_t stream) {
+                   int64_t ws_bytes, int32_t *status, ph_stream_t stream) {
   (void)ws; (void)ws_bytes; (void)stream;
   if (!is_pow2(cap) || cap < 2 * n || cap < 2) return fail("map_insert: cap must be pow2 >= 2n");
+  for (int64_t i = 0; i < n && status; ++i)
+    if (!packable(coords[4 * i], coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3])) *status |= 2;
   for (int64_t s = 0; s < cap; ++s) { tkeys[s] = EMPTY_KEY; tvals[s] = INT_MAX; }
   uint64_t mask = (uint64_t)cap - 1;
   int32_t count = 0;
@@ -127,7 +135,7 @@ int pho_map_find(const int32_t *query, int64_t n, const uint64_t *tkeys, const i
   uint64_t mask = (uint64_t)cap - 1;
   for (int64_t i = 0; i < n; ++i) {
     const int32_t *c = query + 4 * i;
-    out_rows[i] = find(tkeys, tvals, mask, pack(c[0], c[1], c[2], c[3]));
+    out_rows[i] = packable(c[0], c[1], c[2], c[3]) ? find(tkeys, tvals, mask, pack(c[0], c[1], c[2], c[3])) : -1;
   }
   return 0;
 }
@@ -176,7 +184,8 @@ int pho_nbr_build(const int32_t *out_coords, int64_t n_out, const uint64_t *in_t
     const int32_t *c = out_coords + 4 * o;
     for (int k = 0; k < kvol; ++k) {
       const int32_t *d = h_offsets + 3 * k;
-      nbr[(int64_t)k * n_out + o] = find(in_tkeys, in_tvals, mask, pack(c[0], c[1] + d[0], c[2] + d[1], c[3] + d[2]));
+      nbr[(int64_t)k * n_out + o] = packable(c[0], c[1] + d[0], c[2] + d[1], c[3] + d[2])
+                                        ? find(in_tkeys, in_tvals, mask, pack(c[0], c[1] + d[0], c[2] + d[1], c[3] + d[2])) : -1;
     }
   }
   return 0;

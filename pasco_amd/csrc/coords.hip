@@ -159,10 +159,11 @@ extern "C" int ph_mask_compact(const uint8_t *mask, int64_t n, int32_t *keep_row
 // ---- hash insert --------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
     k_insert(const int4 *__restrict__ coords, int64_t n, unsigned long long *__restrict__ tkeys,
-             int32_t *__restrict__ tvals, uint64_t mask, int32_t *__restrict__ row_slot) {
+             int32_t *__restrict__ tvals, uint64_t mask, int32_t *__restrict__ row_slot, int32_t *__restrict__ status) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int4 c = coords[i];
+  if (status != nullptr && !ph_packable(c.x, c.y, c.z, c.w)) atomicOr(status, 2);   // the key would alias another voxel
   uint64_t key = ph_pack(c.x, c.y, c.z, c.w);
   uint64_t slot = ph_hash(key) & mask;
   for (;;) {
@@ -202,7 +203,7 @@ static inline unsigned nblk(int64_t n, int t) { return (unsigned)((n + t - 1) / 
 
 extern "C" int ph_map_insert(const int32_t *coords, int64_t n, uint64_t *tkeys, int32_t *tvals,
                              int64_t cap, int32_t *row2uniq, int32_t *uniq_rows, int32_t *n_uniq,
-                             void *ws, int64_t ws_bytes, ph_stream_t stream) {
+                             void *ws, int64_t ws_bytes, int32_t *status, ph_stream_t stream) {
   hipStream_t st = ph_stream(stream);
   PH_REQUIRE(n >= 0 && n < 0x3FFFFFFF, "map_insert: bad n=%lld", (long long)n);
   PH_REQUIRE(ph_is_pow2(cap) && cap >= 2 * n && cap >= 2, "map_insert: cap=%lld must be pow2 >= 2n",
@@ -217,7 +218,7 @@ extern "C" int ph_map_insert(const int32_t *coords, int64_t n, uint64_t *tkeys, 
   if (uniq_rows == nullptr) {
     // caller guarantees unique coordinates: rows keep their index.
     hipLaunchKernelGGL(k_insert, dim3(nblk(n, 256)), dim3(256), 0, st, (const int4 *)coords, n,
-                       (unsigned long long *)tkeys, tvals, mask, (int32_t *)nullptr);
+                       (unsigned long long *)tkeys, tvals, mask, (int32_t *)nullptr, status);
     PH_LAUNCH_CHECK();
     return 0;
   }
@@ -229,7 +230,7 @@ extern "C" int ph_map_insert(const int32_t *coords, int64_t n, uint64_t *tkeys, 
   char *rest = (char *)(rank_of + n);
   int64_t rest_bytes = ws_bytes - 8 * n;
   hipLaunchKernelGGL(k_insert, dim3(nblk(n, 256)), dim3(256), 0, st, (const int4 *)coords, n,
-                     (unsigned long long *)tkeys, tvals, mask, row_slot);
+                     (unsigned long long *)tkeys, tvals, mask, row_slot, status);
   PH_LAUNCH_CHECK();
   int rc = compact_run(PredFirst{tvals, row_slot}, EmitRows{uniq_rows, rank_of}, n, 1, n_uniq, rest,
                        rest_bytes, st);
@@ -248,7 +249,7 @@ __global__ void __launch_bounds__(256)
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int4 c = q[i];
-  out[i] = ph_find(tkeys, tvals, mask, ph_pack(c.x, c.y, c.z, c.w));
+  out[i] = ph_packable(c.x, c.y, c.z, c.w) ? ph_find(tkeys, tvals, mask, ph_pack(c.x, c.y, c.z, c.w)) : -1;
 }
 
 extern "C" int ph_map_find(const int32_t *query, int64_t n, const uint64_t *tkeys,
@@ -320,8 +321,9 @@ __global__ void __launch_bounds__(256)
   int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= n_out) return;
   int4 c = out_coords[o];
-  uint64_t key = ph_pack(c.x, c.y + off.d[k][0], c.z + off.d[k][1], c.w + off.d[k][2]);
-  nbr[(int64_t)k * n_out + o] = ph_find(tkeys, tvals, mask, key);
+  const int x = c.y + off.d[k][0], y = c.z + off.d[k][1], z = c.w + off.d[k][2];
+  // a neighbour beyond the packable range cannot be in the map (insert flags such coordinates)
+  nbr[(int64_t)k * n_out + o] = ph_packable(c.x, x, y, z) ? ph_find(tkeys, tvals, mask, ph_pack(c.x, x, y, z)) : -1;
 }
 
 extern "C" int ph_nbr_build(const int32_t *out_coords, int64_t n_out, const uint64_t *in_tkeys,

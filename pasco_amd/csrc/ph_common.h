@@ -43,6 +43,12 @@ __host__ __device__ __forceinline__ uint64_t ph_pack(int b, int x, int y, int z)
          ((uint64_t)((uint32_t)(z + PH_COORD_BIAS) & 0x3FFFFu));
 }
 
+// what ph_pack can represent: batch 0 .. 1023, coordinates -2^17 .. 2^17 - 1 (anything else would alias another key)
+__host__ __device__ __forceinline__ bool ph_packable(int b, int x, int y, int z) {
+  return (unsigned)b < 1024u && (unsigned)(x + PH_COORD_BIAS) < (1u << 18) && (unsigned)(y + PH_COORD_BIAS) < (1u << 18) &&
+         (unsigned)(z + PH_COORD_BIAS) < (1u << 18);
+}
+
 __host__ __device__ __forceinline__ uint64_t ph_hash(uint64_t k) {
   k ^= k >> 33;
   k *= 0xff51afd7ed558ccdull;

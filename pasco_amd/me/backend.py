@@ -63,7 +63,7 @@ _SIGNATURES = {
     "abi_version": [],
     "last_error": [],
     "workspace_bytes": [_i64],
-    "map_insert": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
+    "map_insert": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "map_find": [_vp, _i64, _vp, _vp, _i64, _vp, _vp],
     "coords_floor": [_vp, _i64, _i32, _vp, _vp],
     "coords_expand": [_vp, _i64, _i32, _vp, _vp],
@@ -194,13 +194,13 @@ class CBackend:
             uniq_rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
             n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
             rc = self.fn["map_insert"](_ptr(coords), n, _ptr(tkeys), _ptr(tvals), cap, _ptr(row2uniq),
-                                       _ptr(uniq_rows), _ptr(n_uniq), _ptr(ws), ws.numel(),
+                                       _ptr(uniq_rows), _ptr(n_uniq), _ptr(ws), ws.numel(), _ptr(self.status_word(dev)),
                                        self.stream(dev))
             self._check(rc, "map_insert")
             nu = int(n_uniq.item())
             return tkeys, tvals, row2uniq[:n], uniq_rows[:nu], nu
         rc = self.fn["map_insert"](_ptr(coords), n, _ptr(tkeys), _ptr(tvals), cap, None, None, None,
-                                   _ptr(ws), ws.numel(), self.stream(dev))
+                                   _ptr(ws), ws.numel(), _ptr(self.status_word(dev)), self.stream(dev))
         self._check(rc, "map_insert")
         return tkeys, tvals, None, None, n
 
@@ -424,13 +424,21 @@ class CBackend:
         return t
 
     def check_status(self, device) -> None:
-        """Raise if a split-precision convolution met an activation outside the f16 range since the last check
-        (one device->host read; call where the host synchronises anyway)."""
+        """Raise if, since the last check, a split-precision kernel met a value outside the f16 range (bit 0) or a
+        coordinate map was given a coordinate its 64-bit key cannot hold (bit 1): one device->host read; call where the
+        host synchronises anyway."""
         t = self._ws.get(("status", device))
-        if t is not None and int(t.item()) != 0:
-            t.zero_()
-            raise RuntimeError("pasco_amd: activation outside the f16 range in a split-precision convolution; "
-                               "rerun with pasco_amd.graph.fused.set_conv_precision('f32')")
+        if t is None:
+            return
+        v = int(t.item())
+        if v == 0:
+            return
+        t.zero_()
+        if v & 2:
+            raise RuntimeError("pasco_amd: a coordinate outside the packable range (batch index 0..1023, coordinates "
+                               "-131072..131071) was inserted into a coordinate map; it would alias another voxel")
+        raise RuntimeError("pasco_amd: activation outside the f16 range in a split-precision convolution; "
+                           "rerun with pasco_amd.graph.fused.set_conv_precision('f32')")
 
     @staticmethod
     def split_weight_f16(weight: torch.Tensor, exponent=None):

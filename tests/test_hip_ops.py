@@ -325,3 +325,28 @@ def test_ens_row_kernels_match_oracle_and_torch(hip, oracle, q):
     assert torch.equal(o_flag.bool(), (ref_f != 0).any(1)) and torch.equal(h_flag.cpu().bool(), (ref_f != 0).any(1))
     e_out, e_flag = hip.ens_finish(anchor.cuda(), keep[:0].cuda(), sem.cuda(), sel.cuda())     # no query kept
     assert e_out.shape == (sel.shape[0], 0) and not bool(e_flag.any())
+
+
+def test_coordinate_range_guard_matches_oracle(hip, oracle):
+    """Out-of-range coordinates: flagged on insert, -1 on lookup, no neighbour across the edge (same as the oracle)."""
+    dev = torch.device("cuda", 0)
+    hip.status_word(dev).zero_()                                # sticky flag: other tests may have raised it on purpose
+    g = torch.Generator().manual_seed(12)
+    c = torch.randint(-131072, 131072, (5000, 4), generator=g).int()
+    c[:, 0] = torch.randint(0, 1024, (5000,), generator=g).int()
+    tk, tv, *_ = hip.map_insert(c.cuda())
+    hip.check_status(dev)
+    q = c.clone()
+    q[::3, 1] += 1 << 18                                        # would alias row i with a plain mask
+    q[1::3, 0] += 1024
+    exp = oracle.map_find(q, *oracle.map_insert(c)[:2])
+    got = hip.map_find(q.cuda(), tk, tv).cpu()
+    assert torch.equal(got, exp) and bool((got[::3] == -1).all()) and bool((got[1::3] == -1).all())
+    edge = torch.tensor([[0, 131071, 0, 0], [0, -131072, 0, 0]], dtype=torch.int32)
+    offs = [(1, 0, 0), (-1, 0, 0), (0, 0, 0)]
+    tk2, tv2, *_ = hip.map_insert(edge.cuda())
+    assert hip.nbr_build(edge.cuda(), tk2, tv2, offs).cpu().tolist() == [[-1, -1], [-1, -1], [0, 1]]
+    hip.map_insert(torch.tensor([[0, 0, 0, -131073]], dtype=torch.int32).cuda())
+    with pytest.raises(RuntimeError, match="packable range"):
+        hip.check_status(dev)
+    hip.check_status(dev)

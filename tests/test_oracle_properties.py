@@ -1,6 +1,7 @@
 """Property tests (hypothesis) of the coordinate-map semantics on the CPU oracle: negative
 coordinates, duplicates, empty inputs, strides (SURVEY.md section 4 plan item 4)."""
 import numpy as np
+import pytest
 import torch
 from hypothesis import given, settings, strategies as st
 
@@ -122,3 +123,25 @@ def test_prune_same_mask_is_one_map_event(oracle_registered):
     pz = prune(x, keep)
     assert torch.equal(pz.C, c[keep]) and torch.equal(pz.F, x.F[keep])
     assert pz.coordinate_map_key != px.coordinate_map_key
+
+
+def test_coordinates_outside_the_key_range_are_flagged_not_aliased(oracle):
+    """The 64-bit key holds batch 0..1023 and coordinates -2^17 .. 2^17-1: an insert beyond that raises the status flag
+    (check_status), lookups beyond it answer -1 instead of the row of the voxel they would alias."""
+    dev = torch.device("cpu")
+    oracle.status_word(dev).zero_()                            # sticky flag: other tests may have raised it on purpose
+    ok = torch.tensor([[0, 1, 2, 3], [3, -131072, 131071, 0], [1023, 5, 5, 5]], dtype=torch.int32)
+    tk, tv, *_ = oracle.map_insert(ok)
+    oracle.check_status(dev)                                   # nothing raised
+    alias = torch.tensor([[0, 1 + (1 << 18), 2, 3], [1024, 1, 2, 3], [0, 1, 2, 3]], dtype=torch.int32)
+    assert oracle.map_find(alias, tk, tv).tolist() == [-1, -1, 0]
+    oracle.map_insert(torch.tensor([[0, 131072, 0, 0]], dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="packable range"):
+        oracle.check_status(dev)
+    oracle.check_status(dev)                                   # the flag was cleared by the read
+    # neighbours across the edge of the range do not exist
+    edge = torch.tensor([[0, 131071, 0, 0], [0, -131072, 0, 0]], dtype=torch.int32)
+    tk, tv, *_ = oracle.map_insert(edge)
+    offs = [(1, 0, 0), (-1, 0, 0), (0, 0, 0)]
+    nbr = oracle.nbr_build(edge, tk, tv, offs)
+    assert nbr.tolist() == [[-1, -1], [-1, -1], [0, 1]]
