@@ -21,6 +21,8 @@
 //
 // Same tile algebra, accumulation order and epilogue as k_conv_h2 (conv_h2_common.h): results are bit-identical.
 #include <mutex>
+#include <stdlib.h>
+
 #include "conv_h2_common.h"
 
 constexpr int DMA_KMAX = 32;   // kernel offsets one workgroup walks (its slice of the split over the offsets)
@@ -37,7 +39,7 @@ extern "C" void ph_conv_dma_set_ablate(int mask) { g_dma_ablate = 0; g_dma_tall 
 // 32 input channels per stage.  Everything that crosses the vector-memory path (gathered rows AND the weight tile of
 // every workgroup) is paid at ~32 B/clk/CU whether it hits L1 / L2 or not (profiles/README.md, k_conv_dma ablation):
 // the 256-row tile halves the weight bytes per output row.
-template <int WAVES, int WM, int WN, int TM, int TN, bool EMIT>
+template <int WAVES, int WM, int WN, int TM, int TN, bool EMIT, bool INTER = false>
 __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
   constexpr int NT = WAVES * 64;
   constexpr int BM = WM * TM * 32;
@@ -208,6 +210,35 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[ks][j], f.ah[ks][i], acc[i][j], 0, 0, 0);
           }
     };
+    // INTER: the DMA instructions of a stage issued BETWEEN its matrix instructions (one DMA, then its share of the MFMAs)
+    // instead of all in front of them
+    auto fire_mfma = [&](const Src &src, int buf, const Frag &f) {
+      char *abuf = lds + buf * STAGE;
+      constexpr int ND = A_PASSES + B_PASSES, NM = 2 * TM * TN * 3;
+#pragma unroll
+      for (int t = 0; t < ND; ++t) {
+        if (t < A_PASSES) {
+          char *dst = abuf + (t * RPP + wave * 8) * 128;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)src.a[t],
+                                           (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        } else {
+          const int q = t - A_PASSES;
+          char *dst = abuf + A_BYTES + (q * RPP + wave * 8) * 128;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(src.w + boff[q]),
+                                           (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = t * NM / ND; m < (t + 1) * NM / ND; ++m) {
+          const int p = m % 3, ij = (m / 3) % (TM * TN), ks = m / (3 * TM * TN);
+          const int i = ij / TN, j = ij % TN;
+          if (p == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[ks][j], f.al[ks][i], acc[i][j], 0, 0, 0);
+          else if (p == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[ks][j], f.ah[ks][i], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[ks][j], f.ah[ks][i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
     // wait until at most L DMA instructions (= the younger stage) are outstanding, then rendezvous
 #define DMA_WAIT_STAGE()                                                  \
   do {                                                                    \
@@ -244,21 +275,34 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
       prep(s + 3, ix, src);
       readfrag(1, f1);
       DMA_READS_DONE();
-      fire(src, 1);
-      ix = load_idx(s + 4);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma(f0);
-      __builtin_amdgcn_sched_barrier(0);
+      if (INTER) {
+        ix = load_idx(s + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        fire_mfma(src, 1, f0);
+      } else {
+        fire(src, 1);
+        ix = load_idx(s + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // stage s + 1 from f1; fragments of stage s + 2 from buffer 0; DMA of stage s + 4 into buffer 0
       DMA_WAIT_STAGE();
       prep(s + 4, ix, src);
       readfrag(0, f0);
       DMA_READS_DONE();
-      fire(src, 0);
-      ix = load_idx(s + 5);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 1 < nstages) mfma(f1);
-      __builtin_amdgcn_sched_barrier(0);
+      if (INTER) {
+        ix = load_idx(s + 5);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nstages) fire_mfma(src, 0, f1);
+        else fire(src, 0);
+      } else {
+        fire(src, 0);
+        ix = load_idx(s + 5);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nstages) mfma(f1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail loads: nothing may land after the epilogue starts
 #undef DMA_WAIT_STAGE
@@ -277,7 +321,13 @@ static int launch_dma(const ConvArgsH &a, hipStream_t st) {
   const int ntiles = args.n_row_tiles * args.n_col_tiles;
   const int grid = ((ntiles + 7) / 8) * 8;
   const bool emit = args.out_split != nullptr && args.ksplit == 1;
-  if (emit)
+  static const bool inter = [] { const char *e = getenv("PASCO_CONV_DMA_INTER"); return e == nullptr || atoi(e) != 0; }();
+  if (inter && WAVES == 4) {     // default: DMA instructions between the MFMAs (5-10 % on every layer; =0: in front of them)
+    if (emit)
+      hipLaunchKernelGGL((k_conv_dma<WAVES, WM, WN, TM, TN, true, true>), dim3(grid, 1), dim3(WAVES * 64), 0, st, args);
+    else
+      hipLaunchKernelGGL((k_conv_dma<WAVES, WM, WN, TM, TN, false, true>), dim3(grid, args.ksplit), dim3(WAVES * 64), 0, st, args);
+  } else if (emit)
     hipLaunchKernelGGL((k_conv_dma<WAVES, WM, WN, TM, TN, true>), dim3(grid, 1), dim3(WAVES * 64), 0, st, args);
   else
     hipLaunchKernelGGL((k_conv_dma<WAVES, WM, WN, TM, TN, false>), dim3(grid, args.ksplit), dim3(WAVES * 64), 0, st, args);
