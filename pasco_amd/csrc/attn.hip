@@ -299,7 +299,7 @@ __device__ __forceinline__ s16x4 as_rdtr(uint32_t addr) {
   return v;
 }
 
-template <bool MASK>
+template <bool MASK, bool INTER = true>
 __global__ void __launch_bounds__(256) k_attn_split(AttnSplitArgs s) {
   const AttnArgs &a = s.a;
   __shared__ __attribute__((aligned(16))) char lds[AS_STAGE * AS_STAGES];
@@ -352,6 +352,24 @@ __global__ void __launch_bounds__(256) k_attn_split(AttnSplitArgs s) {
   const bool mask_wave = has_bits && wave < 2;          // mask words [w][key]: instr m = wave: w = 2m + h2
   const char *mbase = has_bits ? (const char *)a.bits + (int64_t)b * a.n * 16 + (2 * wave + h2) * 4 : nullptr;
 
+  auto fire_one = [&](int tile_local, int k) {       // one of the wave's three 16-byte DMA instructions of a tile
+    const int64_t nb = (t0 + tile_local) * AS_KT;
+    char *st = lds + (tile_local % AS_STAGES) * AS_STAGE;
+    int64_t key = nb + d_key[k];
+    if (key >= a.n) key = a.n - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(d_base[k] + key * rowb + d_off[k]),
+                                     (__attribute__((address_space(3))) void *)(st + d_dst[k]), 16, 0, 0);
+  };
+  auto fire_mask = [&](int tile_local) {
+    if (mask_wave) {
+      const int64_t nb = (t0 + tile_local) * AS_KT;
+      char *st = lds + (tile_local % AS_STAGES) * AS_STAGE;
+      int64_t key = nb + l31;
+      if (key >= a.n) key = a.n - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(mbase + key * 16),
+                                       (__attribute__((address_space(3))) void *)(st + AS_K_BYTES + AS_V_BYTES + wave * 256), 4, 0, 0);
+    }
+  };
   auto fire = [&](int tile_local) {
     const int64_t nb = (t0 + tile_local) * AS_KT;
     char *st = lds + (tile_local % AS_STAGES) * AS_STAGE;
@@ -432,7 +450,8 @@ __global__ void __launch_bounds__(256) k_attn_split(AttnSplitArgs s) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < ntile) fire(t + 2);
+    const bool pre = t + 2 < ntile;
+    if (pre && (!wave_live || !INTER)) fire(t + 2);          // idle query tiles still carry their share of the DMA
     if (!wave_live) continue;
     const uint32_t so = (uint32_t)((t % AS_STAGES) * AS_STAGE);
     const int64_t nb = (t0 + t) * AS_KT;
@@ -470,12 +489,18 @@ __global__ void __launch_bounds__(256) k_attn_split(AttnSplitArgs s) {
     f32x16 sacc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+    // the DMA of tile t + 2 goes out between the score MFMAs (a wave stalled at the issue of a DMA leaves the matrix
+    // pipe the MFMAs it already issued)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
+      if (INTER && pre) fire_one(t + 2, c);
+      __builtin_amdgcn_sched_barrier(0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[c], qh[c], sacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[c], ql[c], sacc, 0, 0, 0);
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[c], qh[c], sacc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (INTER && pre) fire_mask(t + 2);
     // ---- mask + online softmax: this lane's query is qq; register 4g + r is key nb + 8g + 4 h2 + r ----------------------
     float sv[16];
     float tmax = -INFINITY;
@@ -725,8 +750,13 @@ extern "C" int ph_attn_cross_split(const float *q, const void *k_split, const vo
   s.groups = b * (int)splits;
   hipStream_t st = ph_stream(stream);
   const int64_t groups8 = ((int64_t)s.groups + 7) / 8;       // groups per XCD
-  if (bits != nullptr) hipLaunchKernelGGL(k_attn_split<true>, dim3((unsigned)(groups8 * h * 8)), dim3(256), 0, st, s);
-  else hipLaunchKernelGGL(k_attn_split<false>, dim3((unsigned)(groups8 * h * 8)), dim3(256), 0, st, s);
+  static const bool plain = [] { const char *e = getenv("PASCO_ATTN_INTER"); return e != nullptr && atoi(e) == 0; }();
+  const dim3 grid((unsigned)(groups8 * h * 8));
+  if (plain) {
+    if (bits != nullptr) hipLaunchKernelGGL((k_attn_split<true, false>), grid, dim3(256), 0, st, s);
+    else hipLaunchKernelGGL((k_attn_split<false, false>), grid, dim3(256), 0, st, s);
+  } else if (bits != nullptr) hipLaunchKernelGGL((k_attn_split<true, true>), grid, dim3(256), 0, st, s);
+  else hipLaunchKernelGGL((k_attn_split<false, true>), grid, dim3(256), 0, st, s);
   PH_LAUNCH_CHECK();
   hipLaunchKernelGGL((k_attn_merge<4, 3>), dim3(bh, (qn + 15) / 16), dim3(256), 0, st, a);
   PH_LAUNCH_CHECK();
