@@ -595,7 +595,8 @@ struct ConvHKnobs {
   bool dma_all = false;
   bool win_on = true;      // PASCO_CONV_WIN=0: no LDS-window kernel
   bool win_wide = false;   // PASCO_CONV_WIN=2: also on 128-wide tiles
-  bool win256 = true;      // PASCO_CONV_WIN256=0: no 256-wide window workgroups
+  bool win256 = false;     // PASCO_CONV_WIN256=1: 256-wide window workgroups for 256-channel layers (measured: 568 vs 547 us
+                           // for the gather kernel once its DMA is issued between the MFMAs)
   bool dma_on = true;      // PASCO_CONV_DMA=0: keep every launch on the register-staged k_conv_h2 (A/B comparisons)
   ConvHKnobs() {
     if (const char *e = getenv("PASCO_CONV_DMA")) {
@@ -753,7 +754,7 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   // 128-wide tiles lose to the gather kernel (one workgroup per CU: 668 vs 567 us) and stay there unless
   // PASCO_CONV_WIN=2.
   // 256 output channels: ONE 128 x 256 window workgroup per row tile (8 waves of 64 x 64): window and weight bytes per
-  // MFMA are 0.3x of the gather kernel's (PASCO_CONV_WIN256=0 disables)
+  // MFMA are 0.3x of the gather kernel's, yet no faster (opt-in: PASCO_CONV_WIN256=1 and window tables from the caller)
   const bool win256 = bn == 128 && d->cout == 256 && knobs.win256;
   if (pre && knobs.win_on && !env && d->kvol == 27 &&
       (bn == 64 || win256 || (bn == 128 && (knobs.win_wide || (ph_win_force_bits() & 0x100)))) &&

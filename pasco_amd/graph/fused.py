@@ -372,7 +372,7 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     only = split_only and emit is not None and n_out > 0
     win = None
     if in_split is not None and nbr is not None and nbr.shape[0] == 27 and n_out >= MIN_ROWS_WINDOWS and \
-            be.device_type == "cuda" and (33 <= mod.out_channels <= 64 or mod.out_channels == 256 or _WINDOWS_WIDE):   # 64-wide tiles and full-width 256 (measured)
+            be.device_type == "cuda" and (33 <= mod.out_channels <= 64 or _WINDOWS_WIDE):   # 64-wide tiles (measured)
         win = mgr.kernel_windows(nbr)
     out = be.conv_fwd(
         x_rows, mod.kernel.detach(), nbr, n_out, xshape=xshape, bias=bias,
