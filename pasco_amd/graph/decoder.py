@@ -74,9 +74,7 @@ class DecoderBlock(nn.Module):
         mgr = x.coordinate_manager
         up = self.upsample.net[0]
         # children -> bounds prune -> features only for surviving children
-        kids_key = mgr.expand(x.coordinate_map_key, up.stride)
-        keep = inside_bounds(mgr.get_coordinates(kids_key), global_min, global_max)
-        out_key, _ = mgr.prune(kids_key, keep)
+        out_key = mgr.expand_pruned(x.coordinate_map_key, up.stride, lambda kids: inside_bounds(kids, global_min, global_max))
         nbr = mgr.kernel_map(x.coordinate_map_key, out_key, up.kernel_size, up.dilation, transposed=True)
         dec = self.upsample(x, out_key=out_key, nbr=nbr)
         # coordinate channels (absolute coords / tensor stride) + BN + conv k1 with bias

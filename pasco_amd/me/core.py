@@ -176,6 +176,22 @@ class CoordinateManager:
         out_coords = be.gather_rows(children, uniq_rows) if nu != children.shape[0] else children
         return self._register(out_coords, tkeys, tvals, ts_out)
 
+    def expand_pruned(self, in_key: CoordinateMapKey, stride, keep_of) -> CoordinateMapKey:
+        """`expand` followed by `prune(keep_of(children))` as ONE map event: the children of distinct parents are distinct
+        (parents are multiples of their tensor stride), so the full child map - a hash build, a dedup compaction and a host
+        read that only served to enumerate the candidates - is never built; only the survivors are inserted.  Same
+        coordinates in the same order as the two-step form."""
+        s = _triple(stride)
+        assert s == (2, 2, 2), "generative expansion is served for kernel 2 / stride 2"
+        ts_in = in_key.tensor_stride
+        assert all(t % 2 == 0 for t in ts_in), "cannot up-sample below tensor stride 1"
+        ts_out = tuple(t // 2 for t in ts_in)
+        m = self._maps[in_key]
+        be = self.backend()
+        children = be.coords_expand(m.coords, ts_out[0])
+        keep = be.mask_compact(keep_of(children).contiguous())
+        return self.insert_unique(be.gather_rows(children, keep), ts_out)
+
     def prune(self, in_key: CoordinateMapKey, mask: torch.Tensor):
         """-> (out_key, keep_rows int32)."""
         m = self._maps[in_key]
