@@ -98,6 +98,12 @@ int PH_FN(nbr_build)(const int32_t *out_coords, int64_t n_out, const uint64_t *i
                      const int32_t *in_tvals, int64_t in_cap, const int32_t *h_offsets,
                      int32_t kvol, int32_t *nbr, ph_stream_t stream);
 
+/* nbr_build for a map onto ITSELF with a symmetric kernel (offset[K-1-k] = -offset[k], K odd; `coords` are the rows the
+ * table was built from, unique): same table, half the probes - a hit at offset k also is the entry of the mirrored
+ * offset.  Every stride-1 3x3x3 convolution of the U-Net (mink.py:625-638). */
+int PH_FN(nbr_build_same)(const int32_t *coords, int64_t n, const uint64_t *tkeys, const int32_t *tvals,
+                          int64_t cap, const int32_t *h_offsets, int32_t kvol, int32_t *nbr, ph_stream_t stream);
+
 /* COO kernel map in upstream's form: for every offset k the (in_row, out_row) pairs, sorted by
  * out_row.  pairs_in / pairs_out have kvol*n_out capacity, segment k starts at k*n_out;
  * counts[kvol] is a device array. */

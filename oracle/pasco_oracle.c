@@ -833,3 +833,13 @@ int pho_ens_finish(const float *anchor, int64_t u, int32_t q, const int32_t *kee
   }
   return 0;
 }
+
+/* same-map neighbour table of a symmetric kernel: by definition the table pho_nbr_build gives (the device halves its probes) */
+int pho_nbr_build_same(const int32_t *coords, int64_t n, const uint64_t *tkeys, const int32_t *tvals, int64_t cap,
+                       const int32_t *h_offsets, int32_t kvol, int32_t *nbr, ph_stream_t stream) {
+  if (!(kvol & 1)) return fail("nbr_build_same: odd kernel volume expected");
+  for (int k = 0; k < kvol; ++k)
+    for (int a = 0; a < 3; ++a)
+      if (h_offsets[3 * k + a] != -h_offsets[3 * (kvol - 1 - k) + a]) return fail("nbr_build_same: offsets are not symmetric");
+  return pho_nbr_build(coords, n, tkeys, tvals, cap, h_offsets, kvol, nbr, stream);
+}

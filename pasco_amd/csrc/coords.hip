@@ -342,6 +342,48 @@ extern "C" int ph_nbr_build(const int32_t *out_coords, int64_t n_out, const uint
   return 0;
 }
 
+// Same-map tables of a symmetric kernel (out_coords ARE the rows of the table, offset[K-1-k] = -offset[k], centre in the
+// middle): row i is the neighbour of row o at offset k  <=>  row o is the neighbour of row i at offset K-1-k.  Only the first
+// K/2 offsets are probed; every hit also writes its mirror entry (one writer per entry), the centre column is the identity.
+__global__ void __launch_bounds__(256)
+    k_nbr_build_same(const int4 *__restrict__ coords, int64_t n, const uint64_t *__restrict__ tkeys,
+                     const int32_t *__restrict__ tvals, uint64_t mask, NbrOffsets off, int kvol, int32_t *__restrict__ nbr) {
+  const int k = blockIdx.y;                 // 0 .. K/2
+  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  if (k == kvol / 2) {
+    nbr[(int64_t)k * n + o] = (int32_t)o;
+    return;
+  }
+  int4 c = coords[o];
+  const int x = c.y + off.d[k][0], y = c.z + off.d[k][1], z = c.w + off.d[k][2];
+  const int j = ph_packable(c.x, x, y, z) ? ph_find(tkeys, tvals, mask, ph_pack(c.x, x, y, z)) : -1;
+  nbr[(int64_t)k * n + o] = j;
+  if (j >= 0) nbr[(int64_t)(kvol - 1 - k) * n + j] = (int32_t)o;
+}
+
+extern "C" int ph_nbr_build_same(const int32_t *coords, int64_t n, const uint64_t *tkeys, const int32_t *tvals, int64_t cap,
+                                 const int32_t *h_offsets, int32_t kvol, int32_t *nbr, ph_stream_t stream) {
+  PH_REQUIRE(kvol >= 1 && kvol <= PH_MAX_KVOL && (kvol & 1), "nbr_build_same: odd kernel volume <= %d expected, got %d", PH_MAX_KVOL, kvol);
+  PH_REQUIRE(ph_is_pow2(cap), "nbr_build_same: cap must be pow2");
+  for (int k = 0; k < kvol; ++k)
+    for (int a = 0; a < 3; ++a)
+      PH_REQUIRE(h_offsets[3 * k + a] == -h_offsets[3 * (kvol - 1 - k) + a], "nbr_build_same: offsets are not symmetric");
+  if (n == 0) return 0;
+  hipStream_t st = ph_stream(stream);
+  NbrOffsets off;
+  memset(&off, 0, sizeof(off));
+  memcpy(off.d, h_offsets, sizeof(int32_t) * 3 * kvol);
+  const int half = kvol / 2;
+  if (half > 0)   // mirror half: -1 unless a hit writes it
+    PH_CHECK_HIP(hipMemsetAsync(nbr + (int64_t)(half + 1) * n, 0xFF, (size_t)half * (size_t)n * 4, st));
+  dim3 grid(nblk(n, 256), (unsigned)(half + 1));
+  hipLaunchKernelGGL(k_nbr_build_same, grid, dim3(256), 0, st, (const int4 *)coords, n, tkeys, tvals, (uint64_t)cap - 1, off,
+                     kvol, nbr);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- COO kernel map ------------------------------------------------------------------------------
 struct PredNbr {
   const int32_t *nbr;

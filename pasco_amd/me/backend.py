@@ -68,6 +68,7 @@ _SIGNATURES = {
     "coords_floor": [_vp, _i64, _i32, _vp, _vp],
     "coords_expand": [_vp, _i64, _i32, _vp, _vp],
     "nbr_build": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _vp],
+    "nbr_build_same": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "kmap_compact": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
     "conv_fwd": [C.POINTER(ConvDesc), _vp],
     "conv_last_config": [_vp],
@@ -230,8 +231,9 @@ class CBackend:
         return out
 
     def nbr_build(self, out_coords: torch.Tensor, tkeys: torch.Tensor, tvals: torch.Tensor,
-                  offsets) -> torch.Tensor:
-        """offsets: list of (dx,dy,dz) already scaled by the tensor stride."""
+                  offsets, same_map: bool = False) -> torch.Tensor:
+        """offsets: list of (dx,dy,dz) already scaled by the tensor stride.  `same_map`: out_coords are the (unique) rows
+        the table was built from and the offsets are symmetric -> half the probes (ph_nbr_build_same)."""
         self._chk(out_coords, torch.int32, "out_coords")
         kvol = len(offsets)
         if not 1 <= kvol <= MAX_KVOL:
@@ -239,9 +241,10 @@ class CBackend:
         n_out = out_coords.shape[0]
         flat = (_i32 * (3 * kvol))(*[int(v) for o in offsets for v in o])
         nbr = torch.empty((kvol, n_out), dtype=torch.int32, device=out_coords.device)
-        rc = self.fn["nbr_build"](_ptr(out_coords), n_out, _ptr(tkeys), _ptr(tvals), tkeys.numel(),
-                                  C.cast(flat, _vp), kvol, _ptr(nbr), self.stream(out_coords.device))
-        self._check(rc, "nbr_build")
+        name = "nbr_build_same" if same_map else "nbr_build"
+        rc = self.fn[name](_ptr(out_coords), n_out, _ptr(tkeys), _ptr(tvals), tkeys.numel(),
+                           C.cast(flat, _vp), kvol, _ptr(nbr), self.stream(out_coords.device))
+        self._check(rc, name)
         return nbr
 
     def win_build(self, nbr: torch.Tensor) -> dict:

@@ -231,7 +231,11 @@ class CoordinateManager:
             base_stride = out_key.tensor_stride if transposed else in_key.tensor_stride
             offs = kernel_offsets(ks, base_stride, dl, transposed)
             mi, mo = self._maps[in_key], self._maps[out_key]
-            nbr = self.backend().nbr_build(mo.coords, mi.tkeys, mi.tvals, offs)
+            # a map onto itself with a symmetric kernel (every stride-1 3x3x3 convolution): half the hash probes
+            k = len(offs)
+            same = in_key == out_key and not transposed and k % 2 == 1 and k > 1 and all(
+                tuple(offs[i]) == tuple(-v for v in offs[k - 1 - i]) for i in range(k // 2 + 1))
+            nbr = self.backend().nbr_build(mo.coords, mi.tkeys, mi.tvals, offs, same_map=same)
             self._kmap_cache[ck] = nbr
         return nbr
 

@@ -350,3 +350,23 @@ def test_coordinate_range_guard_matches_oracle(hip, oracle):
     with pytest.raises(RuntimeError, match="packable range"):
         hip.check_status(dev)
     hip.check_status(dev)
+
+
+@pytest.mark.parametrize("ks,dil,n", [(3, 1, 30000), (3, 2, 5000), (5, 1, 300), ((3, 1, 3), 1, 2000)])
+def test_nbr_build_same_map_equals_plain_build(hip, oracle, ks, dil, n):
+    """ph_nbr_build_same (half the probes + mirrored writes) gives the table of ph_nbr_build and of the oracle."""
+    from pasco_amd.me.core import kernel_offsets
+    g = torch.Generator().manual_seed(77 + n)
+    c = torch.cat([torch.randint(0, 3, (n, 1), generator=g), torch.randint(-20, 20, (n, 3), generator=g)], 1).int()
+    c = torch.unique(c, dim=0)
+    c = c[torch.randperm(c.shape[0], generator=g)].contiguous()
+    offs = kernel_offsets(ks, 1, dil, False)
+    if len(offs) > 64:
+        pytest.skip("kernel volume beyond one nbr_build call")
+    tk, tv, *_ = hip.map_insert(c.cuda(), dedup=False)
+    plain = hip.nbr_build(c.cuda(), tk, tv, offs)
+    same = hip.nbr_build(c.cuda(), tk, tv, offs, same_map=True)
+    assert torch.equal(plain, same)
+    tko, tvo, *_ = oracle.map_insert(c, dedup=False)
+    assert torch.equal(same.cpu(), oracle.nbr_build(c, tko, tvo, offs, same_map=True))
+    assert bool((same[len(offs) // 2].cpu() == torch.arange(c.shape[0])).all())
