@@ -164,7 +164,8 @@ typedef struct ph_conv_desc {
                              several workgroups and reduce [splits, n_out, cout] partial sums in a fixed order */
   int64_t splitk_ws_bytes;
   int32_t *status;        /* optional device word; mode 1 ORs bit 0 into it when a gathered activation
-                             exceeds the f16 range (|x| > 65504) - the caller must then redo the layer in mode 0 */
+                             exceeds the f16 range (|x| > 65504) - the caller must then redo the layer in mode 0;
+                             bit 2 when a coordinate fell outside axis_table's rows (the row was clamped) */
   /* mode 2 = mode 1 with BOTH operands pre-split by ph_split_rows (the gather becomes a 16-byte copy: no
    * per-gather conversion).  in_split = ph_split_rows(in [n_in, cin], pro_*, split_exp2) - the prologue is applied there
    * and NOT again by the device; w_split = ph_split_rows of the [kvol*cout, cin] rows of (weight * 2^e)

@@ -399,6 +399,10 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
               float t = 0.f;
               for (int ax = 0; ax < 3; ++ax) {
                 int idx = d->axis_coords[o * 4 + 1 + ax] - d->axis_lo;
+                if ((idx < 0 || idx >= d->axis_rows) && d->status) {   /* clamped: status bit 2 */
+#pragma omp atomic
+                  *(int32_t *)d->status |= 4;
+                }
                 idx = idx < 0 ? 0 : (idx >= d->axis_rows ? d->axis_rows - 1 : idx);
                 t += d->axis_table[((int64_t)ax * d->axis_rows + idx) * cout + n];
               }

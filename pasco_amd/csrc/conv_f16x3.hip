@@ -504,7 +504,9 @@ __global__ void __launch_bounds__(256) k_splitk_epilogue(ConvArgsH a) {
   float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.has_tail && a.residual) rs = *reinterpret_cast<const float4 *>(a.residual + t);
   if (a.has_tail && a.axis_table) {
-    const float4 tb = ph_axis_residual4(a, row, col);
+    int64_t aoff[3];
+    if (ph_axis_offsets(a, row, aoff) && a.status != nullptr) atomicOr(a.status, 4);
+    const float4 tb = ph_axis_residual4(a, aoff, col);
     rs = make_float4(tb.x + rs.x, tb.y + rs.y, tb.z + rs.z, tb.w + rs.w);
   }
   const float r4[4] = {rs.x, rs.y, rs.z, rs.w};

@@ -56,15 +56,19 @@ struct ConvArgsH {
 };
 
 // element offsets of the three table rows (x, y, z) of one output row (coordinates clamped to the table)
-__device__ __forceinline__ void ph_axis_offsets(const ConvArgsH &a, int64_t row, int64_t (&off)[3]) {
+// -> true when a coordinate lies outside the table (its row was clamped: the caller raises status bit 2)
+__device__ __forceinline__ bool ph_axis_offsets(const ConvArgsH &a, int64_t row, int64_t (&off)[3]) {
   const int4 c = *reinterpret_cast<const int4 *>(a.axis_coords + row * 4);
   const int v[3] = {c.y, c.z, c.w};
+  bool clamped = false;
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax) {
     int idx = v[ax] - a.axis_lo;
+    clamped |= idx < 0 || idx >= a.axis_rows;
     idx = idx < 0 ? 0 : (idx >= a.axis_rows ? a.axis_rows - 1 : idx);
     off[ax] = ((int64_t)ax * a.axis_rows + idx) * a.cout;
   }
+  return clamped;
 }
 // t0[x] + t1[y] + t2[z] for 4 consecutive channels of one output row
 __device__ __forceinline__ float4 ph_axis_residual4(const ConvArgsH &a, const int64_t (&off)[3], int col) {
@@ -190,7 +194,7 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
       if (axis_pre) {
         axis_off[i][0] = axis_pre[i][0]; axis_off[i][1] = axis_pre[i][1]; axis_off[i][2] = axis_pre[i][2];
       } else if (row < a.n_out) {
-        ph_axis_offsets(a, row, axis_off[i]);
+        if (ph_axis_offsets(a, row, axis_off[i]) && a.status != nullptr) atomicOr(a.status, 4);
       } else {
         axis_off[i][0] = axis_off[i][1] = axis_off[i][2] = 0;
       }

@@ -17,6 +17,7 @@ masks by membership tests against given voxel sets.
 """
 from __future__ import annotations
 
+import os
 from collections import defaultdict
 from typing import Dict, List, Optional
 
@@ -76,15 +77,72 @@ class DecoderBlock(nn.Module):
         # children -> bounds prune -> features only for surviving children
         out_key = mgr.expand_pruned(x.coordinate_map_key, up.stride, lambda kids: inside_bounds(kids, global_min, global_max))
         nbr = mgr.kernel_map(x.coordinate_map_key, out_key, up.kernel_size, up.dilation, transposed=True)
-        dec = self.upsample(x, out_key=out_key, nbr=nbr)
-        # coordinate channels (absolute coords / tensor stride) + BN + conv k1 with bias
-        ts = dec.tensor_stride[0]
-        feats = torch.cat([dec.F, dec.C[:, 1:].float() / ts], dim=1)
-        dec = ME.SparseTensor(feats, coordinate_map_key=out_key, coordinate_manager=mgr)
-        dec = fused.conv(dec, self.resize[1], pro_bn=self.resize[0], pro_act=ACT_NONE)
+        dec = self._resize_absorbed(x, out_key, nbr)
+        if dec is None:
+            dec = self.upsample(x, out_key=out_key, nbr=nbr)
+            # coordinate channels (absolute coords / tensor stride) + BN + conv k1 with bias
+            ts = dec.tensor_stride[0]
+            feats = torch.cat([dec.F, dec.C[:, 1:].float() / ts], dim=1)
+            dec = ME.SparseTensor(feats, coordinate_map_key=out_key, coordinate_manager=mgr)
+            dec = fused.conv(dec, self.resize[1], pro_bn=self.resize[0], pro_act=ACT_NONE)
         y = run_sequential(self.process, dec + shortcut)
         logits = [fused.conv(y, self.completion_heads[str(i)][0]) for i in range(self.n_heads)]
         return y, logits
+
+
+    # -- `resize` without the concatenation --------------------------------------------------------------------------
+    RESIZE_LO, RESIZE_ROWS = -1024, 5120     # coordinate values the tables cover (a coordinate outside raises the status flag)
+
+    def _resize_absorbed(self, x, out_key, nbr):
+        """upsample -> [features | coords / ts] -> BN -> 1x1 conv (decoder_v3.py:103,133) without forming the C + 3 channel
+        tensor: BN has no activation behind it, so
+            out = F (s_f * W_f) + (bias + b_f W_f) + sum_axis ((c_axis / ts) s_axis + b_axis) W_axis
+        = a C -> C product on the up-sampled features (whose launch writes them ONLY as the split operand) plus three rows of
+        a per-axis table (ph_conv_desc.axis_table).  No 183 MB concatenation, no odd channel count on the fp32 MFMA path.
+        None when the fused split path does not apply (the caller then runs the module sequence)."""
+        mgr = x.coordinate_manager
+        n_out = mgr.size(out_key)
+        conv, bn = self.resize[1], self.resize[0]
+        c_out = conv.out_channels
+        c_in = conv.in_channels - 3
+        be = mgr.backend()
+        if not (fused.fusion() and fused.conv_precision() == "f16x3" and fused._PRESPLIT and fused._kernel_device(x.F.device)
+                and n_out >= fused.MIN_ROWS_LINEAR and c_in % 32 == 0 and be.split_supported(c_in, c_out)
+                and os.environ.get("PASCO_RESIZE_ABSORB", "1") != "0"):
+            return None
+        dec = self.upsample(x, out_key=out_key, nbr=nbr, emit_next=(None, ACT_NONE), split_only=True)
+        if not isinstance(dec, fused.SplitRows):
+            return self._resize_plain(dec, out_key)
+        ts = out_key.tensor_stride[0]
+        w = conv.kernel
+        ver = (w._version, w.data_ptr(), conv.bias._version if conv.bias is not None else -1, ts) + tuple(
+            (t._version, t.data_ptr()) for t in (bn.bn.running_mean, bn.bn.running_var, bn.bn.weight, bn.bn.bias) if t is not None)
+        hit = self.__dict__.get("_ph_resize")
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                s_, b_ = fused.fold_bn(bn)
+                s64, b64, w64 = s_.double(), b_.double(), w.detach().reshape(c_in + 3, c_out).double()
+                wf = (s64[:c_in, None] * w64[:c_in]).t().contiguous().float()                     # [c_out, c_in]
+                bias = b64[:c_in] @ w64[:c_in]
+                if conv.bias is not None:
+                    bias = bias + conv.bias.detach().reshape(-1).double()
+                idx = torch.arange(self.RESIZE_ROWS, device=w.device, dtype=torch.float64) + self.RESIZE_LO
+                tab = torch.stack([((idx / ts) * s64[c_in + a] + b64[c_in + a])[:, None] * w64[c_in + a][None, :]
+                                   for a in range(3)]).float().contiguous()                       # [3, T, c_out]
+            hit = (ver, wf, bias.float().contiguous(), tab)
+            self.__dict__["_ph_resize"] = hit
+        _, wf, bias, tab = hit
+        coords = mgr.get_coordinates(out_key)
+        out = fused.linear_rows(None, wf, bias, self, "resize", in_split=dec.split,
+                                axis=(tab, coords.contiguous(), self.RESIZE_LO))
+        return ME.SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
+
+    def _resize_plain(self, dec, out_key):
+        mgr = dec.coordinate_manager
+        ts = dec.tensor_stride[0]
+        feats = torch.cat([dec.F, dec.C[:, 1:].float() / ts], dim=1)
+        dec = ME.SparseTensor(feats, coordinate_map_key=out_key, coordinate_manager=mgr)
+        return fused.conv(dec, self.resize[1], pro_bn=self.resize[0], pro_act=ACT_NONE)
 
 
 class DecoderGenerativeSepConvV2(nn.Module):

@@ -437,6 +437,9 @@ class CBackend:
         if v == 0:
             return
         t.zero_()
+        if v & 4:
+            raise RuntimeError("pasco_amd: a coordinate outside the range of a per-axis table residual (ph_conv_desc.axis_table) "
+                               "was clamped to the table's edge")
         if v & 2:
             raise RuntimeError("pasco_amd: a coordinate outside the packable range (batch index 0..1023, coordinates "
                                "-131072..131071) was inserted into a coordinate map; it would alias another voxel")
