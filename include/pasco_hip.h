@@ -330,6 +330,16 @@ int PH_FN(bits_orpool)(const uint32_t *bits_in, const int32_t *nbr, int32_t kvol
 
 int PH_FN(bits_or_reduce)(const uint32_t *bits, int64_t n, int32_t b, uint32_t *any, ph_stream_t stream);
 
+/* The attention mask of one level without the pooled map: level voxel i (batch i / n_per_b, coordinates level_coords[i][1..3],
+ * edge s) gets the OR of the bit rows of the fine voxels inside its block [c, c + s)^3, found through the fine map's hash
+ * table (tkeys / tvals of ph_map_insert; bits_in rows in that map's row order).  Equals max-pool (kernel s, stride s) ->
+ * dense -> index of transformer_predictor_v2.py:232-289 whenever no coordinate lies outside [lo[b], hi[b]] (int32 [B, 3]
+ * each, device): `range` (device word, or NULL) gets bit 0 when one does - the dense indexing of the reference then wraps
+ * negative indices, which the caller reproduces through bits_orpool + the dense-site lookup. */
+int PH_FN(bits_block_or)(const int32_t *level_coords, int64_t m, int64_t n_per_b, int32_t s, const uint64_t *tkeys,
+                         const int32_t *tvals, int64_t cap, const uint32_t *bits_in, const int32_t *lo, const int32_t *hi,
+                         uint32_t *bits_out, int32_t *range, ph_stream_t stream);
+
 int PH_FN(attn_cross_fwd)(const float *q, const float *k, const float *v, const uint32_t *bits,
                           const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h,
                           int32_t qn, int32_t dh, void *ws, int64_t ws_bytes, ph_stream_t stream);

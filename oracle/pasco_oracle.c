@@ -847,3 +847,31 @@ int pho_nbr_build_same(const int32_t *coords, int64_t n, const uint64_t *tkeys, 
       if (h_offsets[3 * k + a] != -h_offsets[3 * (kvol - 1 - k) + a]) return fail("nbr_build_same: offsets are not symmetric");
   return pho_nbr_build(coords, n, tkeys, tvals, cap, h_offsets, kvol, nbr, stream);
 }
+
+/* attention-mask bits of a level straight from the fine map (transformer_predictor_v2.py:232-289 without wrap) */
+int pho_bits_block_or(const int32_t *level_coords, int64_t m, int64_t n_per_b, int32_t s, const uint64_t *tkeys,
+                      const int32_t *tvals, int64_t cap, const uint32_t *bits_in, const int32_t *lo, const int32_t *hi,
+                      uint32_t *bits_out, int32_t *range, ph_stream_t stream) {
+  (void)stream;
+  if (s < 1 || s > 8 || n_per_b < 1 || !is_pow2(cap)) return fail("bits_block_or: bad shape");
+  const uint64_t mask = (uint64_t)cap - 1;
+  for (int64_t i = 0; i < m; ++i) {
+    const int32_t *c = level_coords + 4 * i;
+    const int b = (int)(i / n_per_b);
+    if (range)
+      for (int a = 0; a < 3; ++a)
+        if (c[1 + a] < lo[b * 3 + a] || c[1 + a] > hi[b * 3 + a]) *range |= 1;
+    uint32_t acc[4] = {0, 0, 0, 0};
+    for (int dx = 0; dx < s; ++dx)
+      for (int dy = 0; dy < s; ++dy)
+        for (int dz = 0; dz < s; ++dz) {
+          const int x = c[1] + dx, y = c[2] + dy, z = c[3] + dz;
+          if (!packable(b, x, y, z)) continue;
+          const int r = find(tkeys, tvals, mask, pack(b, x, y, z));
+          if (r >= 0)
+            for (int w = 0; w < 4; ++w) acc[w] |= bits_in[(int64_t)r * 4 + w];
+        }
+    for (int w = 0; w < 4; ++w) bits_out[i * 4 + w] = acc[w];
+  }
+  return 0;
+}

@@ -652,6 +652,52 @@ extern "C" int ph_bits_orpool(const uint32_t *bits_in, const int32_t *nbr, int32
   return 0;
 }
 
+// bits_out[i] = OR of the bit rows of the fine voxels inside level voxel i's s^3 block [c, c + s)^3 of batch i / n_per_b,
+// looked up in the fine map's hash table (absent children contribute nothing); range[0] |= 1 when a coordinate of the
+// level lies outside [lo[b], hi[b]] (the caller then takes the exact dense-index path of the reference's wrap semantics)
+__global__ void __launch_bounds__(256)
+    k_bits_block_or(const int4 *__restrict__ level, int64_t m, int64_t n_per_b, int s, const uint64_t *__restrict__ tkeys,
+                    const int32_t *__restrict__ tvals, uint64_t mask, const uint4 *__restrict__ bin,
+                    const int32_t *__restrict__ lo, const int32_t *__restrict__ hi, uint4 *__restrict__ bout,
+                    int32_t *__restrict__ range) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int4 c = level[i];
+  const int b = (int)(i / n_per_b);
+  if (range != nullptr) {
+    const bool out = c.y < lo[b * 3] || c.z < lo[b * 3 + 1] || c.w < lo[b * 3 + 2] || c.y > hi[b * 3] || c.z > hi[b * 3 + 1] ||
+                     c.w > hi[b * 3 + 2];
+    if (out) atomicOr(range, 1);
+  }
+  uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+  for (int dx = 0; dx < s; ++dx)
+    for (int dy = 0; dy < s; ++dy)
+      for (int dz = 0; dz < s; ++dz) {
+        const int x = c.y + dx, y = c.z + dy, z = c.w + dz;
+        if (!ph_packable(b, x, y, z)) continue;
+        const int r = ph_find(tkeys, tvals, mask, ph_pack(b, x, y, z));
+        if (r >= 0) {
+          const uint4 v = bin[r];
+          acc.x |= v.x; acc.y |= v.y; acc.z |= v.z; acc.w |= v.w;
+        }
+      }
+  bout[i] = acc;
+}
+
+extern "C" int ph_bits_block_or(const int32_t *level_coords, int64_t m, int64_t n_per_b, int32_t s, const uint64_t *tkeys,
+                                const int32_t *tvals, int64_t cap, const uint32_t *bits_in, const int32_t *lo,
+                                const int32_t *hi, uint32_t *bits_out, int32_t *range, ph_stream_t stream) {
+  PH_REQUIRE(s >= 1 && s <= 8 && n_per_b >= 1 && m >= 0, "bits_block_or: bad shape");
+  PH_REQUIRE(ph_is_pow2(cap), "bits_block_or: cap must be pow2");
+  PH_REQUIRE(range == nullptr || (lo != nullptr && hi != nullptr), "bits_block_or: range flag needs the bounds");
+  if (m == 0) return 0;
+  hipLaunchKernelGGL(k_bits_block_or, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ph_stream(stream),
+                     (const int4 *)level_coords, m, n_per_b, s, tkeys, tvals, (uint64_t)cap - 1, (const uint4 *)bits_in, lo, hi,
+                     (uint4 *)bits_out, range);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
 // any[b][w] = OR over the n rows of batch b (wave OR-reduction, one atomicOr per wave)
 __global__ void __launch_bounds__(256)
     k_bits_or_reduce(const uint32_t *__restrict__ bits, int64_t n, uint32_t *__restrict__ any) {

@@ -434,6 +434,27 @@ class TransformerPredictorV2(nn.Module):
         bits1 = bits1.reshape(B * P, 4)
         if uniq is not None:
             bits1 = be.gather_rows(bits1, uniq)
+        N = src_C.shape[1]
+        # Fast path: the level voxel's bits = OR over the fine voxels of its s^3 block, straight from the fine map's hash table
+        # (ph_bits_block_or) - no pooled map, no neighbour table, no dense-site map.  Exactly the reference's max-pool ->
+        # dense -> index whenever no coordinate lies outside the subnet's [min, max] box (then the reference's dense
+        # indexing wraps negative indices: the path below reproduces that); the test is made on the device and read once.
+        if be.has("bits_block_or") and os.environ.get("PASCO_MASK_BLOCK", "1") != "0":
+            if cache is not None and "bounds" in cache:
+                mn32, mx32, fine_bad = cache["bounds"]
+            else:
+                mn32 = torch.stack([torch.as_tensor(m) for m in min_Cs]).to(dev).to(torch.int32).contiguous()    # [B, 3]
+                mx32 = torch.stack([torch.as_tensor(m) for m in max_Cs]).to(dev).to(torch.int32).contiguous()
+                vc = voxel_coord.reshape(B, P, 4)[..., 1:].to(torch.int32)
+                fine_bad = ((vc < mn32[:, None]) | (vc > mx32[:, None])).any()
+                if cache is not None:
+                    cache["bounds"] = (mn32, mx32, fine_bad)
+            fine = mgr._maps[key1]
+            out, rng = be.bits_block_or(src_C.reshape(B * N, 4).to(torch.int32).contiguous(), N, src_scale, fine.tkeys,
+                                        fine.tvals, bits1.contiguous(), mn32, mx32, want_range=True)
+            if not bool(((rng != 0) | fine_bad).item()):
+                bits = out.reshape(B, N, 4)
+                return bits, be.bits_or_reduce(bits)
         if src_scale != 1:
             pool = self.max_pools[str(src_scale)]
             keyp = mgr.stride(key1, pool.stride)
@@ -441,7 +462,6 @@ class TransformerPredictorV2(nn.Module):
             pooled_bits = be.bits_orpool(bits1.contiguous(), nbr)
         else:
             keyp, pooled_bits = key1, bits1
-        N = src_C.shape[1]
         mn = torch.stack([torch.as_tensor(m) for m in min_Cs]).to(dev).to(torch.int64)   # [B,3]
         mx = torch.stack([torch.as_tensor(m) for m in max_Cs]).to(dev).to(torch.int64)
         size = torch.div(mx - mn, src_scale, rounding_mode="floor") + 1                   # dense extent per subnet

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "bits_orpool": [_vp, _vp, _i32, _i64, _vp, _vp],
     "bits_or_reduce": [_vp, _i64, _i32, _vp, _vp],
     "attn_cross_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
+    "bits_block_or": [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "ens_resample": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp],
     "ens_merge": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "ens_finish": [_vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp],
@@ -651,6 +652,23 @@ class CBackend:
         rc = self.fn["bits_orpool"](_ptr(bits), _ptr(nbr), kvol, n_out, _ptr(out), self.stream(bits.device))
         self._check(rc, "bits_orpool")
         return out
+
+    def bits_block_or(self, level_coords: torch.Tensor, n_per_b: int, s: int, tkeys, tvals, bits: torch.Tensor, lo=None,
+                      hi=None, want_range: bool = False):
+        """level_coords int32 [M, 4] (batch = row // n_per_b), fine-map table (tkeys, tvals) and its bit rows [N1, 4] ->
+        bits of the level voxels' s^3 blocks [M, 4] (+ a device flag word: some coordinate outside [lo, hi])."""
+        self._chk(level_coords, torch.int32, "level_coords")
+        self._chk(bits, torch.int32, "bits")
+        m = level_coords.shape[0]
+        out = torch.empty((m, 4), dtype=torch.int32, device=bits.device)
+        rng = torch.zeros(1, dtype=torch.int32, device=bits.device) if want_range else None
+        if want_range:
+            self._chk(lo, torch.int32, "lo")
+            self._chk(hi, torch.int32, "hi")
+        rc = self.fn["bits_block_or"](_ptr(level_coords), m, int(n_per_b), int(s), _ptr(tkeys), _ptr(tvals), tkeys.numel(),
+                                      _ptr(bits), _ptr(lo), _ptr(hi), _ptr(out), _ptr(rng), self.stream(bits.device))
+        self._check(rc, "bits_block_or")
+        return (out, rng) if want_range else out
 
     def bits_or_reduce(self, bits: torch.Tensor) -> torch.Tensor:
         """bits int32 [B, N, 4] -> OR over N: [B, 4]."""

@@ -146,3 +146,49 @@ def test_attn_cross_split_vs_oracle_and_peaked_scores(hip, oracle):
     assert torch.equal(ks.cpu(), ks_o)
     got = hip.attn_cross_split(q.cuda(), ks, vs, N, bits_o.cuda(), any_o.cuda()).cpu()
     assert torch.allclose(got, exp, rtol=2e-4, atol=1e-4), float((got - exp).abs().max())
+
+
+@pytest.mark.parametrize("s", [1, 2, 4])
+def test_bits_block_or_matches_oracle_and_pooling(hip, oracle, s):
+    """ph_bits_block_or: OR of the fine voxels' bit rows inside every level voxel's s^3 block = bits_orpool over the stride
+    map followed by a lookup of the level voxel (the path it replaces), and the oracle."""
+    g = torch.Generator().manual_seed(31 + s)
+    B, n1 = 2, 6000
+    fine = torch.cat([torch.randint(0, B, (n1, 1), generator=g), torch.randint(0, 40, (n1, 3), generator=g)], 1).int()
+    fine = torch.unique(fine, dim=0)
+    fine = fine[torch.randperm(fine.shape[0], generator=g)].contiguous()
+    bits1 = torch.randint(-2 ** 31, 2 ** 31 - 1, (fine.shape[0], 4), generator=g, dtype=torch.int64).int()
+    # level voxels: per batch the distinct block origins (in shuffled order) padded with (0, 0, 0) rows
+    per_b = []
+    for b in range(B):
+        org = torch.unique((fine[fine[:, 0] == b][:, 1:] // s) * s, dim=0)
+        per_b.append(org[torch.randperm(org.shape[0], generator=g)])
+    N = max(o.shape[0] for o in per_b) + 3
+    level = torch.zeros(B, N, 4, dtype=torch.int32)
+    for b, o in enumerate(per_b):
+        level[b, : o.shape[0], 1:] = o
+        level[b, :, 0] = b
+    lo = torch.zeros(B, 3, dtype=torch.int32)
+    hi = torch.full((B, 3), 39, dtype=torch.int32)
+    tko, tvo, *_ = oracle.map_insert(fine, dedup=False)
+    exp, rng_o = oracle.bits_block_or(level.reshape(-1, 4), N, s, tko, tvo, bits1, lo, hi, want_range=True)
+    tk, tv, *_ = hip.map_insert(fine.cuda(), dedup=False)
+    got, rng = hip.bits_block_or(level.reshape(-1, 4).cuda(), N, s, tk, tv, bits1.cuda(), lo.cuda(), hi.cuda(), want_range=True)
+    assert torch.equal(got.cpu(), exp) and int(rng.item()) == 0 and int(rng_o.item()) == 0
+    # brute force: OR over the block's fine voxels
+    ref = torch.zeros_like(exp)
+    for i, c in enumerate(level.reshape(-1, 4).tolist()):
+        b = i // N
+        inside = (fine[:, 0] == b) & ((fine[:, 1:] >= torch.tensor(c[1:])) & (fine[:, 1:] < torch.tensor(c[1:]) + s)).all(1)
+        if bool(inside.any()):
+            acc = bits1[inside][0].clone()
+            for row in bits1[inside][1:]:
+                acc |= row
+            ref[i] = acc
+        if i > 400:
+            break
+    assert torch.equal(exp[:402], ref[:402])
+    # a coordinate outside the box raises the flag
+    level[1, 0, 2] = -1
+    _, rng = hip.bits_block_or(level.reshape(-1, 4).cuda(), N, s, tk, tv, bits1.cuda(), lo.cuda(), hi.cuda(), want_range=True)
+    assert int(rng.item()) == 1

@@ -103,13 +103,14 @@ def test_s10_mimo3_split_path_vs_exact_fp32(hip, s10_net):
         close(a["query_logits"], b["query_logits"], f"query logits subnet {i}")
 
 
-@pytest.mark.parametrize("switch", ["PASCO_HEAD_ABSORB", "PASCO_ATTN_SPLIT", "PASCO_PE_TABLE", "PASCO_RESIZE_ABSORB"])
+@pytest.mark.parametrize("switch", ["PASCO_HEAD_ABSORB", "PASCO_ATTN_SPLIT", "PASCO_PE_TABLE", "PASCO_RESIZE_ABSORB", "PASCO_MASK_BLOCK"])
 def test_s10_transformer_restructurings_vs_plain_forms(hip, s10_net, switch, monkeypatch):
     """The algebraic restructurings of the mask transformer at the benchmark size, each against the form it replaces
     (the switch set to 0): mask heads absorbed into the level's features vs voxel features formed and multiplied
     (transformer_predictor_v2.py:143,150,202-218); attention on split K / V operands vs fp32 K / V; position encoding as
     table rows vs materialised; the decoder's `resize` (coordinate channels + BN + 1x1 convolution, decoder_v3.py:103,133)
-    absorbed into a product on the up-sampled features plus table rows vs the concatenated form."""
+    absorbed into a product on the up-sampled features plus table rows vs the concatenated form; attention-mask bits by block
+    lookups in the fine map vs max-pool map + dense-site map (transformer_predictor_v2.py:232-289)."""
     net, scene, teacher = s10_net
 
     def run():
