@@ -370,6 +370,14 @@ int PH_FN(ens_merge)(float *anchor, const float *m, const int32_t *perm, int64_t
 int PH_FN(ens_finish)(const float *anchor, int64_t u, int32_t q, const int32_t *keep, int32_t qk, const float *sem,
                       int32_t c, const int32_t *sel, float *out, uint8_t *flag, ph_stream_t stream);
 
+/* Canonical grid seen through a subnet's transform: for every site (x, y, z) of the X x Y x Z grid (lexicographic site id)
+ * the voxel index of T applied to its centre, as (0, x', y', z') rows: the reference's `transform` + `sample_scene`
+ * addressing (transform_utils.py:60-74,95-117): centre = site * resolution + resolution / 2 + min_bound in float64, cast to
+ * fp32, T (device, 3 x 4 leading rows of the 4 x 4, row-major) in fp32 with the sums in the order ((T0 x + T1 y) + T2 z) + T3,
+ * then (v - min_bound - resolution / 2) / resolution rounded half to even.  h_min_bound: 3 host floats. */
+int PH_FN(project_canonical)(const float *T, int32_t X, int32_t Y, int32_t Z, double resolution, const float *h_min_bound,
+                             int32_t *out_coords, ph_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

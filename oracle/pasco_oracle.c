@@ -875,3 +875,35 @@ int pho_bits_block_or(const int32_t *level_coords, int64_t m, int64_t n_per_b, i
   }
   return 0;
 }
+
+/* canonical sites through T (transform_utils.py:60-74): float64 centre -> fp32 -> fp32 affine, sums in the reference's order */
+int pho_project_canonical(const float *T, int32_t X, int32_t Y, int32_t Z, double resolution, const float *h_min_bound,
+                          int32_t *out_coords, ph_stream_t stream) {
+  (void)stream;
+  if (X < 1 || Y < 1 || Z < 1 || !(resolution > 0)) return fail("project_canonical: bad grid");
+  const float resf = (float)resolution, halff = (float)(resolution / 2);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)X * Y * Z; ++i) {
+    const int c[3] = {(int)(i / ((int64_t)Y * Z)), (int)((i / Z) % Y), (int)(i % Z)};
+    float p[3];
+    for (int a = 0; a < 3; ++a) {
+      volatile double m = (double)c[a] * resolution;
+      volatile double h = m + resolution / 2;
+      p[a] = (float)(h + (double)h_min_bound[a]);
+    }
+    out_coords[4 * i] = 0;
+    for (int r = 0; r < 3; ++r) {
+      volatile float t0 = T[r * 4 + 0] * p[0];
+      volatile float t1 = T[r * 4 + 1] * p[1];
+      volatile float v = t0 + t1;
+      volatile float t2 = T[r * 4 + 2] * p[2];
+      v = v + t2;
+      v = v + T[r * 4 + 3];
+      v = v - h_min_bound[r];
+      v = v - halff;
+      v = v / resf;
+      out_coords[4 * i + 1 + r] = (int32_t)rintf(v);
+    }
+  }
+  return 0;
+}

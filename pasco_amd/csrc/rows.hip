@@ -464,3 +464,53 @@ extern "C" int ph_ens_finish(const float *anchor, int64_t u, int32_t q, const in
   PH_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- canonical voxel centres seen through a subnet's transform (transform_utils.py:60-74; graph/ensemble.py) ---------------
+// site id -> (x, y, z) of the X x Y x Z grid (lexicographic) -> metres (float64 affine, as the reference's numpy grid) ->
+// fp32 -> T (3 x 4, row-major, fp32 products and sums in the reference's order, no fused multiply-add) -> voxel index
+// (round half to even).  One thread per site; out[i] = (0, x', y', z').
+__global__ void __launch_bounds__(256)
+    k_project_canonical(const float *__restrict__ T, int X, int Y, int Z, double res, float mb0, float mb1, float mb2,
+                        int4 *__restrict__ out) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = (int64_t)X * Y * Z;
+  if (i >= n) return;
+  const int z = (int)(i % Z), y = (int)((i / Z) % Y), x = (int)(i / ((int64_t)Y * Z));
+  const float mb[3] = {mb0, mb1, mb2};
+  const int c[3] = {x, y, z};
+  float p[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double m = (double)c[a] * res;
+    const double h = m + res / 2;
+    p[a] = (float)(h + (double)mb[a]);
+  }
+  const float resf = (float)res, halff = (float)(res / 2);
+  int q[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float t0 = T[r * 4 + 0] * p[0];
+    const float t1 = T[r * 4 + 1] * p[1];
+    float v = t0 + t1;
+    const float t2 = T[r * 4 + 2] * p[2];
+    v = v + t2;
+    v = v + T[r * 4 + 3];
+    v = v - mb[r];
+    v = v - halff;
+    v = v / resf;
+    q[r] = (int)rintf(v);
+  }
+  out[i] = make_int4(0, q[0], q[1], q[2]);
+}
+
+extern "C" int ph_project_canonical(const float *T, int32_t X, int32_t Y, int32_t Z, double resolution, const float *h_min_bound,
+                                    int32_t *out_coords, ph_stream_t stream) {
+  PH_REQUIRE(X >= 1 && Y >= 1 && Z >= 1 && resolution > 0, "project_canonical: bad grid");
+  PH_REQUIRE(T && h_min_bound && out_coords, "project_canonical: null buffer");
+  const int64_t n = (int64_t)X * Y * Z;
+  hipLaunchKernelGGL(k_project_canonical, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ph_stream(stream), T, X, Y, Z,
+                     resolution, h_min_bound[0], h_min_bound[1], h_min_bound[2], (int4 *)out_coords);
+  PH_LAUNCH_CHECK();
+  return 0;
+}

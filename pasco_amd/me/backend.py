@@ -89,6 +89,7 @@ _SIGNATURES = {
     "bits_or_reduce": [_vp, _i64, _i32, _vp, _vp],
     "attn_cross_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp],
     "bits_block_or": [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "project_canonical": [_vp, _i32, _i32, _i32, C.c_double, _vp, _vp, _vp],
     "ens_resample": [_vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _vp],
     "ens_merge": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "ens_finish": [_vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp],
@@ -753,6 +754,19 @@ class CBackend:
 
 
     # ---- panoptic ensembling rows (include/pasco_hip.h ens_*) ----------------------------------------------------------
+    def project_canonical(self, T: torch.Tensor, size, resolution: float, min_bound) -> torch.Tensor:
+        """-> int32 [X*Y*Z, 4] = (0, voxel index of T applied to the centre of every site of the size grid)."""
+        T = T.to(dtype=torch.float32).contiguous()
+        if T.device.type != self.device_type:
+            raise ValueError(f"T on {T.device}, backend serves {self.device_type}")
+        assert T.shape[-1] == 4 and T.shape[0] >= 3
+        x, y, z = (int(v) for v in size)
+        out = torch.empty((x * y * z, 4), dtype=torch.int32, device=T.device)
+        mb = (C.c_float * 3)(*[float(v) for v in min_bound])
+        rc = self.fn["project_canonical"](_ptr(T), x, y, z, float(resolution), C.cast(mb, _vp), _ptr(out), self.stream(T.device))
+        self._check(rc, "project_canonical")
+        return out
+
     def ens_resample(self, logits: torch.Tensor, rows: torch.Tensor, sel: torch.Tensor):
         """-> (probs [U, Q], flag uint8 [U]): sigmoid of the subnet's voxel logits resampled on the union sites `sel`
         (int32 canonical site ids) through `rows` (int32 [n_sites], -1 = no voxel -> zero row)."""

@@ -370,3 +370,21 @@ def test_nbr_build_same_map_equals_plain_build(hip, oracle, ks, dil, n):
     tko, tvo, *_ = oracle.map_insert(c, dedup=False)
     assert torch.equal(same.cpu(), oracle.nbr_build(c, tko, tvo, offs, same_map=True))
     assert bool((same[len(offs) // 2].cpu() == torch.arange(c.shape[0])).all())
+
+
+def test_project_canonical_matches_oracle_bit_for_bit(hip, oracle):
+    """ph_project_canonical: the canonical grid through a subnet's transform (transform_utils.py:60-74), same integers as
+    the C restatement (which equals the torch formula: tests/test_oracle_properties.py) on the full 256 x 256 x 32 grid."""
+    import numpy as np
+    from pasco_amd.graph.ensemble import CANONICAL_SIZE, MIN_BOUND, RESOLUTION
+    g = torch.Generator().manual_seed(8)
+    for k in range(4):
+        th = float(torch.rand(1, generator=g)) * 6.28
+        T = torch.eye(4)
+        T[0, 0], T[0, 1], T[1, 0], T[1, 1] = np.cos(th), -np.sin(th), np.sin(th), np.cos(th)
+        if k % 2:
+            T[0] = -T[0]
+        T[:3, 3] = torch.randn(3, generator=g) * 2
+        exp = oracle.project_canonical(T, CANONICAL_SIZE, RESOLUTION, MIN_BOUND)
+        got = hip.project_canonical(T.cuda(), CANONICAL_SIZE, RESOLUTION, MIN_BOUND).cpu()
+        assert torch.equal(got, exp)

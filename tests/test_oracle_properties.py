@@ -145,3 +145,22 @@ def test_coordinates_outside_the_key_range_are_flagged_not_aliased(oracle):
     offs = [(1, 0, 0), (-1, 0, 0), (0, 0, 0)]
     nbr = oracle.nbr_build(edge, tk, tv, offs)
     assert nbr.tolist() == [[-1, -1], [-1, -1], [0, 1]]
+
+
+def test_project_canonical_kernel_restatement_equals_the_torch_formula(oracle):
+    """pho_project_canonical (the restatement the HIP kernel is checked against) = graph/ensemble.py::project_canonical, the
+    reference's `transform` (transform_utils.py:60-74), bit for bit on rotated / translated / flipped transforms."""
+    from pasco_amd.graph.ensemble import MIN_BOUND, RESOLUTION, canonical_sites, project_canonical
+    size = (40, 36, 12)
+    sites = canonical_sites(size, torch.device("cpu"))
+    g = torch.Generator().manual_seed(3)
+    for k in range(6):
+        th = float(torch.rand(1, generator=g)) * 6.28
+        T = torch.eye(4)
+        T[0, 0], T[0, 1], T[1, 0], T[1, 1] = np.cos(th), -np.sin(th), np.sin(th), np.cos(th)
+        if k % 2:
+            T[1] = -T[1]
+        T[:3, 3] = torch.randn(3, generator=g) * 3
+        exp = project_canonical(sites, T)
+        got = oracle.project_canonical(T, size, RESOLUTION, MIN_BOUND)
+        assert torch.equal(got[:, 1:], exp) and bool((got[:, 0] == 0).all())
