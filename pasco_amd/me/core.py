@@ -60,13 +60,32 @@ class CoordinateMapKey:
 
 
 class _CoordMap:
-    __slots__ = ("coords", "tkeys", "tvals", "n")
+    """Rows of a coordinate map + its hash table.  Maps of coordinates that are unique by construction (prune results,
+    ensembler outputs) get their table on the first lookup: most of them are never looked up (their tensors only pass
+    through 1x1 convolutions or are returned), and a hash build of a few hundred thousand rows is ~0.1 ms each."""
+    __slots__ = ("coords", "_tkeys", "_tvals", "n", "_build")
 
-    def __init__(self, coords, tkeys, tvals):
+    def __init__(self, coords, tkeys, tvals, build=None):
         self.coords = coords
-        self.tkeys = tkeys
-        self.tvals = tvals
+        self._tkeys = tkeys
+        self._tvals = tvals
+        self._build = build
         self.n = coords.shape[0]
+
+    def _table(self):
+        if self._tkeys is None:
+            self._tkeys, self._tvals = self._build(self.coords)
+            self._build = None
+
+    @property
+    def tkeys(self):
+        self._table()
+        return self._tkeys
+
+    @property
+    def tvals(self):
+        self._table()
+        return self._tvals
 
 
 def kernel_offsets(kernel_size, tensor_stride, dilation=1, transposed=False) -> List[Tuple[int, int, int]]:
@@ -140,8 +159,13 @@ class CoordinateManager:
         if self.device is None:
             self.device = coords.device
         coords = coords.to(torch.int32).contiguous()
-        tkeys, tvals, _, _, _ = self.backend().map_insert(coords, dedup=False)
-        return self._register(coords, tkeys, tvals, tensor_stride)
+        be = self.backend()
+        if be.device_type != "cuda":      # the CPU checker verifies the caller's uniqueness promise at once
+            tkeys, tvals, _, _, _ = be.map_insert(coords, dedup=False)
+            return self._register(coords, tkeys, tvals, tensor_stride)
+        key = self._register(coords, None, None, tensor_stride)
+        self._maps[key]._build = lambda c: be.map_insert(c, dedup=False)[:2]
+        return key
 
     def stride(self, in_key: CoordinateMapKey, stride) -> CoordinateMapKey:
         s = _triple(stride)
