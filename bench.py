@@ -318,7 +318,7 @@ def main():
     ap.add_argument("--n-classes", type=int, default=20)
     ap.add_argument("--heavy", action="store_true")
     ap.add_argument("--scenes", type=int, default=4, help="different scenes the timed loop rotates over")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="scenes in flight per GPU: worker threads, each with its own HIP stream, take the steps from a shared "
                          "counter (a step's ~60 host synchronisations then overlap with the other scene's kernels); 1 = one "
                          "scene at a time, also measured and reported as `in_flight_1`")
