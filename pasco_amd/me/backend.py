@@ -149,8 +149,13 @@ class CBackend:
             raise RuntimeError(f"{self.prefix}{name} failed ({rc}): {msg.decode() if msg else ''}")
 
     def stream(self, device: torch.device) -> Optional[int]:
+        """Raw handle of torch's current stream on `device` (every launch goes there).  ~430 calls per step: the raw getter
+        (0.3 us) instead of building a torch.cuda.Stream object (4 us)."""
         if device.type == "cuda":
-            return torch.cuda.current_stream(device).cuda_stream
+            idx = device.index
+            if idx is None:
+                idx = torch.cuda.current_device()
+            return _raw_stream(idx)
         return None
 
     def _stream_key(self, device: torch.device):
@@ -807,6 +812,12 @@ class CBackend:
                                    self.stream(anchor.device))
         self._check(rc, "ens_finish")
         return out, flag
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+if _raw_stream is None:      # older torch: the public (slower) route
+    def _raw_stream(idx: int) -> int:
+        return torch.cuda.current_stream(idx).cuda_stream
 
 
 # ---- registry -----------------------------------------------------------------------------------
