@@ -37,19 +37,104 @@ __device__ __forceinline__ uint32_t win_hash(uint32_t k) {
   return k;
 }
 
-// one workgroup per 128-row tile
+// one workgroup per 128-row tile.  Fast path: the tile's input rows span < 2^18 consecutive indices (octree-ordered maps:
+// median span 44 k on the 683 k-row map) -> a bitmap of the span in LDS; the rank of an index = set bits below it (word
+// prefix sums + popcount): no hash probes, no sort.  Wider spans (maps without locality) take the hash set + bitonic sort.
 __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ nbr, int64_t n_out, int32_t *__restrict__ win_rows,
                                                      int32_t *__restrict__ win_cnt, uint16_t *__restrict__ slots,
                                                      int32_t *__restrict__ stats, int wmax_a, int wmax_b) {
-  constexpr int HT = 8192;                       // hash slots (>= 2 x WIN_CAP)
-  __shared__ int32_t keys[HT];
-  __shared__ int32_t uniq[4096];
-  __shared__ int32_t count;
+  constexpr int HT = 8192;                       // hash slots (>= 2 x WIN_CAP) = bitmap words of the fast path
+  constexpr int SPAN_MAX = HT * 32;              // 262 144 indices
+  __shared__ int32_t keys[HT];                   // hash keys | bitmap words
+  __shared__ int32_t uniq[4096];                 // distinct rows (sort path) | word prefix sums (bitmap path: 8192 u16 halves)
+  __shared__ int32_t count, s_min, s_max;
+  __shared__ int32_t wsum[256];
   const int tid = threadIdx.x;
   const int64_t tile = blockIdx.x;
   const int64_t m0 = tile * WIN_BM;
+  if (tid == 0) {
+    count = 0;
+    s_min = 0x7FFFFFFF;
+    s_max = -1;
+  }
+  __syncthreads();
+  {   // index span of the tile
+    int lo = 0x7FFFFFFF, hi = -1;
+    for (int e = tid; e < WIN_CAP; e += 256) {
+      const int k = e / WIN_BM, r = e - k * WIN_BM;
+      const int64_t row = m0 + r;
+      const int idx = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+      if (idx >= 0) {
+        lo = idx < lo ? idx : lo;
+        hi = idx > hi ? idx : hi;
+      }
+    }
+    if (hi >= 0) {
+      atomicMin(&s_min, lo);
+      atomicMax(&s_max, hi);
+    }
+  }
+  __syncthreads();
+  const int base = s_min, top = s_max;
+  int32_t *wr = win_rows + tile * WIN_CAP;
+  uint16_t *sl = slots + tile * WIN_CAP;
+  if (top < 0 || top - base < SPAN_MAX) {
+    // ---- bitmap path ---------------------------------------------------------------------------------------------------
+    const int nwords = top < 0 ? 0 : ((top - base) >> 5) + 1;
+    for (int i = tid; i < nwords; i += 256) keys[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < WIN_CAP; e += 256) {
+      const int k = e / WIN_BM, r = e - k * WIN_BM;
+      const int64_t row = m0 + r;
+      const int idx = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+      if (idx >= 0) atomicOr(&keys[(idx - base) >> 5], 1 << ((idx - base) & 31));
+    }
+    __syncthreads();
+    // exclusive prefix of the word popcounts: thread t owns words [t * per, (t + 1) * per)
+    const int per = (nwords + 255) / 256;
+    int mine = 0;
+    for (int w = tid * per; w < (tid + 1) * per && w < nwords; ++w) mine += __popc((unsigned)keys[w]);
+    wsum[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {           // Hillis-Steele inclusive scan over the 256 partial sums
+      const int v = tid >= d ? wsum[tid - d] : 0;
+      __syncthreads();
+      wsum[tid] += v;
+      __syncthreads();
+    }
+    const int cnt = wsum[255];
+    int run = wsum[tid] - mine;                   // exclusive prefix of this thread's first word
+    uint16_t *pre = reinterpret_cast<uint16_t *>(uniq);     // prefix per word (cnt <= 3456 fits 16 bits)
+    for (int w = tid * per; w < (tid + 1) * per && w < nwords; ++w) {
+      pre[w] = (uint16_t)run;
+      unsigned bits = (unsigned)keys[w];
+      while (bits) {                              // the distinct rows in ascending order
+        const int b = __ffs(bits) - 1;
+        wr[run++] = base + (w << 5) + b;
+        bits &= bits - 1;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      win_cnt[tile] = cnt;
+      atomicAdd(&stats[0], cnt > 0 ? (cnt + wmax_a - 1) / wmax_a : 1);
+      atomicAdd(&stats[1], cnt > 0 ? (cnt + wmax_b - 1) / wmax_b : 1);
+    }
+    for (int e = tid; e < WIN_CAP; e += 256) {
+      const int k = e / WIN_BM, r = e - k * WIN_BM;
+      const int64_t row = m0 + r;
+      const int idx = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+      uint16_t s = 0xFFFFu;
+      if (idx >= 0) {
+        const int off = idx - base, w = off >> 5;
+        s = (uint16_t)(pre[w] + __popc((unsigned)keys[w] & ((1u << (off & 31)) - 1u)));
+      }
+      sl[e] = s;
+    }
+    return;
+  }
+  // ---- hash set + bitonic sort (maps without locality) -------------------------------------------------------------------
   for (int i = tid; i < HT; i += 256) keys[i] = -1;
-  if (tid == 0) count = 0;
   __syncthreads();
   // distinct input rows of the tile: LDS hash set, first inserter appends
   for (int e = tid; e < WIN_CAP; e += 256) {
@@ -90,7 +175,6 @@ __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ n
       }
       __syncthreads();
     }
-  int32_t *wr = win_rows + tile * WIN_CAP;
   for (int i = tid; i < cnt; i += 256) wr[i] = uniq[i];
   if (tid == 0) {
     win_cnt[tile] = cnt;
@@ -98,7 +182,6 @@ __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ n
     atomicAdd(&stats[1], cnt > 0 ? (cnt + wmax_b - 1) / wmax_b : 1);
   }
   // slot of every (offset, row) entry: rank of its input row in the sorted list
-  uint16_t *sl = slots + tile * WIN_CAP;
   for (int e = tid; e < WIN_CAP; e += 256) {
     const int k = e / WIN_BM, r = e - k * WIN_BM;
     const int64_t row = m0 + r;

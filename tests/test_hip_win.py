@@ -53,6 +53,22 @@ def test_win_build_matches_oracle(hip, oracle, n):
         assert torch.equal(wh["rows"][t, : int(cnt[t])].cpu(), wo["rows"][t, : int(cnt[t])])
 
 
+@pytest.mark.parametrize("n_rows,span", [(1000, 5000), (1000, 300000), (700, 262143), (700, 262145), (300, 4000000)])
+def test_win_build_index_spans_on_both_paths(hip, oracle, n_rows, span):
+    """ph_win_build on synthetic neighbour tables whose tiles span few or very many input rows: below 2^18 indices per
+    tile the bitmap / popcount path builds the window, beyond it the hash set + sort - same tables either way (oracle)."""
+    g = torch.Generator().manual_seed(span % 1000 + n_rows)
+    nbr = torch.randint(0, span, (27, n_rows), generator=g).int()
+    nbr[torch.rand(27, n_rows, generator=g) < 0.3] = -1
+    nbr[:, 5] = -1                                   # a row without neighbours
+    nbr[0, 0], nbr[1, 0] = 0, span - 1               # the full span inside the first tile
+    wo, wh = oracle.win_build(nbr), hip.win_build(nbr.cuda())
+    assert torch.equal(wh["cnt"].cpu(), wo["cnt"]) and torch.equal(wh["stats"].cpu(), wo["stats"])
+    assert torch.equal(wh["slots"].cpu(), wo["slots"])
+    for t in range(wo["cnt"].shape[0]):
+        assert torch.equal(wh["rows"][t, : int(wo["cnt"][t])].cpu(), wo["rows"][t, : int(wo["cnt"][t])])
+
+
 def _conv_case(hip, nbr, cin, cout, g, emit=False):
     n = nbr.shape[1]
     x = torch.randn(n, cin, device="cuda", generator=g) * torch.exp(torch.randn(n, 1, device="cuda", generator=g))
