@@ -377,6 +377,10 @@ def main():
     import threading
 
     streams = [torch.cuda.Stream(device=device) for _ in range(max(args.in_flight, 1))]
+    if args.in_flight > 1:
+        # worker threads hand the interpreter over every 0.5 ms instead of every 5 ms: a scene whose stream has run dry gets
+        # to enqueue sooner (PASCO_BENCH_SWITCH_MS overrides)
+        sys.setswitchinterval(float(os.environ.get("PASCO_BENCH_SWITCH_MS", "0.5")) * 1e-3)
 
     def run_steps(first, count, in_flight, window=None, marks=None):
         """Steps first .. first + count - 1 (scene = step mod #scenes).  in_flight == 1: on the current stream, one after the
