@@ -198,6 +198,15 @@ typedef struct ph_conv_desc {
   const int32_t *axis_coords;
   int32_t axis_lo;
   int32_t axis_rows;
+  /* Row lists of a kernel map in which every output row has exactly ONE (offset, input row) pair - the generative transposed
+   * convolutions (mink.py:524-527).  rl_in / rl_out [rl_rows] from ph_rowlist_pack: position i of the list pairs input row
+   * rl_in[i] with output row rl_out[i] (-1 = padding); tile t (128 positions) belongs to kernel offset rl_tile_k[t] (-1 =
+   * unused tile).  With them (mma_mode 2) the launch is a set of k = 1 products, one per 128-position tile, instead of a walk
+   * over all kvol offsets with kvol - 1 empty entries per row; `nbr` still describes the same map (and is what a checker
+   * reads).  NULL = not given. */
+  const int32_t *rl_in, *rl_out, *rl_tile_k;
+  int64_t rl_rows;
+  int32_t rl_tiles;       /* entries of rl_tile_k (an upper bound of the used tiles) */
 } ph_conv_desc;
 
 int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);
@@ -377,6 +386,11 @@ int PH_FN(ens_finish)(const float *anchor, int64_t u, int32_t q, const int32_t *
  * then (v - min_bound - resolution / 2) / resolution rounded half to even.  h_min_bound: 3 host floats. */
 int PH_FN(project_canonical)(const float *T, int32_t X, int32_t Y, int32_t Z, double resolution, const float *h_min_bound,
                              int32_t *out_coords, ph_stream_t stream);
+
+/* COO kernel map (ph_kmap_compact) -> the padded row lists of ph_conv_desc.rl_*: cap = rl_rows (multiple of 128, >= n_out +
+ * 127 * kvol rounded up), tcap = entries of tile_k (>= cap / 128).  Counts stay on the device. */
+int PH_FN(rowlist_pack)(const int32_t *pairs_in, const int32_t *pairs_out, const int32_t *counts, int32_t kvol, int64_t n_out,
+                        int32_t *rl_in, int32_t *rl_out, int32_t *tile_k, int64_t cap, int64_t tcap, ph_stream_t stream);
 
 #ifdef __cplusplus
 }

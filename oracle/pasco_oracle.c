@@ -907,3 +907,24 @@ int pho_project_canonical(const float *T, int32_t X, int32_t Y, int32_t Z, doubl
   }
   return 0;
 }
+
+/* padded row lists of a kernel map given in COO form (one list segment per offset, 128-aligned) */
+int pho_rowlist_pack(const int32_t *pairs_in, const int32_t *pairs_out, const int32_t *counts, int32_t kvol, int64_t n_out,
+                     int32_t *rl_in, int32_t *rl_out, int32_t *tile_k, int64_t cap, int64_t tcap, ph_stream_t stream) {
+  (void)stream;
+  if (kvol < 1 || kvol > PH_MAX_KVOL || cap % 128 != 0 || tcap * 128 < cap) return fail("rowlist_pack: bad shape");
+  int64_t pos = 0;
+  for (int64_t i = 0; i < cap; ++i) rl_in[i] = rl_out[i] = -1;
+  for (int64_t t = 0; t < tcap; ++t) tile_k[t] = -1;
+  for (int k = 0; k < kvol; ++k) {
+    const int64_t padded = ((int64_t)counts[k] + 127) / 128 * 128;
+    if (pos + padded > cap) return fail("rowlist_pack: list capacity too small");
+    for (int64_t j = 0; j < counts[k]; ++j) {
+      rl_in[pos + j] = pairs_in[(int64_t)k * n_out + j];
+      rl_out[pos + j] = pairs_out[(int64_t)k * n_out + j];
+    }
+    for (int64_t t = pos / 128; t < (pos + padded) / 128; ++t) tile_k[t] = k;
+    pos += padded;
+  }
+  return 0;
+}

@@ -77,9 +77,14 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
   const int cout = a.cout;
   const int nchunks = a.cpad >> 5;
   const int kper = (a.kvol + a.ksplit - 1) / a.ksplit;
-  const int k_begin = (int)blockIdx.y * kper;
+  int k_begin = (int)blockIdx.y * kper;
   const int k_end = (k_begin + kper < a.kvol) ? k_begin + kper : a.kvol;
-  const int kcount = k_end > k_begin ? k_end - k_begin : 0;
+  int kcount = k_end > k_begin ? k_end - k_begin : 0;
+  if (a.tile_k != nullptr) {          // row lists: this row tile is ONE kernel offset's k = 1 product (-1: unused tile)
+    k_begin = a.tile_k[row_tile];
+    if (k_begin < 0) return;
+    kcount = 1;
+  }
   const int nstages = kcount * nchunks;
   const uint32_t rsb = 4u * (uint32_t)a.cpad;   // bytes per operand row
 
@@ -99,7 +104,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
       const int k = i / BM, r = i - k * BM;
       const int64_t row = m0 + r;
       int idx = -1;
-      if (row < a.n_out) idx = a.nbr ? a.nbr[(int64_t)(k_begin + k) * a.n_out + row] : (int)row;
+      if (row < a.n_out) idx = a.tile_k ? a.nbr[row] : (a.nbr ? a.nbr[(int64_t)(k_begin + k) * a.n_out + row] : (int)row);
       idx_lds[k * BM + (r % RPP) * 4 + (r / RPP)] = idx;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

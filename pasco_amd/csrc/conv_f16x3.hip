@@ -597,6 +597,7 @@ struct ConvHKnobs {
   bool dma_all = false;
   bool win_on = true;      // PASCO_CONV_WIN=0: no LDS-window kernel
   bool win_wide = false;   // PASCO_CONV_WIN=2: also on 128-wide tiles
+  bool rl_on = true;       // PASCO_CONV_RL=0: ignore row lists (walk all offsets of one-pair maps)
   bool win256 = false;     // PASCO_CONV_WIN256=1: 256-wide window workgroups for 256-channel layers (measured: 568 vs 547 us
                            // for the gather kernel once its DMA is issued between the MFMAs)
   bool dma_on = true;      // PASCO_CONV_DMA=0: keep every launch on the register-staged k_conv_h2 (A/B comparisons)
@@ -610,6 +611,7 @@ struct ConvHKnobs {
       win_on = atoi(e) != 0;
       win_wide = atoi(e) == 2;
     }
+    if (const char *e = getenv("PASCO_CONV_RL")) rl_on = atoi(e) != 0;
     if (const char *e = getenv("PASCO_CONV_WIN256")) win256 = atoi(e) != 0;
     if (const char *e = getenv("PASCO_CONVH_CFG")) has_cfg = sscanf(e, "%d,%d", &cfg_bm, &cfg_kc) >= 1;
     if (const char *e = getenv("PASCO_CONVH_KSPLIT")) {
@@ -698,6 +700,8 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.status = d->status;
   a.zero = nullptr;
   a.ablate = 0;
+  a.out_rows = nullptr;
+  a.tile_k = nullptr;
   a.win_rows = d->win_rows;
   a.win_cnt = d->win_cnt;
   a.win_slots = d->win_slots;
@@ -747,6 +751,22 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
       a.ksplit = want;
       a.partial = (float *)d->splitk_ws;
     }
+  }
+  // one-pair-per-row maps with row lists (generative transposed convolutions): every 128-position tile of the list is the
+  // k = 1 product of one kernel offset; outputs go to the rows the list names
+  if (pre && !env && d->rl_in && d->rl_out && d->rl_tile_k && d->rl_rows > 0 && knobs.rl_on && (bn == 64 || bn == 128)) {
+    ConvArgsH b = a;
+    b.nbr = d->rl_in;
+    b.out_rows = d->rl_out;
+    b.tile_k = d->rl_tile_k;
+    b.n_out = d->rl_rows;
+    b.ksplit = 1;
+    b.partial = nullptr;
+    b.win_stats = nullptr;
+    b.win_gather = 0;
+    const int rc = ph_conv_dma_try(b, bn, st);
+    if (rc == 0) ph_record_cfg(2, 128, bn, 32, 1, a.out_split != nullptr ? 1 : 0, 3, 4);
+    if (rc >= 0) return rc;
   }
   // 3x3x3 convolutions on big maps with window tables: launch the window kernel AND the gather kernel below; the
   // device-side predicate (window passes per tile, ph_win_build) lets exactly one of them do the work.  Only where no

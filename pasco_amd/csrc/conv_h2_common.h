@@ -52,6 +52,8 @@ struct ConvArgsH {
   const float *axis_table;
   const int32_t *axis_coords;
   int axis_lo, axis_rows;
+  // row lists (ph_conv_desc.rl_*): output row of tile row r = out_rows[r] (-1 = padding), kernel offset of row tile t = tile_k[t]
+  const int32_t *out_rows, *tile_k;
   int par_vec;                // every per-channel vector (bias, epi*, osp*) is 16-byte aligned: the epilogue loads them as float4
 };
 
@@ -185,15 +187,22 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
     return;
   }
 
+  // output row of each of this lane's tile rows (-1: beyond the map / list padding); row lists name it explicitly
+  int64_t orow[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t r = m0 + (wm * TM + i) * 32 + l31;
+    orow[i] = r < a.n_out ? (a.out_rows ? (int64_t)a.out_rows[r] : r) : -1;
+  }
   // table residual: the three table rows of each of this lane's rows, found once per tile (or by the caller: axis_pre)
   int64_t axis_off[TM][3];
   if (a.axis_table && axis_vals == nullptr) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int64_t row = m0 + (wm * TM + i) * 32 + l31;
+      const int64_t row = orow[i];
       if (axis_pre) {
         axis_off[i][0] = axis_pre[i][0]; axis_off[i][1] = axis_pre[i][1]; axis_off[i][2] = axis_pre[i][2];
-      } else if (row < a.n_out) {
+      } else if (row >= 0) {
         if (ph_axis_offsets(a, row, axis_off[i]) && a.status != nullptr) atomicOr(a.status, 4);
       } else {
         axis_off[i][0] = axis_off[i][1] = axis_off[i][2] = 0;
@@ -239,8 +248,8 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int64_t row = m0 + (wm * TM + i) * 32 + l31;
-        const bool rok = row < a.n_out;
+        const int64_t row = orow[i];
+        const bool rok = row >= 0;
         float v[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {

@@ -415,3 +415,55 @@ extern "C" int ph_kmap_compact(const int32_t *nbr, int32_t kvol, int64_t n_out, 
                      counts, ws, ws_bytes, ph_stream(stream));
 }
 
+
+// ---- row lists of a one-pair-per-row kernel map (generative transposed convolutions) -----------------------------------------
+// From the COO form (ph_kmap_compact: pairs_in / pairs_out [K, n_out], counts [K]) to one padded list: the pairs of offset k
+// occupy positions [off_k, off_k + counts[k]), off_k = sum_{j<k} roundup128(counts[j]); padding holds -1; tile t (128
+// positions) belongs to offset tile_k[t] (-1 beyond the last tile).  Everything is sized by upper bounds, the counts stay
+// on the device.
+__global__ void __launch_bounds__(256)
+    k_rowlist_pack(const int32_t *__restrict__ pairs_in, const int32_t *__restrict__ pairs_out, const int32_t *__restrict__ counts,
+                   int kvol, int64_t n_out, int32_t *__restrict__ rl_in, int32_t *__restrict__ rl_out,
+                   int32_t *__restrict__ tile_k, int64_t cap, int64_t tcap) {
+  __shared__ int64_t off[PH_MAX_KVOL + 1];
+  if (threadIdx.x == 0) {
+    int64_t o = 0;
+    for (int k = 0; k < kvol; ++k) {
+      off[k] = o;
+      o += ((int64_t)counts[k] + 127) / 128 * 128;
+    }
+    off[kvol] = o;
+  }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride) {
+    int k = 0;
+    while (k < kvol && i >= off[k + 1]) ++k;
+    int vi = -1, vo = -1;
+    if (k < kvol) {
+      const int64_t j = i - off[k];
+      if (j < counts[k]) {
+        vi = pairs_in[(int64_t)k * n_out + j];
+        vo = pairs_out[(int64_t)k * n_out + j];
+      }
+    }
+    rl_in[i] = vi;
+    rl_out[i] = vo;
+    if ((i & 127) == 0 && (i >> 7) < tcap) tile_k[i >> 7] = k < kvol ? k : -1;
+  }
+}
+
+extern "C" int ph_rowlist_pack(const int32_t *pairs_in, const int32_t *pairs_out, const int32_t *counts, int32_t kvol,
+                               int64_t n_out, int32_t *rl_in, int32_t *rl_out, int32_t *tile_k, int64_t cap, int64_t tcap,
+                               ph_stream_t stream) {
+  PH_REQUIRE(kvol >= 1 && kvol <= PH_MAX_KVOL, "rowlist_pack: kvol=%d out of range", kvol);
+  PH_REQUIRE(cap % 128 == 0 && cap >= n_out + (int64_t)kvol * 127 - (kvol * 127) % 128 && tcap * 128 >= cap,
+             "rowlist_pack: list capacity %lld too small for %lld rows and %d offsets", (long long)cap, (long long)n_out, kvol);
+  if (cap == 0) return 0;
+  int64_t blocks = (cap + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_rowlist_pack, dim3((unsigned)blocks), dim3(256), 0, ph_stream(stream), pairs_in, pairs_out, counts, kvol,
+                     n_out, rl_in, rl_out, tile_k, cap, tcap);
+  PH_LAUNCH_CHECK();
+  return 0;
+}

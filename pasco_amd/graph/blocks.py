@@ -95,7 +95,7 @@ class BasicGenerativeDeconvolutionBlock(nn.Module):
     def forward(self, x, out_key=None, nbr=None, emit_next=None, split_only=False):
         return fused.conv(x, self.net[0], epi_bn=self.net[1], epi_act=ACT_LEAKY,
                           slope=self.net[2].module.negative_slope, out_key=out_key, nbr=nbr, emit_next=emit_next,
-                          split_only=split_only)
+                          split_only=split_only, one_pair=True)     # every child has exactly its one parent
 
 
 def first_prologue(seq: nn.Sequential):

@@ -325,7 +325,7 @@ def _split_key(F, ps, pb, pro_act, slope):
 def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NONE, epi_bn=None,
          epi_act: int = ACT_NONE, epi2_bn=None, residual: Optional[torch.Tensor] = None,
          res_act: int = ACT_NONE, slope: float = 0.01, out_key=None, nbr=None, emit_next=None,
-         split_only: bool = False):
+         split_only: bool = False, one_pair: bool = False):
     """One fused launch of a Minkowski-style convolution module on `x`.
 
     out = act_res( act_epi(BN_epi(conv(act_pro(BN_pro(x))) + bias)) -> BN_epi2 -> (+ residual) )
@@ -334,7 +334,10 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     writes that convolution's pre-split operand (no separate ph_split_rows pass) and leaves it in the returned
     tensor's operand cache, where the next `conv` call finds it.  With `split_only` (the result has exactly that one
     reader) the fp32 result is not written at all and a `SplitRows` is returned - when the split path does not
-    apply, a normal SparseTensor comes back.  `x` may itself be a `SplitRows`."""
+    apply, a normal SparseTensor comes back.  `x` may itself be a `SplitRows`.
+    `one_pair`: the caller guarantees that every output row of the map has exactly one (offset, input row) pair (the
+    generative transposed convolutions: each child has its one parent) - the launch then runs as k = 1 products over row
+    lists grouped by offset instead of walking all offsets of every row."""
     mgr = x.coordinate_manager
     if not _FUSION:
         assert not isinstance(x, SplitRows)
@@ -374,11 +377,15 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     if in_split is not None and nbr is not None and nbr.shape[0] == 27 and n_out >= MIN_ROWS_WINDOWS and \
             be.device_type == "cuda" and (33 <= mod.out_channels <= 64 or _WINDOWS_WIDE):   # 64-wide tiles (measured)
         win = mgr.kernel_windows(nbr)
+    rowlist = None
+    if one_pair and in_split is not None and nbr is not None and nbr.shape[0] <= 8 and n_out >= MIN_ROWS_LINEAR and \
+            be.device_type == "cuda" and os.environ.get("PASCO_CONV_RL", "1") != "0":
+        rowlist = mgr.kernel_rowlist(nbr)
     out = be.conv_fwd(
         x_rows, mod.kernel.detach(), nbr, n_out, xshape=xshape, bias=bias,
         pro_scale=ps, pro_shift=pb, pro_act=pro_act, epi_scale=es, epi_shift=eb, epi_act=epi_act,
         epi2_scale=e2s, epi2_shift=e2b, residual=residual, res_act=res_act, slope=slope, split=split,
-        in_split=in_split, emit_split=emit, want_out=not only, win=win, in_split_has_prologue=True)
+        in_split=in_split, emit_split=emit, want_out=not only, win=win, in_split_has_prologue=True, rowlist=rowlist)
     if emit is None:
         return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
     out, out_split = out

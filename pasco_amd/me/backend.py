@@ -48,6 +48,7 @@ class ConvDesc(C.Structure):
         ("out_split", _vp), ("osp_scale", _vp), ("osp_shift", _vp), ("osp_act", _i32), ("reserved2", _i32),
         ("win_rows", _vp), ("win_cnt", _vp), ("win_slots", _vp), ("win_stats", _vp),
         ("axis_table", _vp), ("axis_coords", _vp), ("axis_lo", _i32), ("axis_rows", _i32),
+        ("rl_in", _vp), ("rl_out", _vp), ("rl_tile_k", _vp), ("rl_rows", _i64), ("rl_tiles", _i32),
     ]
 
 
@@ -70,6 +71,7 @@ _SIGNATURES = {
     "nbr_build": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "nbr_build_same": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "kmap_compact": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
+    "rowlist_pack": [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _i64, _vp],
     "conv_fwd": [C.POINTER(ConvDesc), _vp],
     "conv_last_config": [_vp],
     "win_build": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
@@ -254,6 +256,24 @@ class CBackend:
         self._check(rc, name)
         return nbr
 
+    def rowlist_build(self, nbr: torch.Tensor) -> dict:
+        """Padded row lists of a kernel map whose output rows have exactly one pair each (generative transposed
+        convolutions): {"in", "out"} int32 [cap], {"tile_k"} int32 [cap / 128] (include/pasco_hip.h ph_conv_desc.rl_*).  No
+        host read: sizes are upper bounds, counts stay on the device."""
+        self._chk(nbr, torch.int32, "nbr")
+        kvol, n_out = nbr.shape
+        pin, pout, counts = self.kmap_compact(nbr)
+        cap = (n_out + kvol * 127 + 127) // 128 * 128
+        tcap = cap // 128
+        dev = nbr.device
+        rl_in = torch.empty(cap, dtype=torch.int32, device=dev)
+        rl_out = torch.empty(cap, dtype=torch.int32, device=dev)
+        tile_k = torch.empty(tcap, dtype=torch.int32, device=dev)
+        rc = self.fn["rowlist_pack"](_ptr(pin), _ptr(pout), _ptr(counts), kvol, n_out, _ptr(rl_in), _ptr(rl_out), _ptr(tile_k),
+                                     cap, tcap, self.stream(dev))
+        self._check(rc, "rowlist_pack")
+        return {"in": rl_in, "out": rl_out, "tile_k": tile_k}
+
     def win_build(self, nbr: torch.Tensor) -> dict:
         """Input windows of a 3x3x3 kernel map (include/pasco_hip.h ph_win_build): per tile of 128 consecutive output rows
         the ascending list of distinct input rows (`rows` [T, 3456], `cnt` [T]) and the position of every (offset, row)
@@ -294,7 +314,8 @@ class CBackend:
                  epi_shift=None, epi_act=ACT_NONE, slope=0.01, residual=None, res_act=ACT_NONE,
                  epi2_scale=None, epi2_shift=None, split=None, in_split: Optional[torch.Tensor] = None,
                  emit_split=None, want_out: bool = True,
-                 out: Optional[torch.Tensor] = None, win=None, in_split_has_prologue: bool = False, axis=None):
+                 out: Optional[torch.Tensor] = None, win=None, in_split_has_prologue: bool = False, axis=None,
+                 rowlist=None):
         """out = epilogue(sum_k gather(prologue(x))[k] @ W[k]) - one `ph_conv_fwd` launch (include/pasco_hip.h).
 
         `split` selects the split-precision products: (w_hi, w_lo, unscale) from `split_weight_f16` = mode 1
@@ -394,6 +415,9 @@ class CBackend:
                 if w_split.numel() != kvol * cout * 2 * cpad:
                     raise ValueError("conv: w_split does not match the kernel")
                 d.mma_mode, d.in_split, d.w_split = 2, _ptr(in_split), _ptr(w_split)
+                if rowlist is not None and nbr is not None:     # one-pair-per-row map: k = 1 products per list tile
+                    d.rl_in, d.rl_out, d.rl_tile_k = _ptr(rowlist["in"]), _ptr(rowlist["out"]), _ptr(rowlist["tile_k"])
+                    d.rl_rows, d.rl_tiles = int(rowlist["in"].numel()), int(rowlist["tile_k"].numel())
                 if win is not None and kvol == 27 and nbr is not None:
                     d.win_rows, d.win_cnt, d.win_slots, d.win_stats = (_ptr(win["rows"]), _ptr(win["cnt"]),
                                                                        _ptr(win["slots"]), _ptr(win["stats"]))

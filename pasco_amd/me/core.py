@@ -273,6 +273,16 @@ class CoordinateManager:
             cache[key] = hit
         return hit[1]
 
+    def kernel_rowlist(self, nbr: torch.Tensor):
+        """Row lists of a one-pair-per-row neighbour table of this manager (backend.rowlist_build), built once per map."""
+        cache = self.__dict__.setdefault("_rl_cache", {})
+        key = nbr.data_ptr()
+        hit = cache.get(key)
+        if hit is None or hit[0] is not nbr:
+            hit = (nbr, self.backend().rowlist_build(nbr))
+            cache[key] = hit
+        return hit[1]
+
     def kernel_map_coo(self, in_key, out_key, kernel_size, dilation=1, transposed=False):
         """Upstream-style COO kernel map: list over offsets of (in_rows, out_rows)."""
         nbr = self.kernel_map(in_key, out_key, kernel_size, dilation, transposed)

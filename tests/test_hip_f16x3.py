@@ -133,3 +133,44 @@ def test_conv_emits_next_operand(hip, oracle, cout, n, ksplit_shape):
                                       want_out=False)
         assert none_out is None and torch.equal(osp2.view(torch.int16), exp.view(torch.int16))
     hip.check_status(x.device)
+
+
+@pytest.mark.parametrize("cin,cout,n_parents", [(128, 64, 9000), (256, 128, 3000), (256, 256, 2500)])
+def test_generative_transposed_conv_on_row_lists(hip, oracle, cin, cout, n_parents):
+    """One-pair-per-row maps (every child has its one parent, mink.py:524-527): the launch over row lists grouped by kernel
+    offset (ph_conv_desc.rl_*, kernel id 3) gives bit for bit what the walk over all 8 offsets gives, the lists equal the
+    oracle's, and the result matches the oracle's convolution."""
+    from pasco_amd.me.core import kernel_offsets
+    g = torch.Generator().manual_seed(cin + cout)
+    par = torch.cat([torch.zeros(n_parents, 1, dtype=torch.int64), torch.randint(0, 40, (n_parents, 3), generator=g) * 2], 1).int()
+    par = torch.unique(par, dim=0)
+    par = par[torch.randperm(par.shape[0], generator=g)].contiguous()
+    kids = hip.coords_expand(par.cuda(), 1)                     # 8 children per parent, stride 2 -> 1
+    keep = (torch.rand(kids.shape[0], generator=g) < 0.8).cuda()         # pruned like the decoder's bounds test
+    kids = kids[keep].contiguous()
+    tk, tv, *_ = hip.map_insert(par.cuda(), dedup=False)
+    offs = kernel_offsets(2, 1, 1, True)
+    nbr = hip.nbr_build(kids, tk, tv, offs)
+    assert bool(((nbr >= 0).sum(0) == 1).all())                 # exactly one pair per child
+    n_out = kids.shape[0]
+    rl = hip.rowlist_build(nbr)
+    pin, pout, counts = oracle.kmap_compact(nbr.cpu())
+    rl_o = oracle.rowlist_build(nbr.cpu())
+    for key in ("in", "out", "tile_k"):
+        assert torch.equal(rl[key].cpu(), rl_o[key])
+    x = torch.randn(par.shape[0], cin, generator=g).cuda()
+    w = (torch.randn(8, cin, cout, generator=g) / cin ** 0.5).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    es, eb = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.1).cuda()
+    split = hip.split_weight_rows(w)
+    kw = dict(bias=b, epi_scale=es, epi_shift=eb, epi_act=2, slope=0.05, split=split, emit_split=(None, None, 0))
+    plain, plain_op = hip.conv_fwd(x, w, nbr, n_out, **kw)
+    assert hip.conv_last_config()["kernel"] != 3
+    got, got_op = hip.conv_fwd(x, w, nbr, n_out, rowlist=rl, **kw)
+    assert hip.conv_last_config()["kernel"] == 3
+    assert torch.equal(got, plain) and torch.equal(got_op.view(torch.int16), plain_op.view(torch.int16))
+    only, only_op = hip.conv_fwd(x, w, nbr, n_out, rowlist=rl, want_out=False, **kw)
+    assert only is None and torch.equal(only_op.view(torch.int16), plain_op.view(torch.int16))
+    exp = oracle.conv_fwd(x.cpu(), w.cpu(), nbr.cpu(), n_out, bias=b.cpu(), epi_scale=es.cpu(), epi_shift=eb.cpu(), epi_act=2,
+                          slope=0.05)
+    assert torch.allclose(got.cpu(), exp, rtol=1e-4, atol=1e-4)
