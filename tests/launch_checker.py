@@ -174,7 +174,7 @@ class LaunchChecker:
         if (fp32_x and weight is not None and cfg["mma_mode"] == 2 and cfg["ksplit"] == 1 and cfg["kernel"] != 5
                 and shape_key not in self.mode1_done):       # kernel 5 = window / gather pair: other summation order
             self.mode1_done.add(shape_key)
-            p2 = self.inner(x, weight, nbr, n_out, split=split)
+            p2 = self.inner(x, weight, nbr, n_out, split=split, rowlist=kw.get("rowlist"))     # same kernel, plain form
             cfg2 = hip.conv_last_config()
             assert (cfg2["kernel"], cfg2["bm"], cfg2["bn"], cfg2["kc"]) == (cfg["kernel"], cfg["bm"], cfg["bn"], cfg["kc"])
             p1 = self.inner(x, weight, nbr, n_out, split=hip.split_weight_f16(weight))
