@@ -35,7 +35,10 @@ extern "C" {
 #define PH_FN(name) ph_##name
 #endif
 
-#define PH_ABI_VERSION 1
+/* 2: ph_conv_desc grew (split_exp2, out_split, window / axis-table / row-list blocks), ph_map_insert and ph_split_rows gained
+ * their `status` argument.  A caller built against another version must be rebuilt: the binding checks the version AND the size
+ * of ph_conv_desc before the first call. */
+#define PH_ABI_VERSION 2
 #define PH_MAX_KVOL 64 /* largest kernel volume of one nbr_build / pooling call (4x4x4 window); conv_fwd takes tables of up to 4096 offsets (dense bottleneck: 7x7x5 = 245) */
 
 /* activation codes for fused prologue / epilogue */
@@ -46,6 +49,9 @@ extern "C" {
 typedef void *ph_stream_t;
 
 int PH_FN(abi_version)(void);
+/* sizeof(ph_conv_desc) as the library was compiled: the second half of the handshake (a binding whose mirror of the struct
+ * has another size would hand over misaligned fields). */
+int PH_FN(conv_desc_size)(void);
 const char *PH_FN(last_error)(void);
 
 /* Scratch bytes any call below may need for `n` rows. */

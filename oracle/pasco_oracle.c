@@ -50,6 +50,7 @@ static int fail(const char *fmt, ...) {
 }
 
 int pho_abi_version(void) { return PH_ABI_VERSION; }
+int pho_conv_desc_size(void) { return (int)sizeof(ph_conv_desc); }
 
 /* the restatement has one formulation per operator: nothing to report (kernel id -1) */
 int pho_conv_last_config(int32_t *h_out8) {

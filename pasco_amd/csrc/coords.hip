@@ -19,6 +19,7 @@ void ph_set_error(const char *fmt, ...) {
 }
 
 extern "C" int ph_abi_version(void) { return PH_ABI_VERSION; }
+extern "C" int ph_conv_desc_size(void) { return (int)sizeof(ph_conv_desc); }
 extern "C" const char *ph_last_error(void) { return g_err; }
 
 // ---- stable compaction --------------------------------------------------------------------------

@@ -89,6 +89,29 @@ def _gram(a: torch.Tensor, b: torch.Tensor, chunks: int = 256) -> torch.Tensor:
     return out
 
 
+ENS_KERNEL_MAX_Q, ENS_KERNEL_MAX_C = 128, 64     # shapes the ph_ens_* row kernels take (one wave64 per row, two columns a lane)
+
+
+def _ens_resample_torch(logits, rows, sel):
+    """ph_ens_resample in torch (query counts the row kernels do not take): sigmoid(logits[rows[sel]]), zero rows where
+    the site has no voxel; flag = the row has a non-zero entry."""
+    r = rows.index_select(0, sel.long())
+    out = torch.sigmoid(logits.index_select(0, r.clamp(min=0).long()))
+    out = torch.where((r >= 0)[:, None], out, torch.zeros_like(out))
+    return out, (out != 0).any(dim=1).to(torch.uint8)
+
+
+def _ens_merge_torch(anchor, m, perm, i):
+    anchor.copy_((anchor * i + m.index_select(1, perm.long())) / (i + 1))
+    return anchor
+
+
+def _ens_finish_torch(anchor, keep, sem, sel):
+    nonempty = sem.index_select(0, sel.long()).argmax(dim=1) != 0
+    out = anchor.index_select(1, keep.long()) * nonempty[:, None].to(anchor.dtype)
+    return out, (out != 0).any(dim=1).to(torch.uint8)
+
+
 class Ensembler(torch.nn.Module):
     def __init__(self, scene_size=CANONICAL_SIZE):
         super().__init__()
@@ -183,8 +206,15 @@ class Ensembler(torch.nn.Module):
         union_long = union_sites.long()
         site_coords = sites.index_select(0, union_long)                     # [U, 3]
         masks, flags = [], []                                               # per subnet [U, Q] (0 where absent), [U] uint8
+        # the row kernels serve <= 128 queries and <= 64 classes (the reference's 100 / 20); a checkpoint with more runs
+        # the same steps as torch passes instead of failing (num_queries comes from the checkpoint's hyper-parameters)
+        nq = panop_predictions[0]["voxel_logits"].F.shape[1]
+        rowk = be.has("ens_resample") and nq <= ENS_KERNEL_MAX_Q and ensemble_sem_prob_denses[-1].shape[0] <= ENS_KERNEL_MAX_C
+        ens_resample = be.ens_resample if rowk else _ens_resample_torch
+        ens_merge = be.ens_merge if rowk else _ens_merge_torch
+        ens_finish = be.ens_finish if rowk else _ens_finish_torch
         for i in range(n_sub):
-            m, fl = be.ens_resample(panop_predictions[i]["voxel_logits"].F.contiguous(), rows_per_subnet[i].contiguous(),
+            m, fl = ens_resample(panop_predictions[i]["voxel_logits"].F.contiguous(), rows_per_subnet[i].contiguous(),
                                     union_sites)
             masks.append(m)
             flags.append(fl)
@@ -195,7 +225,7 @@ class Ensembler(torch.nn.Module):
             a_idx, b_idx, iou = self.match_queries(anchor_m, masks[i], iou_threshold)
             # the assignment of a square cost matrix lists every anchor query once, in order (a_idx = 0..Q-1)
             anchor_q = (anchor_q * i + query_probs[i][:, b_idx, :]) / (i + 1)
-            be.ens_merge(anchor_m, masks[i], b_idx.to(torch.int32).contiguous(), i)
+            ens_merge(anchor_m, masks[i], b_idx.to(torch.int32).contiguous(), i)
             ious.append(iou)
         Q = anchor_m.shape[1]
         if ious:
@@ -211,7 +241,7 @@ class Ensembler(torch.nn.Module):
             sem_rows = None                      # denses did not come from this cache's ensemble_sem_compl
         if sem_rows is None:                     # channels-last rows of the dense [C, X, Y, Z] tensors
             sem_rows = [d.permute(1, 2, 3, 0).reshape(-1, d.shape[0]).contiguous() for d in ensemble_sem_prob_denses]
-        ens_m, ens_flag = be.ens_finish(anchor_m, keep_cols.to(torch.int32).contiguous(), sem_rows[-1].contiguous(), union_sites)
+        ens_m, ens_flag = ens_finish(anchor_m, keep_cols.to(torch.int32).contiguous(), sem_rows[-1].contiguous(), union_sites)
         masks.append(ens_m)
         flags.append(ens_flag)
         query_probs.append(anchor_q)

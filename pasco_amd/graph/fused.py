@@ -10,7 +10,9 @@
   same kernel."""
 from __future__ import annotations
 
+import contextlib
 import os
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -50,8 +52,26 @@ def set_conv_precision(mode: str) -> None:
     _CONV_PRECISION = "f32" if mode == "f32" else "f16x3"
 
 
+_TLS = threading.local()
+
+
 def conv_precision() -> str:
-    return _CONV_PRECISION
+    """The precision in force for the calling thread: a `precision_override` block, else the process-wide setting."""
+    return getattr(_TLS, "precision", None) or _CONV_PRECISION
+
+
+@contextlib.contextmanager
+def precision_override(mode: str):
+    """Run the enclosed launches of THIS thread with another convolution precision ("f32" | "f16x3") without touching the
+    process-wide setting - other scenes in flight on other threads keep theirs.  PascoNet.forward uses it to redo a step
+    on the exact fp32 path when the f16 range flag of the split-precision operands was raised."""
+    assert mode in ("f32", "f16x3")
+    prev = getattr(_TLS, "precision", None)
+    _TLS.precision = mode
+    try:
+        yield
+    finally:
+        _TLS.precision = prev
 
 
 def set_fusion(on: bool) -> None:
@@ -135,7 +155,7 @@ def split_input(x: SparseTensor, be, ps, pb, pro_act, slope):
 def split_rows_2d(x2d: torch.Tensor):
     """Pre-split operand of a tall [N, cin] matrix for several `linear_rows` calls on it (None when the split
     path does not apply)."""
-    if not (_FUSION and _kernel_device(x2d.device) and _CONV_PRECISION == "f16x3" and _PRESPLIT and x2d.shape[1] % 8 == 0):
+    if not (_FUSION and _kernel_device(x2d.device) and conv_precision() == "f16x3" and _PRESPLIT and x2d.shape[1] % 8 == 0):
         return None
     from ..me.backend import backend_for
     return backend_for(x2d.device).split_rows(x2d.contiguous())
@@ -159,7 +179,7 @@ def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_o
     dev = x2d.device if x2d is not None else in_split.device
     be = None
     min_rows = MIN_ROWS_LINEAR if min_rows is None else min_rows
-    if _FUSION and _kernel_device(dev) and n >= min_rows and _CONV_PRECISION == "f16x3":
+    if _FUSION and _kernel_device(dev) and n >= min_rows and conv_precision() == "f16x3":
         from ..me.backend import backend_for
         be = backend_for(dev)
         if not be.split_supported(cin, cout):
@@ -225,11 +245,11 @@ def linear_bn_act(x2d: Optional[torch.Tensor], lin: nn.Linear, *, pro_bn=None, e
     if epi_bn is not None:
         es, eb = fold_bn(epi_bn)
     w = lin.weight
-    ver = (w._version, w.device, w.data_ptr(), _PRESPLIT, _CONV_PRECISION)
+    ver = (w._version, w.device, w.data_ptr(), _PRESPLIT, conv_precision())
     hit = lin.__dict__.get("_ph_lin_w")
     if hit is None or hit[0] != ver:
         wt = w.detach().t().contiguous()                          # [cin, cout]
-        split = _split_of(wt, be) if (_CONV_PRECISION == "f16x3" and be.split_supported(cin, cout)) else None
+        split = _split_of(wt, be) if (conv_precision() == "f16x3" and be.split_supported(cin, cout)) else None
         hit = (ver, wt, split, lin.bias.detach().contiguous() if lin.bias is not None else None)
         lin.__dict__["_ph_lin_w"] = hit
     _, wt, split, b = hit
@@ -363,7 +383,7 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     else:
         x_rows = x.F if x.F.is_contiguous() else x.F.contiguous()
         xshape = None
-        if _CONV_PRECISION == "f16x3" and be.split_supported(mod.in_channels, mod.out_channels):
+        if conv_precision() == "f16x3" and be.split_supported(mod.in_channels, mod.out_channels):
             split = split_weight(mod, be)
             if _PRESPLIT and n_out > 0:
                 in_split = split_input(x, be, ps, pb, pro_act, slope)
@@ -398,4 +418,4 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     return y
 
 
-__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "set_fusion", "fusion", "linear_rows", "split_rows_2d", "batched_rows_matmul", "prepare_batched_weights", "linear_bn_act", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]
+__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "precision_override", "set_fusion", "fusion", "linear_rows", "split_rows_2d", "batched_rows_matmul", "prepare_batched_weights", "linear_bn_act", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]

@@ -357,6 +357,17 @@ class TransformerPredictorV2(nn.Module):
             output = self.transformer_ffn_layers[layer](output)
         return (output,) + tuple(self.heads_query_side(output, want_operand))
 
+    def query_graph_state(self) -> str:
+        """"graph" (query-side ops replayed from captured hipGraphs), "eager" (switched off: PASCO_QUERY_GRAPH=0, CPU,
+        training) or "eager (capture failed: ...)" - a capture failure is a performance cliff, so serving loops and
+        bench.py report it instead of leaving a one-off warning behind."""
+        broken = self.__dict__.get("_qgraph_broken", False)
+        if broken:
+            return f"eager (capture failed: {broken})"
+        if os.environ.get("PASCO_QUERY_GRAPH", "1") == "0" or not self.__dict__.get("_qgraphs"):
+            return "eager"
+        return "graph"
+
     _QGRAPH_MAX = 48     # captured graphs kept per module (4 per shape and stream; a few shapes, a few streams); oldest evicted
 
     def query_step(self, layer: int, output, query_embed, want_operand: bool):
@@ -383,7 +394,7 @@ class TransformerPredictorV2(nn.Module):
                 while len(graphs) > self._QGRAPH_MAX:          # dicts keep insertion order: drop the oldest capture
                     graphs.pop(next(iter(graphs)))
             except Exception as exc:       # capture is an optimisation: never let it take the step down
-                self.__dict__["_qgraph_broken"] = True
+                self.__dict__["_qgraph_broken"] = f"{type(exc).__name__}: {exc}"
                 import warnings
                 warnings.warn(f"pasco_amd: query-side graph capture failed ({type(exc).__name__}: {exc}); running eagerly")
                 return self._query_step(layer, output, query_embed, want_operand)
@@ -397,15 +408,18 @@ class TransformerPredictorV2(nn.Module):
     def _capture_query_step(self, layer, output, query_embed, want_operand):
         x = output.detach().clone()
         qe = query_embed.detach().clone()
-        side = torch.cuda.Stream(device=output.device)
-        side.wait_stream(torch.cuda.current_stream(output.device))
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(2):             # warm-up outside the capture: library handles, workspaces, autotuning
-                self._query_step(layer, x, qe, want_operand)
-        torch.cuda.current_stream(output.device).wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads may be launching
-            outs = self._query_step(layer, x, qe, want_operand)
+        be = backend_for(output.device)
+        # the captured launches report into the status word of the stream the graph will be replayed on (this one)
+        with be.pin_status(output.device):
+            side = torch.cuda.Stream(device=output.device)
+            side.wait_stream(torch.cuda.current_stream(output.device))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(2):             # warm-up outside the capture: library handles, workspaces, autotuning
+                    self._query_step(layer, x, qe, want_operand)
+            torch.cuda.current_stream(output.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads may be launching
+                outs = self._query_step(layer, x, qe, want_operand)
         return {"graph": g, "x": x, "qe": qe, "outs": outs}
 
     # -- attention mask -----------------------------------------------------------------------------

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import me as ME
-from ..me.backend import backend_for
+from ..me.backend import F16RangeError, backend_for
 from . import fused
 from .fused import ACT_RELU
 from .bottleneck import SPCDense3Dv2
@@ -200,14 +200,32 @@ class PascoNet(nn.Module):
         """`self.feat` + `ME.SparseTensor` + `Augmenter.merge` (net_panoptic_sparse.py:548-550)."""
         coords, feats = self.feat(in_feats, in_coords)
         x = ME.SparseTensor(feats, coords.int())
-        return merge_subnet_inputs(x, self.n_infers)
+        x = merge_subnet_inputs(x, self.n_infers)
+        # the point MLP runs on the split-precision kernel too: should its range flag turn up in `forward`, the input stage is
+        # redone on the exact path together with the rest (the raw inputs are only referenced, not copied)
+        x.__dict__["_ph_source"] = (in_feats, in_coords)
+        return x
 
     def forward(self, in_feat: ME.SparseTensor, global_min_coords, global_max_coords, min_Cs, max_Cs,
                 is_predict_panop=True, keep_override=None, subnets=None):
         """The reference's timed window: `self.unet3d(...)` (net_panoptic_sparse.py:228-250)."""
-        ret = self.unet3d(in_feat, 1, global_min_coords, global_max_coords, min_Cs, max_Cs,
-                          is_predict_panop=is_predict_panop, keep_override=keep_override, subnets=subnets)
-        backend_for(in_feat.device).check_status(in_feat.device)   # f16-range flag of the split-precision convs
+        be = backend_for(in_feat.device)
+        run = lambda: self.unet3d(in_feat, 1, global_min_coords, global_max_coords, min_Cs, max_Cs,
+                                  is_predict_panop=is_predict_panop, keep_override=keep_override, subnets=subnets)
+        try:
+            ret = run()
+            be.check_status(in_feat.device)     # flags of this stream's launches (f16 range, coordinate range, table clamp)
+        except F16RangeError:
+            # an activation left the f16 range of the split-precision operands (|x| > 2047 with the 2^5 operand scale): the
+            # step is redone with every product on the exact fp32 MFMA instead of failing - slower (2-3x), same graph, and
+            # counted so that a serving loop can see it happen
+            self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1
+            with fused.precision_override("f32"):
+                src = in_feat.__dict__.get("_ph_source")
+                if src is not None:             # made by prepare_input: its point MLP may be what raised the flag
+                    in_feat = self.prepare_input(*src)
+                ret = run()
+            be.check_status(in_feat.device)
         return ret
 
     def ensemble(self, ret, Ts):
@@ -223,6 +241,8 @@ class PascoNet(nn.Module):
             ssc_confidences = [r.reshape(X, Y, Z) for r in cache["sem_conf"]]
         else:
             ssc_confidences = [r.max(dim=1)[0].reshape(X, Y, Z) for r in cache["sem_rows"]]
+        dev = ssc_confidences[0].device
+        backend_for(dev).check_status(dev)      # the ensembler's lazy map builds report into the same stream's word
         return ssc_confidences, sem_prob_denses, panop
 
     def step_inference(self, in_feats, in_coords, Ts, global_min_coords, global_max_coords, min_Cs, max_Cs,

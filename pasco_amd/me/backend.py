@@ -8,8 +8,10 @@ error.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
+import threading
 from typing import Dict, Optional
 
 import torch
@@ -18,6 +20,21 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpascohip.so")
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+ABI_VERSION = 2          # include/pasco_hip.h PH_ABI_VERSION this binding was written against
+
+
+class StatusError(RuntimeError):
+    """A device-side status flag was raised since the last check (`CBackend.check_status`).  `bits` holds every flag:
+    1 = f16 range of a split-precision operand, 2 = unpackable coordinate, 4 = coordinate outside a per-axis table."""
+
+    def __init__(self, bits: int, message: str):
+        super().__init__(message)
+        self.bits = bits
+
+
+class F16RangeError(StatusError):
+    """ONLY bit 0 was raised: an activation left the f16 range of the split-precision convolutions.  The result of the
+    step is unusable, the exact-fp32 path (fused.set_conv_precision("f32")) serves the same graph."""
 MAX_KVOL = 64
 # Activation operands of the split-precision convolutions stand for x * 2^SPLIT_ACT_EXP2 (include/pasco_hip.h
 # `split_exp2`): an f16 lo half is normal only while |x| * 2^e >= 2^-3, so unscaled activations below 0.125 lost
@@ -62,6 +79,7 @@ class SemEnsDesc(C.Structure):
 # name -> argtypes (everything returns int unless listed in _RESTYPES)
 _SIGNATURES = {
     "abi_version": [],
+    "conv_desc_size": [],
     "last_error": [],
     "workspace_bytes": [_i64],
     "map_insert": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp],
@@ -122,6 +140,16 @@ class CBackend:
         self.device_type = device_type
         self.lib = C.CDLL(path)
         self.fn: Dict[str, object] = {}
+        # handshake BEFORE anything else is bound: version, then the size of the one struct that crosses the boundary
+        ver = getattr(self.lib, prefix + "abi_version", None)
+        v = int(ver()) if ver is not None else -1
+        if v != ABI_VERSION:
+            raise RuntimeError(f"{path}: C-ABI version {v}, this binding expects {ABI_VERSION} - rebuild the library "
+                               "(python -m pasco_amd.build --force; oracle: python -m oracle.build)")
+        dsz = getattr(self.lib, prefix + "conv_desc_size", None)
+        if dsz is None or int(dsz()) != C.sizeof(ConvDesc):
+            raise RuntimeError(f"{path}: sizeof(ph_conv_desc) = {None if dsz is None else int(dsz())}, the binding's mirror has "
+                               f"{C.sizeof(ConvDesc)} bytes - rebuild the library against include/pasco_hip.h")
         for name, argtypes in _SIGNATURES.items():
             f = getattr(self.lib, prefix + name)
             f.argtypes = argtypes
@@ -133,10 +161,8 @@ class CBackend:
                 f.argtypes = argtypes
                 f.restype = C.c_int
                 self.fn[name] = f
-        v = self.fn["abi_version"]()
-        if v != 1:
-            raise RuntimeError(f"{path}: ABI version {v}, expected 1")
         self._ws: Dict[torch.device, torch.Tensor] = {}
+        self._tls = threading.local()
         # tests may let a CPU checker library take the split-operand (mode 2) descriptors as well, so that the
         # host-side plumbing of that path (operand emission, split-only tensors) is exercised without a GPU
         self.checker_split = False
@@ -163,6 +189,8 @@ class CBackend:
     def _stream_key(self, device: torch.device):
         """Scratch buffers are reused from launch to launch, which is only safe in stream order: one set per
         (device, stream)."""
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         return (device, self.stream(device) or 0)
 
     def workspace(self, n: int, device: torch.device) -> torch.Tensor:
@@ -449,33 +477,60 @@ class CBackend:
         return dict(zip(names, [int(v) for v in buf]))
 
     def status_word(self, device) -> torch.Tensor:
-        """Device word the split-precision kernels OR their range flag into (one per device)."""
-        key = ("status", device)
+        """Device word the kernels OR their flags into: one per (device, STREAM), like the scratch buffers - every kernel
+        that can raise a flag of a scene and the read-and-clear of `check_status` are then ordered by the stream, so scenes
+        in flight on other streams neither lose a flag nor see a foreign one."""
+        pinned = getattr(self._tls, "status_pin", None)
+        if pinned is not None:
+            return pinned
+        key = ("status",) + self._stream_key(torch.device(device))
         t = self._ws.get(key)
         if t is None:
             t = torch.zeros(1, dtype=torch.int32, device=device)
             self._ws[key] = t
         return t
 
+    @contextlib.contextmanager
+    def pin_status(self, device):
+        """Inside the block every launch of THIS thread reports into the status word of the stream that is current NOW -
+        for work that is recorded on another stream but belongs to this one (hipGraph capture runs on a capture stream;
+        the replay is launched on, and checked from, the caller's stream)."""
+        prev = getattr(self._tls, "status_pin", None)
+        self._tls.status_pin = None
+        self._tls.status_pin = self.status_word(device)
+        try:
+            yield
+        finally:
+            self._tls.status_pin = prev
+
+    STATUS_TEXT = {
+        1: "an activation outside the f16 range in a split-precision convolution / attention operand (rerun with "
+           "pasco_amd.graph.fused.set_conv_precision('f32'); PascoNet.forward does so by itself)",
+        2: "a coordinate outside the packable range (batch index 0..1023, coordinates -131072..131071) was inserted into a "
+           "coordinate map; it would alias another voxel",
+        4: "a coordinate outside the rows of a per-axis table residual (ph_conv_desc.axis_table) was clamped to the table's "
+           "edge; the materialised forms are selected with PASCO_RESIZE_ABSORB=0 PASCO_PE_TABLE=0 PASCO_HEAD_ABSORB=0",
+    }
+
     def check_status(self, device) -> None:
-        """Raise if, since the last check, a split-precision kernel met a value outside the f16 range (bit 0) or a
-        coordinate map was given a coordinate its 64-bit key cannot hold (bit 1): one device->host read; call where the
-        host synchronises anyway."""
-        t = self._ws.get(("status", device))
+        """Raise if, since the last check ON THIS STREAM, a kernel raised a status bit: 0 = a value outside the f16 range
+        met a split-precision operand, 1 = a coordinate map was given a coordinate its 64-bit key cannot hold, 2 = a
+        per-axis table clamped a coordinate.  One device->host read (call where the host synchronises anyway); read and
+        clear are two stream-ordered operations on the stream's own word.  Every raised bit is reported; the exception is
+        an `F16RangeError` when bit 0 is the only one (the caller may redo the step on the exact path)."""
+        t = self._ws.get(("status",) + self._stream_key(torch.device(device)))
         if t is None:
             return
-        v = int(t.item())
+        snap = t.clone()          # stream-ordered: after every kernel of this stream that could raise a flag ...
+        t.zero_()                 # ... and before any later one
+        v = int(snap.item())
         if v == 0:
             return
-        t.zero_()
-        if v & 4:
-            raise RuntimeError("pasco_amd: a coordinate outside the range of a per-axis table residual (ph_conv_desc.axis_table) "
-                               "was clamped to the table's edge")
-        if v & 2:
-            raise RuntimeError("pasco_amd: a coordinate outside the packable range (batch index 0..1023, coordinates "
-                               "-131072..131071) was inserted into a coordinate map; it would alias another voxel")
-        raise RuntimeError("pasco_amd: activation outside the f16 range in a split-precision convolution; "
-                           "rerun with pasco_amd.graph.fused.set_conv_precision('f32')")
+        msgs = [self.STATUS_TEXT[b] for b in (1, 2, 4) if v & b]
+        if v & ~7:
+            msgs.append(f"unknown status bits {v & ~7:#x}")
+        text = f"pasco_amd: device status {v:#x}: " + "; ".join(msgs)
+        raise (F16RangeError if v == 1 else StatusError)(v, text)
 
     @staticmethod
     def split_weight_f16(weight: torch.Tensor, exponent=None):

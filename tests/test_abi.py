@@ -32,7 +32,19 @@ def test_hip_library_exports_every_symbol():
     for n in declared():
         assert hasattr(lib, "ph_" + n), f"libpascohip.so lacks ph_{n}"
     lib.ph_abi_version.restype = ctypes.c_int
-    assert lib.ph_abi_version() == 1
+    assert lib.ph_abi_version() == 2
+    from pasco_amd.me.backend import ConvDesc
+    assert lib.ph_conv_desc_size() == ctypes.sizeof(ConvDesc)
+
+
+def test_binding_rejects_other_abi_versions(monkeypatch):
+    """A stale library (other PH_ABI_VERSION or another ph_conv_desc size) is refused with a 'rebuild' message instead of
+    being called with misaligned arguments."""
+    from pasco_amd.build import build_hip
+    from pasco_amd.me import backend
+    monkeypatch.setattr(backend, "ABI_VERSION", 3)
+    with pytest.raises(RuntimeError, match="rebuild"):
+        backend.CBackend(build_hip(verbose=False), "ph_", "cuda")
 
 
 def test_oracle_exports_every_symbol(oracle):

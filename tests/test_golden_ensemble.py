@@ -61,6 +61,14 @@ def test_ensemble_and_panoptic_match_reference_cpu(oracle_registered):
     run_case("cpu", rtol=1e-4, atol=1e-5)
 
 
+def test_ensemble_beyond_the_row_kernels_shapes_matches_reference_cpu(oracle_registered, monkeypatch):
+    """More queries than the ph_ens_* row kernels take (a checkpoint's num_queries > 128): the torch formulation of the
+    same three steps serves the scene instead of a RuntimeError - forced here, same reference vectors."""
+    import pasco_amd.graph.ensemble as ens_mod
+    monkeypatch.setattr(ens_mod, "ENS_KERNEL_MAX_Q", 0)
+    run_case("cpu", rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.gpu
 def test_ensemble_and_panoptic_match_reference_gpu(hip):
     run_case("cuda", rtol=1e-3, atol=1e-4)
