@@ -69,7 +69,27 @@ def pmc_traffic(kernel):
     return None if r is None else r["hbm_bytes_per_launch"]
 
 
-def _roofs(name, flops, bytes_alg, time_s):
+HBM_COPY_GBS = None      # stream-copy rate measured on THIS box (measure_stream_copy), the achievable HBM roof
+
+
+def measure_stream_copy(device, nbytes=1 << 30, reps=5):
+    """Achievable HBM rate of this box: a float4 device-to-device copy of 1 GiB (read + write counted), best of `reps`
+    ('measure achievable with a stream-copy kernel on the box'; MI355X_MICROARCH.md quotes ~6.3 TB/s)."""
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    best = 0.0
+    for _ in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del src, dst
+    return best
+
+
+def _roofs(name, flops, bytes_alg, time_s, bytes_min=None):
     """Both roofs of one group of launches: algorithmic bytes against the HBM peak, matrix work against the
     MFMA peak of the arithmetic actually used; `bound` = the roof the group sits closer to."""
     tf = flops / time_s / 1e12
@@ -81,6 +101,11 @@ def _roofs(name, flops, bytes_alg, time_s):
         mfma_frac, mfma_peak, mfma_tf = tf / F32_MFMA_PEAK_TFLOPS, F32_MFMA_PEAK_TFLOPS, tf
     e = {"useful_TFLOPs": round(tf, 3), "alg_GBps": round(gbs, 1), "alg_frac_of_hbm_peak": round(hbm_frac, 4),
          "mfma_TFLOPs_issued": round(mfma_tf, 2), "mfma_frac_of_peak": round(mfma_frac, 4)}
+    if bytes_min is not None:       # compulsory bytes (every input row once): what an ideal on-chip reuse would leave
+        e["min_GBps"] = round(bytes_min / time_s / 1e9, 1)
+        e["min_frac_of_hbm_peak"] = round(bytes_min / time_s / 1e9 / HBM_PEAK_GBS, 4)
+    if HBM_COPY_GBS:                # the same rates against the stream-copy rate of this box
+        e["alg_frac_of_box_copy_rate"] = round(gbs / HBM_COPY_GBS, 4)
     if hbm_frac >= mfma_frac:
         e.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_frac, 4))
     else:
@@ -95,8 +120,9 @@ def roofline_object(per_kernel, steps, classes=None):
         avg = s["time_s"] / s["launches"]
         e = {"kernel": name, "launches_per_step": s["launches"] / steps, "avg_launch_us": round(avg * 1e6, 2),
              "ms_per_step": round(s["time_s"] / steps * 1e3, 3), "flops_per_launch": s["flops"] / s["launches"],
-             "alg_bytes_per_launch": s["bytes_alg"] / s["launches"]}
-        e.update(_roofs(name, s["flops"], s["bytes_alg"], s["time_s"]))
+             "alg_bytes_per_launch": s["bytes_alg"] / s["launches"],
+             "min_bytes_per_launch": s.get("bytes_min", 0.0) / s["launches"]}
+        e.update(_roofs(name, s["flops"], s["bytes_alg"], s["time_s"], s.get("bytes_min")))
         rec = pmc_record(name)
         e["traffic"] = None if rec is None else rec["hbm_bytes_per_launch"]
         if rec is not None:
@@ -109,6 +135,8 @@ def roofline_object(per_kernel, steps, classes=None):
 
     names = sorted((n for n in per_kernel if n.startswith("k_conv")), key=lambda n: -per_kernel[n]["time_s"])
     out = entry(names[0], per_kernel[names[0]])
+    if HBM_COPY_GBS:
+        out["hbm_box_copy_GBps"] = round(HBM_COPY_GBS, 1)       # float4 copy of 1 GiB on this box, read + write
     out["conv_ms_per_step"] = round(sum(per_kernel[n]["time_s"] for n in names) / steps * 1e3, 3)
     if len(names) > 1:
         out["other_conv_kernel"] = entry(names[1], per_kernel[names[1]])
@@ -126,7 +154,7 @@ def roofline_object(per_kernel, steps, classes=None):
             r = {"class": cls, "kernel": kern, "launches_per_step": s["launches"] / steps,
                  "ms_per_step": round(s["time_s"] / steps * 1e3, 3),
                  "avg_launch_us": round(s["time_s"] / s["launches"] * 1e6, 1)}
-            r.update(_roofs(kern, s["flops"], s["bytes_alg"], s["time_s"]))
+            r.update(_roofs(kern, s["flops"], s["bytes_alg"], s["time_s"], s.get("bytes_min")))
             rows.append(r)
         out["by_layer_class"] = rows
     return out
@@ -206,9 +234,11 @@ def physical_cores():
     return len(seen) or (os.cpu_count() or 1)
 
 
-def cpu_baseline(n_infers, in_channels):
-    """Same graph, oracle backend (C + OpenMP) + torch CPU for the dense parts, host cores only: one warm-up
-    scene on a 128x128x16 grid (thread pools, page faults, weight operand caches), then ONE full S10 scene timed."""
+def cpu_baseline(n_infers, in_channels, timed=3):
+    """Same graph, oracle backend (C + OpenMP) + torch CPU for the dense parts, host cores only: ONE warm-up scene on the
+    same 256x256x32 grid (thread pools, page faults, weight operand caches), then `timed` full S10 scenes (seeds 0, 1, 2),
+    median reported (warm-up + timed scenes, median; 3 instead of 5 scenes keeps the default run within
+    a few minutes at ~20 s per scene)."""
     from oracle.build import build_oracle
     from pasco_amd.me import backend
     from pasco_amd.me.backend import CBackend
@@ -219,20 +249,25 @@ def cpu_baseline(n_infers, in_channels):
     backend.register_checker_backend(CBackend(build_oracle(), "pho_", "cpu"))
     try:
         net = build_net(n_infers, in_channels, "cpu")
-        small = make_scene(0, n_infers=n_infers, in_channels=in_channels, grid=(128, 128, 16))
-        tk = TeacherKeep(small, "cpu")
-        with torch.no_grad():
-            run_scene(net, small, tk)
-        full = make_scene(0, n_infers=n_infers, in_channels=in_channels)
-        tk = TeacherKeep(full, "cpu")
-        with torch.no_grad():
-            t0 = time.time()
-            run_scene(net, full, tk)
-            t_full = time.time() - t0
-        return dict(value=round(1.0 / t_full, 5), unit="scenes/s", cores=cores, kind="port",
-                    sample=f"1 full S10 scene (seed 0, M={n_infers}, {int(full.occ.sum())} occupied voxels) in {t_full:.2f} s after a "
-                           f"warm-up scene on a 128x128x16 grid; oracle C/OpenMP sparse ops + torch-CPU dense ops; "
-                           f"{cpu_model()}: {cores} threads = physical cores of {os.cpu_count()} logical CPUs (OpenMP and torch)")
+        times, occ = [], 0
+        for k in range(timed + 1):                 # scene 0 twice: once as the warm-up, once timed
+            full = make_scene(max(k - 1, 0), n_infers=n_infers, in_channels=in_channels)
+            tk = TeacherKeep(full, "cpu")
+            with torch.no_grad():
+                t0 = time.time()
+                run_scene(net, full, tk)
+                dt = time.time() - t0
+            if k > 0:
+                times.append(dt)
+            else:
+                occ = int(full.occ.sum())
+        times.sort()
+        med = times[len(times) // 2]
+        return dict(value=round(1.0 / med, 5), unit="scenes/s", cores=cores, kind="port",
+                    sample=f"median of {timed} full S10 scenes (seeds 0..{timed - 1}, M={n_infers}, {occ} occupied voxels in seed 0; "
+                           f"{', '.join(f'{t:.2f}' for t in times)} s) after one warm-up scene on the same grid; oracle C/OpenMP "
+                           f"sparse ops + torch-CPU dense ops; {cpu_model()}: {cores} threads = physical cores of "
+                           f"{os.cpu_count()} logical CPUs (OpenMP and torch)")
     finally:
         backend.register_checker_backend(None)
 
@@ -281,11 +316,11 @@ def dry_run(args, world, rank):
         dist.destroy_process_group()
 
 
-def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False):
+def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False, heavy=False):
     """Short timed row of another BASELINE.json configuration on this GPU (1 warm-up + `steps` scenes)."""
     from pasco_amd.graph import fused
     from pasco_amd.graph.synth import make_scene, TeacherKeep
-    net = build_net(n_infers, in_channels, device, n_classes=n_classes)
+    net = build_net(n_infers, in_channels, device, n_classes=n_classes, heavy=heavy)
     scene = make_scene(seed=0, n_infers=n_infers, in_channels=in_channels).to(device)
     teacher = TeacherKeep(scene, device)
     if unfused:                 # INTEGRATION.md route (a): reference-style module sequence, exact fp32 products
@@ -347,6 +382,9 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU (MI355X); the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # each rank (and the worker threads it starts) stays on whole physical cores next to its GPU: PASCO_BENCH_PIN=0 disables
+    from pasco_amd.graph.dist import pin_rank
+    pinned = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device_index=local_rank)
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
@@ -356,6 +394,9 @@ def main():
     from pasco_amd.graph.profiling import ConvProfiler
 
     be = hip_backend()   # raises if libpascohip.so is missing
+    global HBM_COPY_GBS
+    if rank == 0 and not args.no_profile:
+        HBM_COPY_GBS = measure_stream_copy(device)
     from pasco_amd.graph import fused
     fused.set_conv_precision(args.conv_precision)
     net = build_net(args.n_infers, args.in_channels, device, heavy=args.heavy, n_classes=args.n_classes)
@@ -484,6 +525,8 @@ def main():
         prof.enabled = False
         one_in_flight = {"value": round(1.0 / dt1, 4), "unit": "scenes/s", "ms_per_step": round(dt1 * 1e3, 3),
                          "steps": args.steps}
+        if window:      # the reference's own timing window (`self.unet3d`, README.md:448-449), one scene at a time
+            one_in_flight["unet_window_ms"] = round(sum(a.elapsed_time(b) for a, b in window) / len(window), 3)
     if gc_was_on:
         gc.enable()
 
@@ -564,6 +607,17 @@ def main():
             if per_kernel:
                 res["roofline"] = roofline_object(per_kernel, args.steps, classes)
         res["config"]["in_flight"] = args.in_flight
+        res["host_threads"] = {"scene_threads_per_rank": max(args.in_flight, 1), "ranks": world,
+                               "cpus_per_rank": len(pinned) if pinned else len(os.sched_getaffinity(0)),
+                               "pinned_to_gpu_local_cores": bool(pinned), "omp_num_threads": os.environ.get("OMP_NUM_THREADS"),
+                               "note": "host side of a scene = Python launch loop under the GIL; ranks x scene threads "
+                                       "compete for cores only across ranks (each rank pinned to its own cores)"}
+        res["query_graph"] = net.transformer_predictor.query_graph_state()
+        res["range_fallbacks"] = int(getattr(net, "range_fallbacks", 0))
+        if heads and world > 1 and last.get("out") is not None and "exchange" in last["out"]:
+            ex = dict(last["out"]["exchange"])
+            ex["MB_sent_per_rank_per_scene"] = round(ex["bytes_sent"] / 1e6, 2)
+            res["exchange"] = ex
         if one_in_flight is not None:
             res["in_flight_1"] = one_in_flight
         if gc_row is not None:
@@ -577,6 +631,8 @@ def main():
             for name, kw in (("mimo1_semantickitti", dict(n_infers=1, in_channels=283, n_classes=20)),
                              ("mimo3_sscbench_kitti360", dict(n_infers=3, in_channels=8, n_classes=19)),
                              ("mimo8_one_gpu", dict(n_infers=8, in_channels=283, n_classes=20)),
+                             # SURVEY.md 8(d) "second row": the logged run's decoder depth (hparams.yaml heavy_decoder: true)
+                             ("mimo3_heavy_decoder", dict(n_infers=3, in_channels=283, n_classes=20, heavy=True)),
                              ("mimo1_unfused_me_modules", dict(n_infers=1, in_channels=283, n_classes=20, unfused=True))):
                 try:
                     rows[name] = short_row(device=device, **kw)

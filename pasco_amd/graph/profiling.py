@@ -83,7 +83,7 @@ class ConvProfiler:
         recorded launch (k=3 / k=2 strided / generative transposed / k=1 convolutions and the dense bottleneck's
         implicit GEMMs): launches, time, algorithmic flops / bytes (flops = 2 P Cin Cout,
         B_alg = 4 P Cin + 4 N_out Cout + 8 P + 4 K Cin Cout, P = pairs of the neighbour table, P = N for
-        identity maps)."""
+        identity maps; B_min = the same with 4 N_in Cin in place of 4 P Cin: the compulsory lower bound)."""
         torch.cuda.synchronize()
         pair_cache = {}
         out = {}
@@ -108,23 +108,27 @@ class ConvProfiler:
                 P = pair_cache[key]
                 idx_bytes = 8.0 * P
             cin, cout, n_out = r["cin"], r["cout"], r["n_out"]
-            d = out.setdefault(r["kernel"], dict(launches=0, time_s=0.0, flops=0.0, bytes_alg=0.0,
+            d = out.setdefault(r["kernel"], dict(launches=0, time_s=0.0, flops=0.0, bytes_alg=0.0, bytes_min=0.0,
                                                  k3_launches=0, k3_time_s=0.0, k3_flops=0.0))
             fl = 2.0 * P * cin * cout
+            # compulsory lower bound of SURVEY.md 8(d): every input row read ONCE instead of once per pair
+            b_min = 4.0 * min(r["n_in"], P) * cin + 4.0 * n_out * cout + idx_bytes + 4.0 * r["kvol"] * cin * cout
             d["launches"] += 1
             d["time_s"] += dt
             d["flops"] += fl
             d["bytes_alg"] += 4.0 * P * cin + 4.0 * n_out * cout + idx_bytes + 4.0 * r["kvol"] * cin * cout
+            d["bytes_min"] += b_min
             if r["kvol"] == 27:
                 d["k3_launches"] += 1
                 d["k3_time_s"] += dt
                 d["k3_flops"] += fl
             c = classes.setdefault((layer_class(r["kvol"], cin, cout), r["kernel"]),
-                                   dict(launches=0, time_s=0.0, flops=0.0, bytes_alg=0.0))
+                                   dict(launches=0, time_s=0.0, flops=0.0, bytes_alg=0.0, bytes_min=0.0))
             c["launches"] += 1
             c["time_s"] += dt
             c["flops"] += fl
             c["bytes_alg"] += 4.0 * P * cin + 4.0 * n_out * cout + idx_bytes + 4.0 * r["kvol"] * cin * cout
+            c["bytes_min"] += b_min
         if by_class:
             return out, classes
         return out

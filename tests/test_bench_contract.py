@@ -14,7 +14,7 @@ def _rec(launches, time_s, flops, bytes_alg, k3=0):
 
 
 def test_roofline_object_fields():
-    per_kernel = {"k_conv_h2": _rec(1120, 0.27, 4.7e13, 8.1e11, k3=600),
+    per_kernel = {"k_conv_h2": dict(_rec(1120, 0.27, 4.7e13, 8.1e11, k3=600), bytes_min=2.7e11),
                   "k_conv_mfma": _rec(40, 0.0066, 3.1e11, 1.1e10),
                   "k_split_rows": _rec(410, 0.0103, 0.0, 3.7e10)}
     classes = {("k3 C=64", "k_conv_h2"): dict(launches=60, time_s=0.05, flops=1.0e13, bytes_alg=2.0e11),
@@ -30,6 +30,8 @@ def test_roofline_object_fields():
     rows = {x["class"]: x for x in r["by_layer_class"]}
     assert rows["k3 C=256"]["bound"] == "mfma" and rows["k3 C=256"]["kernel"] == "k_conv_dma"
     assert rows["k3 C=64"]["bound"] == "hbm"
+    # compulsory bytes (SURVEY.md 8(d) B_min) ride next to the algorithmic ones
+    assert abs(r["min_frac_of_hbm_peak"] - 2.7e11 / 0.27 / 1e9 / 8000.0) < 1e-3 and r["min_bytes_per_launch"] == 2.7e11 / 1120
     assert r["launches_per_step"] == 112.0 and abs(r["avg_launch_us"] - 0.27 / 1120 * 1e6) < 0.01
     assert r["other_conv_kernel"]["kernel"] == "k_conv_mfma" and r["other_conv_kernel"]["bound"] == "mfma"
     assert r["other_conv_kernel"]["peak"] == 157.3

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pasco_amd.graph.dist import allgather_voxel_logits, shard_indices, timed_steps
+from pasco_amd.graph.dist import allgather_voxel_logits, packed_allgather, rank_cpu_set, shard_indices, timed_steps
 
 
 def _free_port():
@@ -32,6 +32,17 @@ def _worker(rank, world, port, q):
             ef = torch.randn(50 + 37 * r, 20, generator=gr)
             ec = torch.randint(0, 256, (50 + 37 * r, 4), generator=gr).int()
             ok = ok and torch.equal(fs[r], ef) and torch.equal(cs[r], ec)
+        # the packed form of the same exchange: two collectives for all parts, bytes accounted
+        ql = torch.randn(3 * rank, 21, generator=g)              # rank 0 contributes an EMPTY part
+        got, st = packed_allgather([feats, coords, ql])
+        ok = ok and st["collectives"] == 2 and st["bytes_sent"] == n * 20 * 4 + n * 4 * 4 + 3 * rank * 21 * 4
+        for r in range(world):
+            gr = torch.Generator().manual_seed(100 + r)
+            ef = torch.randn(50 + 37 * r, 20, generator=gr)
+            ec = torch.randint(0, 256, (50 + 37 * r, 4), generator=gr).int()
+            eq = torch.randn(3 * r, 21, generator=gr)
+            ok = ok and torch.equal(got[r][0], ef) and torch.equal(got[r][1], ec) and torch.equal(got[r][2], eq)
+            ok = ok and got[r][1].dtype == torch.int32 and tuple(got[r][2].shape) == (3 * r, 21)
         # timing contract: the slow rank sets the time for everybody
         import time
         elapsed = timed_steps(lambda: time.sleep(0.01 * (1 + 3 * rank)), steps=3, warmup=1)
@@ -59,10 +70,12 @@ def test_world2_gloo():
     assert res[0][3] == [0, 2, 4, 6] and res[1][3] == [1, 3, 5]
 
 
-def _c4_worker(rank, world, port, q):
+def _c4_worker(rank, world, port, q, n_infers=2):
     import sys
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from tests.conftest import load_oracle
@@ -72,16 +85,18 @@ def _c4_worker(rank, world, port, q):
         from pasco_amd.graph.synth import TeacherKeep, make_scene
         backend.register_checker_backend(load_oracle())
         torch.manual_seed(3)
-        net = PascoNet(n_classes=20, n_infers=2, in_channels=12, f=8, num_queries=8, heavy_decoder=False).eval()
+        net = PascoNet(n_classes=20, n_infers=n_infers, in_channels=12, f=8, num_queries=8, heavy_decoder=False).eval()
         net.ensembler.scene_size = (24, 24, 8)
-        sc = make_scene(4, n_infers=2, in_channels=12, grid=(24, 24, 8), occupancy=0.12)
+        sc = make_scene(4, n_infers=n_infers, in_channels=12, grid=(24, 24, 8), occupancy=0.12)
         tk = TeacherKeep(sc, "cpu")
         with torch.no_grad():
             x = net.prepare_input(sc.in_feats, sc.in_coords)
             args = (x, sc.global_min_Cs, sc.global_max_Cs, sc.min_Cs, sc.max_Cs)
             ref = net(*args, keep_override=tk)                                  # all heads on one process
             got = subnet_parallel_forward(net, *args, keep_override=tk)         # one head per rank + all-gather
-            ok = True
+            ok = len(got["panop_predictions"]) == n_infers and all(p is not None for p in got["panop_predictions"])
+            ex = got["exchange"]
+            ok = ok and ex["rounds"] == -(-n_infers // world) and ex["collectives"] == 2 * ex["rounds"] and ex["bytes_sent"] > 0
             for a, b in zip(got["panop_predictions"], ref["panop_predictions"]):
                 ok = ok and torch.equal(a["voxel_logits"].C, b["voxel_logits"].C)
                 ok = ok and torch.allclose(a["voxel_logits"].F, b["voxel_logits"].F, rtol=1e-4, atol=1e-5)
@@ -109,6 +124,47 @@ def test_subnet_parallel_heads_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[1] for r in res)
+
+
+def test_subnet_parallel_heads_ragged_tail_world4_gloo():
+    """n_infers NOT divisible by the world size (M = 6 on 4 ranks: the second exchange round has two ranks with nothing to
+    contribute): every rank still ends with all six subnets' predictions, equal to the single-process graph."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c4_worker, args=(r, world, port, q, 6)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(res) == world and all(r[1] for r in res)
+
+
+def test_rank_cpu_sets_follow_the_gpu_numa_node(tmp_path):
+    """8 ranks on a 2-socket host with SMT (fake sysfs): each rank gets whole physical cores of ITS GPU's socket, the sets
+    of different ranks are disjoint, and without PCI information the allowed cores are split evenly."""
+    sysfs = tmp_path
+    ncpu = 32                                               # cores 0-15, SMT siblings 16-31; socket 0 = cores 0-7, socket 1 = 8-15
+    for c in range(ncpu):
+        d = sysfs / "devices" / "system" / "cpu" / f"cpu{c}" / "topology"
+        d.mkdir(parents=True)
+        core = c % 16
+        (d / "core_cpus_list").write_text(f"{core},{core + 16}\n")
+    for g in range(8):
+        d = sysfs / "bus" / "pci" / "devices" / f"0000:{g:02x}:00.0"
+        d.mkdir(parents=True)
+        (d / "local_cpulist").write_text("0-7,16-23\n" if g < 4 else "8-15,24-31\n")
+    sets = [rank_cpu_set(r, 8, f"0000:{r:02x}:00.0", sysfs=str(sysfs), allowed=range(ncpu)) for r in range(8)]
+    assert sets[0] == [0, 1, 16, 17] and sets[3] == [6, 7, 22, 23] and sets[4] == [8, 9, 24, 25]
+    flat = [c for s_ in sets for c in s_]
+    assert len(flat) == len(set(flat)) == ncpu
+    even = [rank_cpu_set(r, 4, None, sysfs=str(sysfs), allowed=range(ncpu)) for r in range(4)]
+    assert even[1] == [4, 5, 6, 7, 20, 21, 22, 23] and sum(len(e) for e in even) == ncpu
+    one = rank_cpu_set(0, 1, "0000:05:00.0", sysfs=str(sysfs), allowed=range(ncpu))
+    assert one == [8, 9, 10, 11, 12, 13, 14, 15, 24, 25, 26, 27, 28, 29, 30, 31]      # a single rank: its GPU's whole socket
 
 
 def test_bench_launches_its_own_ranks():
