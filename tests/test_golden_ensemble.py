@@ -11,6 +11,9 @@ from pasco_amd.graph.panoptic import panoptic_inference
 from tests.test_golden import compare_sparse, load
 
 
+JAC = 1.0      # coordinate sets of the ensembled outputs: measured overlap 1.0 on CPU and GPU (round 3)
+
+
 def run_case(device, rtol, atol):
     d = load("ensemble.npz")
     n_sub = d["Ts"].shape[0]
@@ -29,15 +32,18 @@ def run_case(device, rtol, atol):
         got = sd[:, probe[:, 0], probe[:, 1], probe[:, 2]].T.cpu()
         exp = d[f"semdense_{i}_probe"]
         bad = ((got - exp).abs() > atol + rtol * exp.abs()).any(dim=1).float().mean()
-        assert bad < 2e-3, f"semantic ensemble {i}: {float(bad):.2e} of probed sites differ"
         hist = torch.bincount(sd.argmax(0).reshape(-1).cpu(), minlength=20)
-        assert (hist - d[f"semdense_{i}_argmax_hist"]).abs().sum() <= 40
+        flips = int((hist - d[f"semdense_{i}_argmax_hist"]).abs().sum())
+        print(f"[ensemble {device}] semantic {i}: {float(bad):.2e} of probed sites beyond tolerance, argmax histogram differs by {flips}")
+        # CPU (oracle arithmetic = the fixture's): exact.  GPU: a different fp32 summation order may move a softmax by an ulp
+        assert bad <= (0.0 if device == "cpu" else 2e-3), f"semantic ensemble {i}: {float(bad):.2e} of probed sites differ"
+        assert flips <= (0 if device == "cpu" else 40)
     for i, o in enumerate(out):
         assert torch.allclose(o["query_probs"].cpu(), d[f"out_{i}_query"], rtol=rtol, atol=atol), f"query probs {i}"
         compare_sparse(o["voxel_probs"].C, o["voxel_probs"].F, d[f"out_{i}_voxel_C"], d[f"out_{i}_voxel_F"],
-                       rtol, atol, f"voxel_probs_{i}", min_jaccard=0.995)
+                       rtol, atol, f"voxel_probs_{i}", min_jaccard=JAC)
         compare_sparse(o["sem_probs"].C, o["sem_probs"].F, d[f"out_{i}_voxel_C"], d[f"out_{i}_sem_F"],
-                       rtol, atol, f"sem_probs_{i}", min_jaccard=0.995)
+                       rtol, atol, f"sem_probs_{i}", min_jaccard=JAC)
         pi = panoptic_inference(o["voxel_probs"], o["query_probs"], overlap_threshold=0.4, object_mask_threshold=0.7,
                                 thing_ids=[1, 2, 3, 4, 5, 6, 7, 8], scene_size=(256, 256, 32),
                                 min_C=torch.zeros(3, dtype=torch.int32), input_query_logit=False,
@@ -48,7 +54,7 @@ def run_case(device, rtol, atol):
         conf = torch.tensor([s["confidence"] for s in pi["segments_infos"][0]])
         assert torch.allclose(conf, d[f"pi_{i}_segconf"], rtol=rtol, atol=atol)
         compare_sparse(o["voxel_probs"].C, pi["panoptic_seg_sparses"][0].float()[:, None], d[f"out_{i}_voxel_C"],
-                       d[f"pi_{i}_panoptic_sparse"].float()[:, None], 0.0, 0.5, f"panoptic ids {i}", min_jaccard=0.995)
+                       d[f"pi_{i}_panoptic_sparse"].float()[:, None], 0.0, 0.5, f"panoptic ids {i}", min_jaccard=JAC)
         c = d[f"out_{i}_voxel_C"].long()
         for k in ("semantic_seg_denses", "ins_uncertainty_denses", "vox_confidence_denses", "vox_uncertainty_denses"):
             got = pi[k][0][c[:, 1], c[:, 2], c[:, 3]].cpu().float()
