@@ -398,6 +398,37 @@ int PH_FN(project_canonical)(const float *T, int32_t X, int32_t Y, int32_t Z, do
 int PH_FN(rowlist_pack)(const int32_t *pairs_in, const int32_t *pairs_out, const int32_t *counts, int32_t kvol, int64_t n_out,
                         int32_t *rl_in, int32_t *rl_out, int32_t *tile_k, int64_t cap, int64_t tcap, ph_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Input stage: voxel max of the point features + MIMO channel concatenation (CylinderFeat.forward after its PPmodel,
+ * pasco/models/unet3d_sparse_v2.py:53-86: torch.unique(dim=0) of the (subnet, voxel) rows + torch_scatter.scatter_max; then
+ * Augmenter.merge, pasco/models/augmenter.py:13-27: SparseTensor.dense -> channel cat over the subnets -> ME.to_sparse).
+ * Restated without the sort and without the dense [M, C, X, Y, Z] tensor: the merged rows are the occupied sites of the
+ * points' bounding box in lexicographic (x, y, z) order, row r holds in channels [b*C, (b+1)*C) the max over subnet b's
+ * points in that voxel, 0 where subnet b has none.
+ *   points_bounds      out6 (device) = min x, y, z, max x, y, z over xyz int64 [n, 3] (the reference's index dtype)
+ *   points_mark        flags[site] = 1 for the site ((x-lo)*dimy + (y-lo))*dimz + (z-lo) of every point; flags is zero-filled
+ *                      by the caller, h_lo3 / h_dims3 are HOST ints; a point outside the box raises status bit 3
+ *   mask_compact_rank  mask_compact that also writes rank_of[i] = row of kept element i (rows of the occupied sites)
+ *   points_link        chains the points of every (merged row, subnet) cell: next[i] = previous head of cell
+ *                      rank_of[site(i)] * m + b(i), head[cell] = i (head int32 [v * m] filled with -1 by the caller, next
+ *                      int32 [n]); subnet b of point i from h_starts (HOST int64 [m + 1]: first point of every subnet - the
+ *                      points of a subnet are contiguous); m <= 8.  The order inside a chain is arbitrary (it feeds a max).
+ *   cells_max          out[r, b*c + ch] = max over the chain of cell (r, b) of h[i, ch] (h fp32 [n, c] = the point MLP's
+ *                      output), 0 for an empty chain; coords[r] = (0, x, y, z) of sites[r] (int32 [v]: the kept site ids);
+ *                      status bit 3 when a row is entirely zero (ME.to_sparse drops such a row: the caller must redo
+ *                      the stage on its general path - the row count cannot change without a host read); c % 4 == 0
+ * ------------------------------------------------------------------------------------------- */
+int PH_FN(points_bounds)(const int64_t *xyz, int64_t n, int32_t *out6, ph_stream_t stream);
+int PH_FN(points_mark)(const int64_t *xyz, int64_t n, const int32_t *h_lo3, const int32_t *h_dims3, uint8_t *flags,
+                       int32_t *status, ph_stream_t stream);
+int PH_FN(mask_compact_rank)(const uint8_t *mask, int64_t n, int32_t *keep_rows, int32_t *rank_of, int32_t *n_keep,
+                             void *ws, int64_t ws_bytes, ph_stream_t stream);
+int PH_FN(points_link)(const int64_t *xyz, int64_t n, const int64_t *h_starts, int32_t m, const int32_t *h_lo3,
+                       const int32_t *h_dims3, const int32_t *rank_of, int32_t *head, int32_t *next, ph_stream_t stream);
+int PH_FN(cells_max)(const float *h, int32_t c, const int32_t *head, const int32_t *next, int64_t v, int32_t m,
+                     const int32_t *sites, const int32_t *h_lo3, const int32_t *h_dims3, float *out, int32_t *coords,
+                     int32_t *status, ph_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

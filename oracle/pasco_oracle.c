@@ -25,6 +25,8 @@
  *   a8  union add                                    -> pho_map_insert + pho_scatter_add_rows
  *   a9  dense / to_sparse (lexicographic b,x,y,z)     -> pho_to_dense / pho_to_sparse_coords / pho_dense_gather
  *   a10 local max pooling                            -> pho_maxpool_fwd (transformer_predictor_v2.py:100-102)
+ *   a12 voxel max of the point features, a13 MIMO merge -> pho_points_* + pho_cells_max
+ *       (unet3d_sparse_v2.py:53-86, augmenter.py:13-27)
  *
  * Same C ABI as include/pasco_hip.h with the `pho_` prefix; pointers are host pointers and the
  * stream argument is ignored.  Plain C + OpenMP.
@@ -559,6 +561,98 @@ int pho_mask_compact(const uint8_t *mask, int64_t n, int32_t *keep_rows, int32_t
   for (int64_t i = 0; i < n; ++i)
     if (mask[i]) keep_rows[cnt++] = (int32_t)i;
   *n_keep = cnt;
+  return 0;
+}
+
+/* ---- a12 / a13: voxel max of the point features + MIMO merge (unet3d_sparse_v2.py:53-86, augmenter.py:13-27) -------- */
+int pho_points_bounds(const int64_t *xyz, int64_t n, int32_t *out6, ph_stream_t stream) {
+  (void)stream;
+  for (int a = 0; a < 3; ++a) out6[a] = INT_MAX, out6[3 + a] = INT_MIN;
+  for (int64_t i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) {
+      int64_t v = xyz[i * 3 + a];
+      int32_t w = v < INT_MIN ? INT_MIN : (v > INT_MAX ? INT_MAX : (int32_t)v);
+      if (w < out6[a]) out6[a] = w;
+      if (w > out6[3 + a]) out6[3 + a] = w;
+    }
+  return 0;
+}
+
+static int64_t pts_site(const int64_t *xyz, int64_t i, const int32_t *lo, const int32_t *dim) {
+  int64_t x = xyz[i * 3] - lo[0], y = xyz[i * 3 + 1] - lo[1], z = xyz[i * 3 + 2] - lo[2];
+  if (x < 0 || y < 0 || z < 0 || x >= dim[0] || y >= dim[1] || z >= dim[2]) return -1;
+  return (x * dim[1] + y) * dim[2] + z;
+}
+
+int pho_points_mark(const int64_t *xyz, int64_t n, const int32_t *h_lo3, const int32_t *h_dims3, uint8_t *flags,
+                    int32_t *status, ph_stream_t stream) {
+  (void)stream;
+  if (h_dims3[0] <= 0 || h_dims3[1] <= 0 || h_dims3[2] <= 0) return fail("points_mark: bad grid");
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t s = pts_site(xyz, i, h_lo3, h_dims3);
+    if (s >= 0) flags[s] = 1;
+    else if (status) *status |= 8;
+  }
+  return 0;
+}
+
+int pho_mask_compact_rank(const uint8_t *mask, int64_t n, int32_t *keep_rows, int32_t *rank_of, int32_t *n_keep, void *ws,
+                          int64_t ws_bytes, ph_stream_t stream) {
+  (void)ws; (void)ws_bytes; (void)stream;
+  int32_t cnt = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (mask[i]) {
+      if (rank_of) rank_of[i] = cnt;
+      keep_rows[cnt++] = (int32_t)i;
+    } else if (rank_of) rank_of[i] = -1;
+  }
+  *n_keep = cnt;
+  return 0;
+}
+
+int pho_points_link(const int64_t *xyz, int64_t n, const int64_t *h_starts, int32_t m, const int32_t *h_lo3,
+                    const int32_t *h_dims3, const int32_t *rank_of, int32_t *head, int32_t *next, ph_stream_t stream) {
+  (void)stream;
+  if (m < 1 || m > 8) return fail("points_link: needs 1 <= m <= 8");
+  int b = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    while (b + 1 < m && i >= h_starts[b + 1]) ++b;
+    int64_t s = pts_site(xyz, i, h_lo3, h_dims3);
+    if (s < 0) {
+      next[i] = -1;
+      continue;
+    }
+    int64_t cell = (int64_t)rank_of[s] * m + b;
+    next[i] = head[cell];
+    head[cell] = (int32_t)i;
+  }
+  return 0;
+}
+
+int pho_cells_max(const float *h, int32_t c, const int32_t *head, const int32_t *next, int64_t v, int32_t m,
+                  const int32_t *sites, const int32_t *h_lo3, const int32_t *h_dims3, float *out, int32_t *coords,
+                  int32_t *status, ph_stream_t stream) {
+  (void)stream;
+  if (c <= 0 || c % 4 || m < 1 || m > 8) return fail("cells_max: needs c %% 4 == 0 and 1 <= m <= 8");
+  for (int64_t r = 0; r < v; ++r) {
+    int nz = 0;
+    for (int b = 0; b < m; ++b) {
+      float *dst = out + (r * m + b) * c;
+      int p = head[r * m + b];
+      for (int ch = 0; ch < c; ++ch) dst[ch] = p >= 0 ? h[(int64_t)p * c + ch] : 0.f;
+      for (p = p >= 0 ? next[p] : -1; p >= 0; p = next[p])
+        for (int ch = 0; ch < c; ++ch)
+          if (h[(int64_t)p * c + ch] > dst[ch]) dst[ch] = h[(int64_t)p * c + ch];
+      for (int ch = 0; ch < c; ++ch) nz |= dst[ch] != 0.f;
+    }
+    int s = sites[r];
+    int z = s % h_dims3[2], xy = s / h_dims3[2];
+    coords[r * 4] = 0;
+    coords[r * 4 + 1] = xy / h_dims3[1] + h_lo3[0];
+    coords[r * 4 + 2] = xy % h_dims3[1] + h_lo3[1];
+    coords[r * 4 + 3] = z + h_lo3[2];
+    if (!nz && status) *status |= 8;
+  }
   return 0;
 }
 

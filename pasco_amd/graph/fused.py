@@ -218,14 +218,17 @@ def axis_rows(axis) -> torch.Tensor:
 
 
 def linear_bn_act(x2d: Optional[torch.Tensor], lin: nn.Linear, *, pro_bn=None, epi_bn=None, epi_act: int = ACT_NONE,
-                  min_rows: Optional[int] = None, in_split=None, emit: bool = False):
+                  min_rows: Optional[int] = None, in_split=None, emit: bool = False, emit_into: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None):
     """act(BN_epi(Linear(BN_pro(x)))) for a tall [N, cin] operand as ONE launch of the convolution kernel
     (identity map, eval BatchNorm folded into the gather prologue / store epilogue) - the point MLP of
     CylinderFeat (unet3d_sparse_v2.py:27-43) without separate normalisation / activation passes.
     Small N, CPU tensors: plain torch modules.
     `emit`: the result is read only by the next layer of the chain -> return (None, operand) with the result stored
     only as that layer's pre-split operand ((y, None) when the split path does not apply); `in_split` = such an
-    operand from the previous layer (then `x2d` is None)."""
+    operand from the previous layer (then `x2d` is None).  `emit_into` = the rows of a larger operand tensor the emitted
+    operand is to be written to (several inputs feeding one chain without concatenating them first); `out` = the same for
+    the fp32 result (kernel route only)."""
     cin, cout = lin.in_features, lin.out_features
     n = x2d.shape[0] if x2d is not None else in_split.shape[0]
     dev = x2d.device if x2d is not None else in_split.device
@@ -259,7 +262,7 @@ def linear_bn_act(x2d: Optional[torch.Tensor], lin: nn.Linear, *, pro_bn=None, e
                       bias=b, pro_scale=ps, pro_shift=pb, epi_scale=es, epi_shift=eb, epi_act=epi_act, split=split,
                       in_split=in_split if (split is not None and _PRESPLIT) else None,
                       emit_split=(None, None, ACT_NONE) if do_emit else None, want_out=not do_emit,
-                      in_split_has_prologue=True)
+                      in_split_has_prologue=True, out_split=emit_into if do_emit else None, out=None if do_emit else out)
     if not emit:
         return out
     return out if do_emit else (out, None)

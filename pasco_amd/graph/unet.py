@@ -15,7 +15,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import me as ME
-from ..me.backend import F16RangeError, backend_for
+import os
+
+from ..me.backend import F16RangeError, StatusError, backend_for
 from . import fused
 from .fused import ACT_RELU
 from .bottleneck import SPCDense3Dv2
@@ -70,13 +72,38 @@ class CylinderFeat(nn.Module):
             nn.Linear(128, 256), nn.BatchNorm1d(256), nn.ReLU(),
             nn.Linear(256, out_pt_fea_dim))
 
-    def _mlp(self, fea: torch.Tensor) -> torch.Tensor:
-        """PPmodel; in eval mode each Linear runs as one fused launch with its BatchNorms / ReLU folded in."""
+    def _mlp(self, fea) -> torch.Tensor:
+        """PPmodel; in eval mode each Linear runs as one fused launch with its BatchNorms / ReLU folded in.  `fea` may be the
+        LIST of the subnets' point features: the first layer then runs once per subnet and writes its rows of the shared
+        hidden operand - the [P, 283] concatenation (430 MB at S10) is never formed."""
+        if isinstance(fea, (list, tuple)) and (self.training or len(fea) == 1):
+            fea = torch.cat(list(fea), dim=0)
         if self.training:
             return self.PPmodel(fea)
         m = self.PPmodel
         # each hidden activation has one reader (the next Linear): it is stored only as that layer's operand
-        h, hs = fused.linear_bn_act(fea, m[1], pro_bn=m[0], epi_bn=m[2], epi_act=ACT_RELU, emit=True)
+        if isinstance(fea, (list, tuple)):
+            h = hs = None
+            dev = fea[0].device
+            total = sum(int(f.shape[0]) for f in fea)
+            c0, c1 = m[1].in_features, m[1].out_features
+            if fused.fusion() and fused._kernel_device(dev) and min(int(f.shape[0]) for f in fea) >= fused.MIN_ROWS_LINEAR:
+                from ..me.backend import backend_for as _bf
+                emit = fused.conv_precision() == "f16x3" and fused._PRESPLIT and c1 % 32 == 0 and _bf(dev).split_supported(c0, c1)
+                if emit:      # rows of the shared hidden operand
+                    hs = torch.empty((total, c1 // 32, 2, 32), dtype=torch.float16, device=dev)
+                else:         # odd input width (283 = 27 + 256): exact-fp32 launches, rows of the shared fp32 result
+                    h = torch.empty((total, c1), dtype=torch.float32, device=dev)
+                r0 = 0
+                for f in fea:
+                    r1 = r0 + int(f.shape[0])
+                    fused.linear_bn_act(f, m[1], pro_bn=m[0], epi_bn=m[2], epi_act=ACT_RELU, emit=emit,
+                                        emit_into=hs[r0:r1] if emit else None, out=None if emit else h[r0:r1])
+                    r0 = r1
+            else:
+                h, hs = fused.linear_bn_act(torch.cat(list(fea), dim=0), m[1], pro_bn=m[0], epi_bn=m[2], epi_act=ACT_RELU, emit=True)
+        else:
+            h, hs = fused.linear_bn_act(fea, m[1], pro_bn=m[0], epi_bn=m[2], epi_act=ACT_RELU, emit=True)
         h, hs = fused.linear_bn_act(h, m[4], epi_bn=m[5], epi_act=ACT_RELU, in_split=hs, emit=True)
         h, hs = fused.linear_bn_act(h, m[7], epi_bn=m[8], epi_act=ACT_RELU, in_split=hs, emit=True)
         return fused.linear_bn_act(h, m[10], in_split=hs)
@@ -196,15 +223,48 @@ class PascoNet(nn.Module):
         self.object_mask_threshold = object_mask_threshold
         self.thing_ids = tuple(thing_ids)
 
-    def prepare_input(self, in_feats: List[torch.Tensor], in_coords: List[torch.Tensor]) -> ME.SparseTensor:
-        """`self.feat` + `ME.SparseTensor` + `Augmenter.merge` (net_panoptic_sparse.py:548-550)."""
-        coords, feats = self.feat(in_feats, in_coords)
-        x = ME.SparseTensor(feats, coords.int())
-        x = merge_subnet_inputs(x, self.n_infers)
+    def prepare_input(self, in_feats: List[torch.Tensor], in_coords: List[torch.Tensor], fused_stage: bool = True) -> ME.SparseTensor:
+        """`self.feat` + `ME.SparseTensor` + `Augmenter.merge` (net_panoptic_sparse.py:548-550).  On a device with a backend
+        the voxel max and the merge are one sort-free pass over the points (`CBackend.pooled_merge`: no per-subnet voxel
+        tensor, no unique / sort, no dense detour); `fused_stage=False` or PASCO_INPUT_FUSED=0 runs the reference's
+        sequence of steps (CylinderFeat.forward, SparseTensor, merge)."""
+        x = self._prepare_input_fused(in_feats, in_coords) if fused_stage else None
+        if x is None:
+            coords, feats = self.feat(in_feats, in_coords)
+            x = ME.SparseTensor(feats, coords.int())
+            x = merge_subnet_inputs(x, self.n_infers)
         # the point MLP runs on the split-precision kernel too: should its range flag turn up in `forward`, the input stage is
         # redone on the exact path together with the rest (the raw inputs are only referenced, not copied)
         x.__dict__["_ph_source"] = (in_feats, in_coords)
         return x
+
+    def _prepare_input_fused(self, in_feats, in_coords):
+        dev = in_feats[0].device
+        if self.training or os.environ.get("PASCO_INPUT_FUSED", "1") == "0" or len(in_feats) != self.n_infers or \
+                not 1 <= self.n_infers <= 8:
+            return None
+        try:
+            be = backend_for(dev)             # the GPU library, or (tests) a registered CPU checker
+        except RuntimeError:
+            return None
+        if not be.has("cells_max"):
+            return None
+        starts = [0]
+        for c in in_coords:
+            starts.append(starts[-1] + int(c.shape[0]))
+        if starts[-1] == 0:
+            return None
+        xyz = torch.cat([c if c.dtype == torch.int64 else c.to(torch.int64) for c in in_coords], dim=0).contiguous()
+        h = self.feat._mlp(list(in_feats)).contiguous()
+        if h.shape[1] % 4 != 0:
+            return None
+        got = be.pooled_merge(h, xyz, starts)
+        if got is None:
+            return None
+        coords, feats = got
+        mgr = ME.CoordinateManager(D=3, device=dev)
+        key = mgr.insert_unique(coords, 1)              # occupied sites are distinct by construction: no dedup pass
+        return ME.SparseTensor(feats, coordinate_map_key=key, coordinate_manager=mgr)
 
     def forward(self, in_feat: ME.SparseTensor, global_min_coords, global_max_coords, min_Cs, max_Cs,
                 is_predict_panop=True, keep_override=None, subnets=None):
@@ -215,15 +275,24 @@ class PascoNet(nn.Module):
         try:
             ret = run()
             be.check_status(in_feat.device)     # flags of this stream's launches (f16 range, coordinate range, table clamp)
-        except F16RangeError:
-            # an activation left the f16 range of the split-precision operands (|x| > 2047 with the 2^5 operand scale): the
-            # step is redone with every product on the exact fp32 MFMA instead of failing - slower (2-3x), same graph, and
-            # counted so that a serving loop can see it happen
-            self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1
-            with fused.precision_override("f32"):
+        except StatusError as err:
+            if err.bits & ~(1 | 8):
+                raise                           # a coordinate no map / table can hold: nothing to redo
+            # bit 0: an activation left the f16 range of the split-precision operands (|x| > 2047 with the 2^5 operand scale)
+            # -> every product on the exact fp32 MFMA; bit 3: the fused input stage met an all-zero merged row -> the
+            # reference's sequence of steps for the input stage.  The step is redone instead of failing - slower, same graph -
+            # and counted so that a serving loop can see it happen.
+            if err.bits & 1:
+                self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1
+            if err.bits & 8:
+                self.input_fallbacks = getattr(self, "input_fallbacks", 0) + 1
+            import contextlib
+            with (fused.precision_override("f32") if err.bits & 1 else contextlib.nullcontext()):
                 src = in_feat.__dict__.get("_ph_source")
-                if src is not None:             # made by prepare_input: its point MLP may be what raised the flag
-                    in_feat = self.prepare_input(*src)
+                if src is not None:             # made by prepare_input: its point MLP / merge may be what raised the flag
+                    in_feat = self.prepare_input(*src, fused_stage=not (err.bits & 8))
+                elif err.bits & 8:
+                    raise
                 ret = run()
             be.check_status(in_feat.device)
         return ret

@@ -25,7 +25,8 @@ ABI_VERSION = 2          # include/pasco_hip.h PH_ABI_VERSION this binding was w
 
 class StatusError(RuntimeError):
     """A device-side status flag was raised since the last check (`CBackend.check_status`).  `bits` holds every flag:
-    1 = f16 range of a split-precision operand, 2 = unpackable coordinate, 4 = coordinate outside a per-axis table."""
+    1 = f16 range of a split-precision operand, 2 = unpackable coordinate, 4 = coordinate outside a per-axis table,
+    8 = the fused input stage must be redone on its general path (all-zero merged row)."""
 
     def __init__(self, bits: int, message: str):
         super().__init__(message)
@@ -114,6 +115,11 @@ _SIGNATURES = {
     "ens_merge": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "ens_finish": [_vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp],
     "attn_cross_split": [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
+    "points_bounds": [_vp, _i64, _vp, _vp],
+    "points_mark": [_vp, _i64, _vp, _vp, _vp, _vp, _vp],
+    "mask_compact_rank": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
+    "points_link": [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cells_max": [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"last_error": C.c_char_p, "workspace_bytes": _i64, "attn_workspace_bytes": _i64}
 _OPTIONAL = {}
@@ -343,7 +349,7 @@ class CBackend:
                  epi2_scale=None, epi2_shift=None, split=None, in_split: Optional[torch.Tensor] = None,
                  emit_split=None, want_out: bool = True,
                  out: Optional[torch.Tensor] = None, win=None, in_split_has_prologue: bool = False, axis=None,
-                 rowlist=None):
+                 rowlist=None, out_split: Optional[torch.Tensor] = None):
         """out = epilogue(sum_k gather(prologue(x))[k] @ W[k]) - one `ph_conv_fwd` launch (include/pasco_hip.h).
 
         `split` selects the split-precision products: (w_hi, w_lo, unscale) from `split_weight_f16` = mode 1
@@ -388,7 +394,11 @@ class CBackend:
             raise ValueError("conv: emit_split needs a mode-2 split and cout % 32 == 0")
         if out is None and (want_out or not emit):
             out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
-        out_split = torch.empty((n_out, cout // 32, 2, 32), dtype=torch.float16, device=dev) if emit else None
+        if emit and out_split is not None:       # caller-owned operand rows (a row slice of a larger operand tensor)
+            if out_split.dtype != torch.float16 or not out_split.is_contiguous() or out_split.numel() != n_out * 2 * cout:
+                raise ValueError("conv: out_split must be contiguous f16 [n_out, cout / 32, 2, 32]")
+        else:
+            out_split = torch.empty((n_out, cout // 32, 2, 32), dtype=torch.float16, device=dev) if emit else None
         if n_out == 0:
             return (out, out_split) if emit else out
         d = ConvDesc()
@@ -508,6 +518,8 @@ class CBackend:
            "pasco_amd.graph.fused.set_conv_precision('f32'); PascoNet.forward does so by itself)",
         2: "a coordinate outside the packable range (batch index 0..1023, coordinates -131072..131071) was inserted into a "
            "coordinate map; it would alias another voxel",
+        8: "the fused input stage met a merged row that is entirely zero or a point outside its box (ME.to_sparse drops such a "
+           "row: the stage has to run on its general path, PASCO_INPUT_FUSED=0; PascoNet.forward redoes it by itself)",
         4: "a coordinate outside the rows of a per-axis table residual (ph_conv_desc.axis_table) was clamped to the table's "
            "edge; the materialised forms are selected with PASCO_RESIZE_ABSORB=0 PASCO_PE_TABLE=0 PASCO_HEAD_ABSORB=0",
     }
@@ -526,9 +538,9 @@ class CBackend:
         v = int(snap.item())
         if v == 0:
             return
-        msgs = [self.STATUS_TEXT[b] for b in (1, 2, 4) if v & b]
-        if v & ~7:
-            msgs.append(f"unknown status bits {v & ~7:#x}")
+        msgs = [self.STATUS_TEXT[b] for b in (1, 2, 4, 8) if v & b]
+        if v & ~15:
+            msgs.append(f"unknown status bits {v & ~15:#x}")
         text = f"pasco_amd: device status {v:#x}: " + "; ".join(msgs)
         raise (F16RangeError if v == 1 else StatusError)(v, text)
 
@@ -620,6 +632,58 @@ class CBackend:
                                      self.stream(dev))
         self._check(rc, "mask_compact")
         return keep[: int(cnt.item())]
+
+    # -- input stage (include/pasco_hip.h points_* / cells_max) ---------------------------------------------------
+    MAX_INPUT_SITES = 1 << 27      # byte flags + int32 ranks per site of the points' bounding box: 640 MB at the cap
+
+    def pooled_merge(self, h: torch.Tensor, xyz: torch.Tensor, starts, bounds=None):
+        """Voxel max of the point features + MIMO channel concatenation in one sort-free pass (CylinderFeat's scatter_max
+        + Augmenter.merge): h fp32 [P, C] = the point MLP's output for the points of ALL subnets (subnet b's points are
+        rows starts[b] .. starts[b + 1]), xyz int64 [P, 3] their voxel indices -> (coords int32 [V, 4] = (0, x, y, z) in
+        lexicographic order, feats fp32 [V, M * C]).  Two host reads (bounding box - skipped with `bounds` = (lo3, hi3)
+        host ints - and the row count).  An all-zero merged row (which ME.to_sparse would drop) raises status bit 3 for
+        the caller's end-of-step check instead of costing a third read.  None when the box is too large for site flags."""
+        self._chk(h, torch.float32, "h")
+        self._chk(xyz, torch.int64, "xyz")
+        n, c = h.shape
+        m = len(starts) - 1
+        if not (c % 4 == 0 and 1 <= m <= 8 and tuple(xyz.shape) == (n, 3)):
+            raise ValueError("pooled_merge: h [P, C] with C % 4 == 0, xyz int64 [P, 3], at most 8 subnets")
+        dev = h.device
+        st = self.stream(dev)
+        if bounds is None:
+            b6 = torch.empty(6, dtype=torch.int32, device=dev)
+            self._check(self.fn["points_bounds"](_ptr(xyz), n, _ptr(b6), st), "points_bounds")
+            b6 = b6.tolist()
+            lo, hi = b6[:3], b6[3:]
+        else:
+            lo, hi = [int(v) for v in bounds[0]], [int(v) for v in bounds[1]]
+        dims = [hi[a] - lo[a] + 1 for a in range(3)]
+        nsites = dims[0] * dims[1] * dims[2]
+        if n == 0 or min(dims) <= 0 or nsites > self.MAX_INPUT_SITES:
+            return None
+        hlo, hdim = (_i32 * 3)(*lo), (_i32 * 3)(*dims)
+        hst = (_i64 * (m + 1))(*[int(v) for v in starts])
+        flags = torch.zeros(nsites, dtype=torch.uint8, device=dev)
+        status = _ptr(self.status_word(dev))
+        self._check(self.fn["points_mark"](_ptr(xyz), n, C.cast(hlo, _vp), C.cast(hdim, _vp), _ptr(flags), status, st),
+                    "points_mark")
+        sites = torch.empty(min(n, nsites), dtype=torch.int32, device=dev)
+        rank = torch.empty(nsites, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = self.workspace(nsites, dev)
+        self._check(self.fn["mask_compact_rank"](_ptr(flags), nsites, _ptr(sites), _ptr(rank), _ptr(cnt), _ptr(ws), ws.numel(),
+                                                 st), "mask_compact_rank")
+        v = int(cnt.item())
+        head = torch.full((max(v * m, 1),), -1, dtype=torch.int32, device=dev)
+        nxt = torch.empty(n, dtype=torch.int32, device=dev)
+        self._check(self.fn["points_link"](_ptr(xyz), n, C.cast(hst, _vp), m, C.cast(hlo, _vp), C.cast(hdim, _vp), _ptr(rank),
+                                           _ptr(head), _ptr(nxt), st), "points_link")
+        out = torch.empty((v, m * c), dtype=torch.float32, device=dev)
+        coords = torch.empty((v, 4), dtype=torch.int32, device=dev)
+        self._check(self.fn["cells_max"](_ptr(h), c, _ptr(head), _ptr(nxt), v, m, _ptr(sites), C.cast(hlo, _vp), C.cast(hdim, _vp),
+                                         _ptr(out), _ptr(coords), status, st), "cells_max")
+        return coords, out
 
     def gather_rows(self, src: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
         """src [N,C] (4-byte dtype), rows int32 [M] -> [M,C]; rows == -1 give zeros."""

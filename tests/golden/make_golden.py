@@ -338,7 +338,60 @@ def golden_transform_and_matching():
     save("transform_matching.npz", **arrays)
 
 
+@torch.no_grad()
+def golden_input_stage():
+    """The reference's OWN input stage: `CylinderFeat.forward` (PPmodel + sorted unique + scatter_max,
+    unet3d_sparse_v2.py:53-86) followed by `ME.SparseTensor` and `Augmenter.merge` (augmenter.py:13-27), on points of three
+    subnets with duplicated voxels and negative coordinates.  `torch_scatter.scatter_max` (not installed) is served by
+    torch's scatter_reduce(amax); the reference's `torch.randperm(..., device=get_device())` is GPU-only (get_device() is -1
+    on CPU tensors), so randperm is called without the device for the duration of the call - the shuffle is result-neutral
+    (it permutes rows ahead of a SORTED unique and a max)."""
+    import torch_scatter
+    import pasco.models.unet3d_sparse_v2 as ref_mod
+    from pasco.models.augmenter import Augmenter
+
+    def scatter_max(src, index, dim=0):
+        out = torch.full((int(index.max()) + 1, src.shape[1]), float("-inf"), dtype=src.dtype)
+        out.scatter_reduce_(0, index[:, None].expand_as(src), src, reduce="amax", include_self=True)
+        return out, None
+
+    torch_scatter.scatter_max = scatter_max
+    ref_mod.torch_scatter = torch_scatter
+    torch.manual_seed(11)
+    g = torch.Generator().manual_seed(11)
+    fea_dim, f, M = 12, 8, 3
+    feat = ref_mod.CylinderFeat(fea_dim=fea_dim, out_pt_fea_dim=f).eval()
+    randomise_bn(feat, g)
+    pt_fea, xy_ind = [], []
+    for i in range(M):
+        nvox = 350 + 40 * i
+        vox = torch.stack([torch.randint(-9, 30, (nvox,), generator=g), torch.randint(-5, 26, (nvox,), generator=g),
+                           torch.randint(-3, 9, (nvox,), generator=g)], dim=1)
+        reps = 1 + torch.poisson(torch.ones(nvox), generator=g).long()
+        ind = vox.repeat_interleave(reps, dim=0)
+        ind = ind[torch.randperm(ind.shape[0], generator=g)]
+        xy_ind.append(ind)
+        pt_fea.append(torch.randn(ind.shape[0], fea_dim, generator=g))
+    real_randperm = torch.randperm
+    torch.randperm = lambda n, device=None, **kw: real_randperm(n, **kw)
+    try:
+        unq, pooled = feat(pt_fea, xy_ind)
+    finally:
+        torch.randperm = real_randperm
+    x = ME.SparseTensor(pooled, unq.int())
+    merged = Augmenter().merge(x)
+    arrays = dict(cfg=np.array([fea_dim, f, M]), unq=unq, pooled=pooled, merged_C=merged.C, merged_F=merged.F)
+    for i in range(M):
+        arrays[f"pt_fea_{i}"], arrays[f"xy_ind_{i}"] = pt_fea[i], xy_ind[i]
+    arrays.update(sd_arrays("sd.", feat))
+    print("input stage", tuple(unq.shape), tuple(pooled.shape), tuple(merged.F.shape))
+    save("input_stage.npz", **arrays)
+
+
 if __name__ == "__main__":
+    if "--input-only" in sys.argv:
+        golden_input_stage()
+        sys.exit(0)
     if "--ensemble-only" in sys.argv:
         golden_ensemble()
         sys.exit(0)
@@ -353,3 +406,4 @@ if __name__ == "__main__":
     golden_unet(1, True, "m1_heavy")
     golden_ensemble()
     golden_transform_and_matching()
+    golden_input_stage()
