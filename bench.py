@@ -613,7 +613,10 @@ def main():
                                "note": "host side of a scene = Python launch loop under the GIL; ranks x scene threads "
                                        "compete for cores only across ranks (each rank pinned to its own cores)"}
         res["query_graph"] = net.transformer_predictor.query_graph_state()
-        res["range_fallbacks"] = int(getattr(net, "range_fallbacks", 0))
+        # steps that had to be redone (each costs a second pass): f16 range -> exact fp32, fused input stage -> general route,
+        # an optimistic shortcut that did not hold -> checked paths.  All 0 on the S10 scenes.
+        res["fallbacks"] = {"f16_range": int(getattr(net, "range_fallbacks", 0)), "input_stage": int(getattr(net, "input_fallbacks", 0)),
+                            "optimistic": int(getattr(net, "optimistic_fallbacks", 0))}
         if heads and world > 1 and last.get("out") is not None and "exchange" in last["out"]:
             ex = dict(last["out"]["exchange"])
             ex["MB_sent_per_rank_per_scene"] = round(ex["bytes_sent"] / 1e6, 2)

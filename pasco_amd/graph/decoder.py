@@ -202,16 +202,27 @@ class DecoderGenerativeSepConvV2(nn.Module):
         if subnets is not None:   # pad like the full batch would: longest subnet over all subnets
             for scale, x in xs.items():
                 pad_to[scale] = max(int(keep_mask(i, scale, x).sum()) for i in range(self.n_infers))
-        for i in (range(self.n_infers) if subnets is None else subnets):
-            for scale, x in xs.items():
+        # every (subnet, scale) prune of this branch depends only on tensors that exist now: their compactions are launched
+        # back to back and the row counts read ONCE (9 map events at M = 3, one synchronisation)
+        todo = [(i, scale, x, keep_mask(i, scale, x)) for i in (range(self.n_infers) if subnets is None else subnets)
+                for scale, x in xs.items()]
+        mgrs = {id(x.coordinate_manager) for _, _, x, _ in todo}
+        if len(mgrs) == 1 and todo:
+            mgr = todo[0][2].coordinate_manager
+            pruned = mgr.prune_batch([(x.coordinate_map_key, keep) for _, _, x, keep in todo])
+        else:
+            pruned = [x.coordinate_manager.prune(x.coordinate_map_key, keep) for _, _, x, keep in todo]
+        for (i, scale, x, keep), (out_key, rows) in zip(todo, pruned):
+            mgr = x.coordinate_manager
+            be = mgr.backend()
+            if scale == 1:      # logits and features of one map, same mask: one map event (decoder_v3.py:421-427)
                 logits = sem_logits_at_scales[scale][i]
-                keep = keep_mask(i, scale, x)
-                if scale == 1:
-                    sem_logits_pruneds.append(self.pruning(logits, keep))
-                xi = self.pruning(x, keep)
-                vf = self.voxel_feats[f"scale{scale}_infer{i}"]
-                h = fused.conv(xi, vf[0], epi_bn=vf[1], epi_act=ACT_RELU)
-                xs_infers[scale].append(fused.conv(h, vf[3]))
+                sem_logits_pruneds.append(ME.SparseTensor(be.gather_rows(logits.F.contiguous(), rows), coordinate_map_key=out_key,
+                                                          coordinate_manager=mgr))
+            xi = ME.SparseTensor(be.gather_rows(x.F.contiguous(), rows), coordinate_map_key=out_key, coordinate_manager=mgr)
+            vf = self.voxel_feats[f"scale{scale}_infer{i}"]
+            h = fused.conv(xi, vf[0], epi_bn=vf[1], epi_act=ACT_RELU)
+            xs_infers[scale].append(fused.conv(h, vf[3]))
         batched = {s: batch_sparse_tensor(v, pad_to[s]) for s, v in xs_infers.items()}
         sem_F, sem_C = batch_sparse_tensor(sem_logits_pruneds, pad_to[1])
         keep_pad = ((sem_F != 0).sum(-1) + (sem_C != 0).sum(-1)) != 0

@@ -179,8 +179,8 @@ class Ensembler(torch.nn.Module):
         iou = torch.where(union != 0, inter / union, torch.zeros_like(inter))
         iou = iou * (iou > iou_threshold)
         a_idx, b_idx = linear_sum_assignment((1.0 - iou).cpu().numpy())
-        a_idx = torch.as_tensor(a_idx, device=iou.device)
-        b_idx = torch.as_tensor(b_idx, device=iou.device)
+        ab = torch.as_tensor(np.stack([a_idx, b_idx])).to(iou.device)        # one upload for both index vectors
+        a_idx, b_idx = ab[0], ab[1]
         return a_idx, b_idx, iou[a_idx, b_idx]
 
     def ensemble_panop(self, panop_predictions, ensemble_sem_prob_denses, Ts, iou_threshold=0.2, cache: dict = None):
@@ -247,8 +247,9 @@ class Ensembler(torch.nn.Module):
         query_probs.append(anchor_q)
         out = []
         coords4 = torch.cat([torch.zeros((site_coords.shape[0], 1), dtype=torch.int32, device=dev), site_coords], dim=1)
+        nz_rows = be.mask_compact_many(flags)                                 # one host read for all outputs' row counts
         for i, m in enumerate(masks):
-            nz32 = be.mask_compact(flags[i])                                  # ME.to_sparse keeps non-zero sites
+            nz32 = nz_rows[i]                                                 # ME.to_sparse keeps non-zero sites
             c = be.gather_rows(coords4, nz32)
             mgr = ME.CoordinateManager(D=3, device=dev)
             key = mgr.insert_unique(c, 1)                                     # canonical sites are unique

@@ -74,6 +74,40 @@ def precision_override(mode: str):
         _TLS.precision = prev
 
 
+def optimistic() -> bool:
+    """True where the graph may take a shortcut WITHOUT the host read that would justify it, leaving a device-side flag for
+    the end-of-step check instead (`CBackend.optimistic_word`; `PascoNet.forward` redoes the step with the shortcuts off when
+    the flag was raised): the attention-mask block lookups, the "kept rows are the leading rows" selection of the mask
+    transformer's outputs, the dense bottleneck's "no all-zero site".  Each saves one host synchronisation per use; each is
+    exact whenever its flag stays down.  OFF unless the caller switched it on for the current thread
+    (`optimistic_override(True)`) - only a caller that ends the step with `CBackend.check_status` and can redo it may do so:
+    `PascoNet.forward` does (PASCO_OPTIMISTIC=0 keeps it off); `UNet3DV2` / the modules used on their own take the checked
+    paths."""
+    return bool(getattr(_TLS, "optimistic", False))
+
+
+def optimistic_word(device):
+    """The stream's optimistic word (`CBackend.optimistic_word`) when shortcuts are on and a backend serves `device`, else
+    None (the caller then takes its checked path)."""
+    if not optimistic():
+        return None
+    from ..me.backend import backend_for
+    try:
+        return backend_for(device).optimistic_word(device)
+    except RuntimeError:
+        return None
+
+
+@contextlib.contextmanager
+def optimistic_override(on: bool):
+    prev = getattr(_TLS, "optimistic", None)
+    _TLS.optimistic = bool(on)
+    try:
+        yield
+    finally:
+        _TLS.optimistic = prev
+
+
 def set_fusion(on: bool) -> None:
     """False = the UNFUSED drop-in route (INTEGRATION.md route (a)): `conv` runs what the reference's module trees
     launch on `pasco_amd.me` - MinkowskiBatchNorm, MinkowskiReLU / LeakyReLU, the plain `MinkowskiConvolution`
@@ -421,4 +455,4 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     return y
 
 
-__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "precision_override", "set_fusion", "fusion", "linear_rows", "split_rows_2d", "batched_rows_matmul", "prepare_batched_weights", "linear_bn_act", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]
+__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "precision_override", "optimistic", "optimistic_override", "set_fusion", "fusion", "linear_rows", "split_rows_2d", "batched_rows_matmul", "prepare_batched_weights", "linear_bn_act", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]

@@ -253,7 +253,7 @@ class MLP(nn.Module):
 
 
 class LazyRows:
-    """A sparse tensor whose feature rows are a row selection of a bigger matrix, gathered on first access
+    """A sparse tensor whose feature rows are a row selection (index tensor, or an int n = the n leading rows) of a bigger matrix, gathered on first access
     (`.F` / `.C` / `.features` / `.coordinates`, or `.materialize()` for the ME.SparseTensor itself)."""
 
     def __init__(self, src: torch.Tensor, rows: torch.Tensor, key, mgr):
@@ -263,7 +263,8 @@ class LazyRows:
 
     def materialize(self):
         if self._st is None:
-            self._st = ME.SparseTensor(self._src.index_select(0, self._rows), coordinate_map_key=self.coordinate_map_key,
+            rows = self._src[:self._rows] if isinstance(self._rows, int) else self._src.index_select(0, self._rows)
+            self._st = ME.SparseTensor(rows, coordinate_map_key=self.coordinate_map_key,
                                        coordinate_manager=self.coordinate_manager)
             self._src = self._rows = None
         return self._st
@@ -464,6 +465,18 @@ class TransformerPredictorV2(nn.Module):
                 if cache is not None:
                     cache["bounds"] = (mn32, mx32, fine_bad)
             fine = mgr._maps[key1]
+            opt = fused_mod.optimistic_word(dev)
+            if opt is not None:
+                # no host read: the kernel ORs its range flag into the stream's optimistic word and `fine_bad` is folded into
+                # it once per forward; the end-of-step check redoes the step on the exact path below should either be set
+                if cache is None or not cache.get("fine_bad_folded"):
+                    opt.bitwise_or_(fine_bad.to(torch.int32))
+                    if cache is not None:
+                        cache["fine_bad_folded"] = True
+                out = be.bits_block_or(src_C.reshape(B * N, 4).to(torch.int32).contiguous(), N, src_scale, fine.tkeys,
+                                       fine.tvals, bits1.contiguous(), mn32, mx32, range_word=opt)
+                bits = out.reshape(B, N, 4)
+                return bits, be.bits_or_reduce(bits)
             out, rng = be.bits_block_or(src_C.reshape(B * N, 4).to(torch.int32).contiguous(), N, src_scale, fine.tkeys,
                                         fine.tvals, bits1.contiguous(), mn32, mx32, want_range=True)
             if not bool(((rng != 0) | fine_bad).item()):
@@ -626,24 +639,45 @@ class TransformerPredictorV2(nn.Module):
             predictions_class.append(oc)
             predictions_mask.append(om)
         panop_predictions = []
+        # Optimistic row selection (no host read): the kept rows of subnet b are normally exactly its n_b leading rows (the
+        # batch was padded behind them).  That is verified ON THE DEVICE - one comparison of keep_pad with the expected
+        # pattern, folded into the stream's optimistic word - and the outputs are row slices; should it not hold, the
+        # end-of-step check redoes the step through the compaction below.
+        lead = None
+        opt = fused_mod.optimistic_word(keep_pad.device) if sem_tensors is not None else None
+        if opt is not None and all(t is not None and t.F.shape[0] <= voxel_coord.shape[1] for t in sem_tensors):
+            lead = [int(t.F.shape[0]) for t in sem_tensors]
+            bad = None
+            for b, n_b in enumerate(lead):      # leading n_b rows kept, nothing behind them (host ints: no copy)
+                v = ~keep_pad[b, :n_b].all() | keep_pad[b, n_b:].any()
+                bad = v if bad is None else (bad | v)
+            opt.bitwise_or_(bad.to(torch.int32))
         for b in range(B):
-            kept = keep_pad[b].nonzero().reshape(-1)          # one compaction per subnet, reused by every mask
-            src = sem_tensors[b] if sem_tensors is not None else None
-            if src is not None and kept.shape[0] == src.F.shape[0] and src.F.shape[0] <= voxel_coord.shape[1]:
-                # kept = 0 .. n-1 (ascending, distinct, all below n): the rows ARE the source tensor's rows
-                first = ME.SparseTensor(predictions_mask[0][b].index_select(0, kept),
-                                        coordinate_map_key=src.coordinate_map_key, coordinate_manager=src.coordinate_manager)
+            if lead is not None:
+                src, n_b = sem_tensors[b], lead[b]
+                key, mgr = src.coordinate_map_key, src.coordinate_manager
+                first = ME.SparseTensor(predictions_mask[0][b][:n_b], coordinate_map_key=key, coordinate_manager=mgr)
+                aux_masks = [first] + [LazyRows(m[b], n_b, key, mgr) for m in predictions_mask[1:-1]]
+                last = ME.SparseTensor(predictions_mask[-1][b][:n_b], coordinate_map_key=key,
+                                       coordinate_manager=mgr) if len(predictions_mask) > 1 else first
             else:
-                first = ME.SparseTensor(predictions_mask[0][b].index_select(0, kept), voxel_coord[b].index_select(0, kept))
-            key, mgr = first.coordinate_map_key, first.coordinate_manager
-            idx = first.unique_index        # None unless coordinates repeat
-            rows = kept if idx is None else kept.index_select(0, idx.long())
-            # Only the LAST prediction's voxel logits feed the inference path (ensembling, panoptic_inference); the
-            # auxiliary ones exist for the training loss (net_panoptic_sparse.py:437-451).  Each is an 84 MB row gather
-            # at S10, so they are gathered when somebody asks for them, not per step.
-            aux_masks = [first] + [LazyRows(m[b], rows, key, mgr) for m in predictions_mask[1:-1]]
-            last = ME.SparseTensor(predictions_mask[-1][b].index_select(0, rows), coordinate_map_key=key,
-                                   coordinate_manager=mgr) if len(predictions_mask) > 1 else first
+                kept = keep_pad[b].nonzero().reshape(-1)          # one compaction per subnet, reused by every mask
+                src = sem_tensors[b] if sem_tensors is not None else None
+                if src is not None and kept.shape[0] == src.F.shape[0] and src.F.shape[0] <= voxel_coord.shape[1]:
+                    # kept = 0 .. n-1 (ascending, distinct, all below n): the rows ARE the source tensor's rows
+                    first = ME.SparseTensor(predictions_mask[0][b].index_select(0, kept),
+                                            coordinate_map_key=src.coordinate_map_key, coordinate_manager=src.coordinate_manager)
+                else:
+                    first = ME.SparseTensor(predictions_mask[0][b].index_select(0, kept), voxel_coord[b].index_select(0, kept))
+                key, mgr = first.coordinate_map_key, first.coordinate_manager
+                idx = first.unique_index        # None unless coordinates repeat
+                rows = kept if idx is None else kept.index_select(0, idx.long())
+                # Only the LAST prediction's voxel logits feed the inference path (ensembling, panoptic_inference); the
+                # auxiliary ones exist for the training loss (net_panoptic_sparse.py:437-451).  Each is an 84 MB row gather
+                # at S10, so they are gathered when somebody asks for them, not per step.
+                aux_masks = [first] + [LazyRows(m[b], rows, key, mgr) for m in predictions_mask[1:-1]]
+                last = ME.SparseTensor(predictions_mask[-1][b].index_select(0, rows), coordinate_map_key=key,
+                                       coordinate_manager=mgr) if len(predictions_mask) > 1 else first
             classes = [c[b].unsqueeze(0) for c in predictions_class]
             panop_predictions.append({
                 "query_logits": classes[-1],

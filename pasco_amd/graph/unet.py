@@ -158,10 +158,14 @@ class UNet3DV2(nn.Module):
         """stride-8 features -> dense grid -> SPCDense3Dv2 -> back to a sparse tensor that shares the
         encoder's coordinate manager (unet3d_sparse_v2.py:182-214)."""
         scale = deepest.tensor_stride[0]
-        gmin = global_min_coords.to(deepest.device)
-        max_c = deepest.C[:, 1:].max(dim=0)[0].to(torch.int32)
-        gmax = torch.max(global_max_coords.to(deepest.device).to(torch.int32), max_c)
-        size = (compute_scene_size(gmin, gmax, scale) // scale).tolist()
+        dev = deepest.device
+        gmin = global_min_coords.to(dev)
+        max_c = deepest.C[:, 1:].max(dim=0)[0].to(torch.int64)
+        # ONE host read for everything the host needs here (bounds + the largest stride-8 coordinate)
+        hv = torch.cat([gmin.reshape(-1).to(torch.int64), global_max_coords.to(dev).reshape(-1).to(torch.int64), max_c]).tolist()
+        gmin_h = hv[0:3]
+        gmax_h = [max(a, b) for a, b in zip(hv[3:6], hv[6:9])]
+        size = [-(-(mx - mn + 1) // scale) for mn, mx in zip(gmin_h, gmax_h)]      # compute_scene_size(...) // scale
         # channels-last rows of the dense grid (sites in lexicographic order = ME.to_sparse order);
         # the reference goes sparse -> dense [1,C,X,Y,Z] -> Conv3d stack -> ME.to_sparse, this is the
         # same computation without leaving the row layout.
@@ -170,16 +174,22 @@ class UNet3DV2(nn.Module):
         c = deepest.F.shape[1]
         site = torch.div(deepest.C[:, 1:].to(torch.int64) - gmin.to(torch.int64).reshape(1, 3), scale,
                          rounding_mode="floor")
-        inside = ((site >= 0) & (site < torch.tensor(dims[1:], device=site.device))).all(dim=1)
+        inside = (site >= 0).all(dim=1) & (site[:, 0] < dims[1]) & (site[:, 1] < dims[2]) & (site[:, 2] < dims[3])
         lin = ((deepest.C[:, 0].to(torch.int64) * dims[1] + site[:, 0]) * dims[2] + site[:, 1]) * dims[3] + site[:, 2]
-        rows = deepest.F.new_zeros((nsites, c))
-        rows[lin[inside]] = deepest.F[inside]
+        rows = deepest.F.new_zeros((nsites + 1, c))            # one spare row takes the rows outside the grid (no host read)
+        rows.index_copy_(0, torch.where(inside, lin, torch.full_like(lin, nsites)), deepest.F)
+        rows = rows[:nsites]
         dense3d, dropout = self.dense3d[0], self.dense3d[1]
         assert not dropout.training
         out = dense3d.forward_rows(rows, dims)
         site_coords, _ = dense3d._grid_tables(dims, out.device)
         nz = (out != 0).any(dim=1)                     # ME.to_sparse drops all-zero sites
-        if not bool(nz.all()):
+        opt = fused.optimistic_word(dev)
+        if opt is not None:
+            # every site of the bottleneck's output is normally non-zero (biases, BatchNorm shifts): keep them all and leave
+            # the verification to the end-of-step check instead of reading it here
+            opt.bitwise_or_((~nz).any().to(torch.int32))
+        elif not bool(nz.all()):
             out, site_coords = out[nz].contiguous(), site_coords[nz]
         coords = site_coords.clone()
         coords[:, 1:] = coords[:, 1:] * scale + gmin.reshape(1, -1).to(coords.dtype)
@@ -273,10 +283,12 @@ class PascoNet(nn.Module):
         run = lambda: self.unet3d(in_feat, 1, global_min_coords, global_max_coords, min_Cs, max_Cs,
                                   is_predict_panop=is_predict_panop, keep_override=keep_override, subnets=subnets)
         try:
-            ret = run()
+            # this function ends the step with the status check and can redo it: the graph may take its optimistic shortcuts
+            with fused.optimistic_override(os.environ.get("PASCO_OPTIMISTIC", "1") != "0"):
+                ret = run()
             be.check_status(in_feat.device)     # flags of this stream's launches (f16 range, coordinate range, table clamp)
         except StatusError as err:
-            if err.bits & ~(1 | 8):
+            if err.bits & ~(1 | 8 | 16):
                 raise                           # a coordinate no map / table can hold: nothing to redo
             # bit 0: an activation left the f16 range of the split-precision operands (|x| > 2047 with the 2^5 operand scale)
             # -> every product on the exact fp32 MFMA; bit 3: the fused input stage met an all-zero merged row -> the
@@ -286,8 +298,11 @@ class PascoNet(nn.Module):
                 self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1
             if err.bits & 8:
                 self.input_fallbacks = getattr(self, "input_fallbacks", 0) + 1
+            if err.bits & 16:                   # an optimistic shortcut did not hold: the checked paths serve this scene
+                self.optimistic_fallbacks = getattr(self, "optimistic_fallbacks", 0) + 1
             import contextlib
-            with (fused.precision_override("f32") if err.bits & 1 else contextlib.nullcontext()):
+            with (fused.precision_override("f32") if err.bits & 1 else contextlib.nullcontext()), \
+                    (fused.optimistic_override(False) if err.bits & 16 else contextlib.nullcontext()):
                 src = in_feat.__dict__.get("_ph_source")
                 if src is not None:             # made by prepare_input: its point MLP / merge may be what raised the flag
                     in_feat = self.prepare_input(*src, fused_stage=not (err.bits & 8))

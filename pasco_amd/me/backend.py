@@ -26,7 +26,8 @@ ABI_VERSION = 2          # include/pasco_hip.h PH_ABI_VERSION this binding was w
 class StatusError(RuntimeError):
     """A device-side status flag was raised since the last check (`CBackend.check_status`).  `bits` holds every flag:
     1 = f16 range of a split-precision operand, 2 = unpackable coordinate, 4 = coordinate outside a per-axis table,
-    8 = the fused input stage must be redone on its general path (all-zero merged row)."""
+    8 = the fused input stage must be redone on its general path (all-zero merged row), 16 = an optimistic shortcut of the
+    graph did not hold (redo with the checked paths)."""
 
     def __init__(self, bits: int, message: str):
         super().__init__(message)
@@ -490,13 +491,23 @@ class CBackend:
         """Device word the kernels OR their flags into: one per (device, STREAM), like the scratch buffers - every kernel
         that can raise a flag of a scene and the read-and-clear of `check_status` are then ordered by the stream, so scenes
         in flight on other streams neither lose a flag nor see a foreign one."""
+        return self._status_pair(device)[0:1]
+
+    def optimistic_word(self, device) -> torch.Tensor:
+        """Second word of the stream's status pair: kernels and torch ops OR a non-zero value into it when an OPTIMISTIC
+        shortcut of the graph turned out not to hold (a fast path taken without the host read that would have justified it
+        - see `pasco_amd.graph.fused.optimistic`).  `check_status` reports it as bit 4 (16) and the caller redoes the step
+        with the shortcuts off."""
+        return self._status_pair(device)[1:2]
+
+    def _status_pair(self, device) -> torch.Tensor:
         pinned = getattr(self._tls, "status_pin", None)
         if pinned is not None:
             return pinned
         key = ("status",) + self._stream_key(torch.device(device))
         t = self._ws.get(key)
         if t is None:
-            t = torch.zeros(1, dtype=torch.int32, device=device)
+            t = torch.zeros(2, dtype=torch.int32, device=device)
             self._ws[key] = t
         return t
 
@@ -507,7 +518,7 @@ class CBackend:
         the replay is launched on, and checked from, the caller's stream)."""
         prev = getattr(self._tls, "status_pin", None)
         self._tls.status_pin = None
-        self._tls.status_pin = self.status_word(device)
+        self._tls.status_pin = self._status_pair(device)
         try:
             yield
         finally:
@@ -518,6 +529,9 @@ class CBackend:
            "pasco_amd.graph.fused.set_conv_precision('f32'); PascoNet.forward does so by itself)",
         2: "a coordinate outside the packable range (batch index 0..1023, coordinates -131072..131071) was inserted into a "
            "coordinate map; it would alias another voxel",
+        16: "an optimistic shortcut of the graph did not hold (a fast path taken without the host read that would justify it: "
+            "attention-mask block lookups with a coordinate outside its subnet's box, kept rows that are not the leading rows, "
+            "an all-zero bottleneck site); PASCO_OPTIMISTIC=0 takes the checked paths; PascoNet.forward redoes the step by itself",
         8: "the fused input stage met a merged row that is entirely zero or a point outside its box (ME.to_sparse drops such a "
            "row: the stage has to run on its general path, PASCO_INPUT_FUSED=0; PascoNet.forward redoes it by itself)",
         4: "a coordinate outside the rows of a per-axis table residual (ph_conv_desc.axis_table) was clamped to the table's "
@@ -535,12 +549,14 @@ class CBackend:
             return
         snap = t.clone()          # stream-ordered: after every kernel of this stream that could raise a flag ...
         t.zero_()                 # ... and before any later one
-        v = int(snap.item())
+        v, opt = snap.tolist()
+        if opt != 0:
+            v |= 16
         if v == 0:
             return
-        msgs = [self.STATUS_TEXT[b] for b in (1, 2, 4, 8) if v & b]
-        if v & ~15:
-            msgs.append(f"unknown status bits {v & ~15:#x}")
+        msgs = [self.STATUS_TEXT[b] for b in (1, 2, 4, 8, 16) if v & b]
+        if v & ~31:
+            msgs.append(f"unknown status bits {v & ~31:#x}")
         text = f"pasco_amd: device status {v:#x}: " + "; ".join(msgs)
         raise (F16RangeError if v == 1 else StatusError)(v, text)
 
@@ -685,6 +701,27 @@ class CBackend:
                                          _ptr(out), _ptr(coords), status, st), "cells_max")
         return coords, out
 
+    def mask_compact_many(self, masks) -> list:
+        """`mask_compact` of several independent masks with ONE host read for all their counts (the compactions are
+        launched back to back, each with its own scratch; the counts come back in one small copy) -> list of int32 row
+        tensors.  What a sequence of prunes that do not depend on one another costs: one synchronisation, not one each."""
+        masks = [m.view(torch.uint8) if m.dtype == torch.bool else m for m in masks]
+        if not masks:
+            return []
+        dev = masks[0].device
+        cnts = torch.zeros(len(masks), dtype=torch.int32, device=dev)
+        keeps = []
+        for j, mask in enumerate(masks):
+            self._chk(mask, torch.uint8, "mask")
+            n = mask.shape[0]
+            keep = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+            ws = torch.empty(int(self.fn["workspace_bytes"](int(n))), dtype=torch.uint8, device=dev)   # one per launch
+            rc = self.fn["mask_compact"](_ptr(mask), n, _ptr(keep), cnts[j:j + 1].data_ptr(), _ptr(ws), ws.numel(),
+                                         self.stream(dev))
+            self._check(rc, "mask_compact")
+            keeps.append(keep)
+        return [k[:c] for k, c in zip(keeps, cnts.tolist())]
+
     def gather_rows(self, src: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
         """src [N,C] (4-byte dtype), rows int32 [M] -> [M,C]; rows == -1 give zeros."""
         if src.element_size() != 4:
@@ -803,15 +840,15 @@ class CBackend:
         return out
 
     def bits_block_or(self, level_coords: torch.Tensor, n_per_b: int, s: int, tkeys, tvals, bits: torch.Tensor, lo=None,
-                      hi=None, want_range: bool = False):
+                      hi=None, want_range: bool = False, range_word: Optional[torch.Tensor] = None):
         """level_coords int32 [M, 4] (batch = row // n_per_b), fine-map table (tkeys, tvals) and its bit rows [N1, 4] ->
         bits of the level voxels' s^3 blocks [M, 4] (+ a device flag word: some coordinate outside [lo, hi])."""
         self._chk(level_coords, torch.int32, "level_coords")
         self._chk(bits, torch.int32, "bits")
         m = level_coords.shape[0]
         out = torch.empty((m, 4), dtype=torch.int32, device=bits.device)
-        rng = torch.zeros(1, dtype=torch.int32, device=bits.device) if want_range else None
-        if want_range:
+        rng = torch.zeros(1, dtype=torch.int32, device=bits.device) if want_range else range_word   # caller's word: OR-ed into
+        if rng is not None:
             self._chk(lo, torch.int32, "lo")
             self._chk(hi, torch.int32, "hi")
         rc = self.fn["bits_block_or"](_ptr(level_coords), m, int(n_per_b), int(s), _ptr(tkeys), _ptr(tvals), tkeys.numel(),

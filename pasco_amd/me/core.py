@@ -232,6 +232,26 @@ class CoordinateManager:
         self.__dict__["_last_prune"] = (in_key, mask, mask._version, out_key, keep)
         return out_key, keep
 
+    def prune_batch(self, jobs):
+        """`prune` for several (in_key, mask) jobs that do not depend on one another - the per-subnet prunes of the panoptic
+        branch (decoder_v3.py:421-432) - with ONE host read for all their row counts -> list of (out_key, keep_rows).
+        Jobs that repeat an earlier (in_key, mask tensor) pair share its map event, like `prune`."""
+        be = self.backend()
+        uniq, order = {}, []
+        for in_key, mask in jobs:
+            m = self._maps[in_key]
+            assert mask.shape[0] == m.n, f"mask has {mask.shape[0]} rows, map has {m.n}"
+            k = (in_key, id(mask), mask._version)
+            if k not in uniq:
+                uniq[k] = len(order)
+                order.append((in_key, mask))
+        keeps = be.mask_compact_many([mask.contiguous() for _, mask in order])
+        done = []
+        for (in_key, mask), keep in zip(order, keeps):
+            coords = be.gather_rows(self._maps[in_key].coords, keep)
+            done.append((self.insert_unique(coords, in_key.tensor_stride), keep))
+        return [done[uniq[(in_key, id(mask), mask._version)]] for in_key, mask in jobs]
+
     def union(self, key_a: CoordinateMapKey, key_b: CoordinateMapKey):
         """-> (out_key, rows_a2out, rows_b2out): lhs rows first, then unseen rhs rows."""
         assert key_a.tensor_stride == key_b.tensor_stride, "union needs equal tensor strides"

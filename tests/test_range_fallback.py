@@ -117,3 +117,46 @@ def test_status_word_is_per_stream(hip):
             hip.check_status(dev)
         hip.check_status(dev)
     torch.cuda.synchronize()
+
+
+def _same(a, b):
+    for s in b["sem_logits_at_scales"]:
+        for x, y in zip(a["sem_logits_at_scales"][s], b["sem_logits_at_scales"][s]):
+            assert torch.equal(x.C.cpu(), y.C.cpu()) and torch.equal(x.F.cpu(), y.F.cpu())
+    for x, y in zip(a["panop_predictions"], b["panop_predictions"]):
+        assert torch.equal(x["voxel_logits"].C.cpu(), y["voxel_logits"].C.cpu())
+        assert torch.equal(x["voxel_logits"].F.cpu(), y["voxel_logits"].F.cpu())
+        assert torch.equal(x["query_logits"].cpu(), y["query_logits"].cpu())
+
+
+def test_optimistic_shortcuts_give_the_checked_paths_results_cpu(oracle_registered, monkeypatch):
+    """`PascoNet.forward` takes its shortcuts without host reads (attention-mask block lookups, leading-rows selection, no
+    all-zero bottleneck site) and validates them at the end of the step: whether they held (no fallback) or not (the step is
+    redone on the checked paths), the results are those of PASCO_OPTIMISTIC=0 bit for bit.  A forced violation must be seen."""
+    dev = torch.device("cpu")
+    oracle_registered.status_word(dev).zero_()
+    oracle_registered.optimistic_word(dev).zero_()
+    net, scene = _net_scene()
+    monkeypatch.setenv("PASCO_OPTIMISTIC", "0")
+    ref = _run(net, scene, "cpu")
+    monkeypatch.delenv("PASCO_OPTIMISTIC")
+    net.optimistic_fallbacks = 0
+    got = _run(net, scene, "cpu")
+    _same(got, ref)
+    natural = net.optimistic_fallbacks
+    # a violation nobody can miss: raise the flag from inside the step
+    from pasco_amd.graph import decoder
+    inner = decoder.DecoderGenerativeSepConvV2.predict_panop
+
+    def poisoned(self, *a, **k):
+        from pasco_amd.graph import fused as f
+        w = f.optimistic_word(dev)
+        if w is not None:
+            w.fill_(1)
+        return inner(self, *a, **k)
+
+    monkeypatch.setattr(decoder.DecoderGenerativeSepConvV2, "predict_panop", poisoned)
+    got2 = _run(net, scene, "cpu")
+    assert net.optimistic_fallbacks == natural + 1
+    _same(got2, ref)
+    oracle_registered.check_status(dev)                           # nothing left behind
