@@ -35,6 +35,8 @@ class Encoder3DSepV2(nn.Module):
 
     def forward(self, x: ME.SparseTensor):
         assert not self.training, "inference only"
+        # the three strided coordinate maps depend on the input coordinates only: built together, one host read for their sizes
+        x.coordinate_manager.stride_chain(x.coordinate_map_key, 3)
         # each stage's last launch also writes the next stage's first operand (fused.conv emit_next)
         s1 = run_sequential(self.s1, fused.conv(x, self.enc_in_feats, emit_next=first_prologue(self.s1)),
                             emit_last=first_prologue(self.s1s2))

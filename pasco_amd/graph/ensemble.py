@@ -178,10 +178,13 @@ class Ensembler(torch.nn.Module):
         union = anchor_mask.sum(0)[:, None] + aux_mask.sum(0)[None, :] - inter
         iou = torch.where(union != 0, inter / union, torch.zeros_like(inter))
         iou = iou * (iou > iou_threshold)
-        a_idx, b_idx = linear_sum_assignment((1.0 - iou).cpu().numpy())
-        ab = torch.as_tensor(np.stack([a_idx, b_idx])).to(iou.device)        # one upload for both index vectors
-        a_idx, b_idx = ab[0], ab[1]
-        return a_idx, b_idx, iou[a_idx, b_idx]
+        iou_h = iou.cpu()                                                    # the one host read of the matching step
+        a_idx, b_idx = linear_sum_assignment((1.0 - iou_h).numpy())
+        matched_h = iou_h[a_idx, b_idx]                                      # host copy: the query filter is decided there too
+        ab = torch.as_tensor(np.stack([a_idx, b_idx]))
+        if iou.is_cuda:                                                      # pinned staging: the upload does not synchronise
+            ab = ab.pin_memory().to(iou.device, non_blocking=True)
+        return ab[0], ab[1], matched_h
 
     def ensemble_panop(self, panop_predictions, ensemble_sem_prob_denses, Ts, iou_threshold=0.2, cache: dict = None):
         """-> one dict per subnet + the ensemble: {"sem_probs", "voxel_probs" (SparseTensors on the
@@ -228,10 +231,12 @@ class Ensembler(torch.nn.Module):
             ens_merge(anchor_m, masks[i], b_idx.to(torch.int32).contiguous(), i)
             ious.append(iou)
         Q = anchor_m.shape[1]
-        if ious:
-            keep = torch.stack(ious, dim=0).mean(0) > iou_threshold
-            keep_cols = keep.nonzero().reshape(-1)
-            anchor_q = anchor_q[:, keep, :]
+        if ious:       # matched IoUs are host tensors (they came down with the cost matrix): the filter costs no device read
+            keep_h = torch.stack(ious, dim=0).mean(0) > iou_threshold
+            keep_cols = keep_h.nonzero().reshape(-1)
+            if dev.type == "cuda":
+                keep_cols = keep_cols.pin_memory().to(dev, non_blocking=True)
+            anchor_q = anchor_q.index_select(1, keep_cols)
         else:
             keep_cols = torch.arange(Q, device=dev)
         # zero the ensemble where the ensembled semantic class is "empty"

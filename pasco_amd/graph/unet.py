@@ -193,8 +193,9 @@ class UNet3DV2(nn.Module):
             out, site_coords = out[nz].contiguous(), site_coords[nz]
         coords = site_coords.clone()
         coords[:, 1:] = coords[:, 1:] * scale + gmin.reshape(1, -1).to(coords.dtype)
-        return ME.SparseTensor(features=out, coordinates=coords, tensor_stride=scale,
-                               coordinate_manager=deepest.coordinate_manager)
+        mgr = deepest.coordinate_manager
+        key = mgr.insert_unique(coords.to(torch.int32).contiguous(), scale)   # grid sites are distinct: no dedup pass, no count read
+        return ME.SparseTensor(out, coordinate_map_key=key, coordinate_manager=mgr)
 
     def forward(self, in_feat, bs, global_min_coords, global_max_coords, min_Cs, max_Cs,
                 is_predict_panop=True, keep_override=None, subnets=None):

@@ -227,27 +227,37 @@ class CBackend:
 
     def map_insert(self, coords: torch.Tensor, dedup: bool = True):
         """coords int32 [N,4] -> (tkeys, tvals, row2uniq|None, uniq_rows|None, n_uniq)."""
+        tkeys, tvals, row2uniq, uniq_rows, n_uniq = self.map_insert_launch(coords, dedup)
+        if not dedup:
+            return tkeys, tvals, None, None, coords.shape[0]
+        nu = int(n_uniq.item())
+        return tkeys, tvals, row2uniq, uniq_rows[:nu], nu
+
+    def map_insert_launch(self, coords: torch.Tensor, dedup: bool = True, n_uniq: Optional[torch.Tensor] = None):
+        """The launches of `map_insert` without its host read: -> (tkeys, tvals, row2uniq [N], uniq_rows [N] (the first
+        n_uniq entries valid), n_uniq int32 device tensor [1]); several independent inserts can then share ONE read of their
+        counts (`n_uniq` = a one-element slice of a caller's count vector).  Each call takes its own scratch."""
         self._chk(coords, torch.int32, "coords")
         n = coords.shape[0]
         dev = coords.device
         cap = self.table_capacity(n)
         tkeys = torch.empty(cap, dtype=torch.int64, device=dev)
         tvals = torch.empty(cap, dtype=torch.int32, device=dev)
-        ws = self.workspace(n, dev)
+        ws = torch.empty(int(self.fn["workspace_bytes"](int(n))), dtype=torch.uint8, device=dev)
         if dedup:
             row2uniq = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
             uniq_rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-            n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
+            if n_uniq is None:
+                n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
             rc = self.fn["map_insert"](_ptr(coords), n, _ptr(tkeys), _ptr(tvals), cap, _ptr(row2uniq),
-                                       _ptr(uniq_rows), _ptr(n_uniq), _ptr(ws), ws.numel(), _ptr(self.status_word(dev)),
+                                       _ptr(uniq_rows), n_uniq.data_ptr(), _ptr(ws), ws.numel(), _ptr(self.status_word(dev)),
                                        self.stream(dev))
             self._check(rc, "map_insert")
-            nu = int(n_uniq.item())
-            return tkeys, tvals, row2uniq[:n], uniq_rows[:nu], nu
+            return tkeys, tvals, row2uniq[:n], uniq_rows, n_uniq
         rc = self.fn["map_insert"](_ptr(coords), n, _ptr(tkeys), _ptr(tvals), cap, None, None, None,
                                    _ptr(ws), ws.numel(), _ptr(self.status_word(dev)), self.stream(dev))
         self._check(rc, "map_insert")
-        return tkeys, tvals, None, None, n
+        return tkeys, tvals, None, None, None
 
     def map_find(self, query: torch.Tensor, tkeys: torch.Tensor, tvals: torch.Tensor) -> torch.Tensor:
         self._chk(query, torch.int32, "query")

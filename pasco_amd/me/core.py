@@ -186,6 +186,50 @@ class CoordinateManager:
         self._origin[key] = (in_key, row2uniq)
         return key
 
+    def stride_chain(self, in_key: CoordinateMapKey, levels: int) -> List[CoordinateMapKey]:
+        """The maps `stride(stride(...stride(in_key, 2)..., 2), 2)` of an encoder (k = 2, s = 2 down-convolutions,
+        encoder_v2.py:124,133,142) built together: level l's coordinates are floor(c / 2^l) 2^l of the INPUT rows and its rows
+        are numbered by their first contributing input row either way (a level's rows are ordered by first contributor, so
+        "first level-(l-1) row" and "first input row" order the level-l voxels identically) - the `levels` hash inserts are
+        independent and share ONE host read of their row counts instead of one each.  Registers the maps in the stride cache
+        under the keys the step-by-step calls look up; -> their keys."""
+        keys, todo, k = [], [], in_key
+        for l in range(levels):
+            nxt = self._stride_cache.get((k, (2, 2, 2)))
+            if nxt is None:
+                break
+            keys.append(nxt)
+            k = nxt
+        if len(keys) == levels:
+            return keys
+        if keys:               # partly built step by step already: finish the same way
+            for l in range(len(keys), levels):
+                keys.append(self.stride(keys[-1] if keys else in_key, 2))
+            return keys
+        m = self._maps[in_key]
+        be = self.backend()
+        ts0 = in_key.tensor_stride[0]
+        cnts = torch.zeros(levels, dtype=torch.int32, device=m.coords.device)
+        parts = []
+        for l in range(levels):
+            floored = be.coords_floor(m.coords, ts0 << (l + 1))
+            parts.append((floored,) + be.map_insert_launch(floored, dedup=True, n_uniq=cnts[l:l + 1]))
+        counts = cnts.tolist()                                   # the one host read
+        prev_key, prev_first = in_key, None                      # prev_first[j] = first INPUT row of row j of the previous level
+        for l, (floored, tkeys, tvals, row2uniq, uniq_rows, _) in enumerate(parts):
+            nu = counts[l]
+            uniq_rows = uniq_rows[:nu]
+            coords = be.gather_rows(floored, uniq_rows) if nu != floored.shape[0] else floored
+            ts = ts0 << (l + 1)
+            key = self._register(coords, tkeys, tvals, (ts, ts, ts))
+            self._stride_cache[(prev_key, (2, 2, 2))] = key
+            # row of the previous level -> row of this level (what the step-by-step insert would have returned)
+            r2u = row2uniq if prev_first is None else be.gather_rows(row2uniq.reshape(-1, 1).contiguous(), prev_first).reshape(-1)
+            self._origin[key] = (prev_key, r2u)
+            prev_key, prev_first = key, uniq_rows
+            keys.append(key)
+        return keys
+
     def expand(self, in_key: CoordinateMapKey, stride) -> CoordinateMapKey:
         """Generative transposed-conv output map: children c + {0,1}^3 * ts_out (k=2, stride=2)."""
         s = _triple(stride)

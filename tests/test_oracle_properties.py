@@ -164,3 +164,26 @@ def test_project_canonical_kernel_restatement_equals_the_torch_formula(oracle):
         exp = project_canonical(sites, T)
         got = oracle.project_canonical(T, size, RESOLUTION, MIN_BOUND)
         assert torch.equal(got[:, 1:], exp) and bool((got[:, 0] == 0).all())
+
+
+def test_stride_chain_equals_step_by_step_strides(oracle_registered):
+    """Encoder maps built together from the input rows (one host read) == stride(stride(stride(x, 2), 2), 2): same
+    coordinates in the same row order at every level, and the cached keys serve the step-by-step calls."""
+    import pasco_amd.me as ME
+    g = torch.Generator().manual_seed(21)
+    c = torch.cat([torch.zeros(3000, 1, dtype=torch.long), torch.randint(-40, 90, (3000, 3), generator=g)], dim=1).int()
+    a = ME.SparseTensor(torch.zeros(3000, 1), c)
+    b = ME.SparseTensor(torch.zeros(3000, 1), c)
+    ma, mb = a.coordinate_manager, b.coordinate_manager
+    chain = ma.stride_chain(a.coordinate_map_key, 3)
+    k = b.coordinate_map_key
+    for l in range(3):
+        k = mb.stride(k, 2)
+        assert chain[l].tensor_stride == k.tensor_stride
+        assert torch.equal(ma.get_coordinates(chain[l]), mb.get_coordinates(k)), f"level {l}"
+    k1 = ma.stride(a.coordinate_map_key, 2)
+    assert k1 == chain[0] and ma.stride(ma.stride(k1, 2), 2) == chain[2]
+    # kernel maps of the strided convolutions come out the same
+    n1 = ma.kernel_map(chain[0], chain[1], 2)
+    n2 = mb.kernel_map(mb.stride(b.coordinate_map_key, 2), mb.stride(mb.stride(b.coordinate_map_key, 2), 2), 2)
+    assert torch.equal(n1, n2)
