@@ -33,7 +33,7 @@ constexpr int DMA_KMAX = 32;   // kernel offsets one workgroup walks (its slice 
 static int g_dma_ablate = 0;
 static int g_dma_tall = 0;
 int ph_dma_ablate_bits() { return g_dma_ablate; }
-extern "C" void ph_conv_dma_set_ablate(int mask) { g_dma_ablate = 0; g_dma_tall = (mask & 0x100) ? 1 : 0; }
+extern "C" void ph_conv_dma_set_ablate(int mask) { g_dma_ablate = mask & 0xff; g_dma_tall = (mask & 0x100) ? 1 : 0; }
 
 // One workgroup = WAVES (4 or 8) waves as WM x WN, tile BM = WM*TM*32 rows (128 / 256) x BN = WN*TN*32 channels,
 // 32 input channels per stage.  Everything that crosses the vector-memory path (gathered rows AND the weight tile of
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
       const int k = i / BM, r = i - k * BM;
       const int64_t row = m0 + r;
       int idx = -1;
-      if (row < a.n_out) idx = a.tile_k ? a.nbr[row] : (a.nbr ? a.nbr[(int64_t)(k_begin + k) * a.n_out + row] : (int)row);
+      if (row < a.n_out) idx = a.tile_k ? a.nbr[row] : (a.nbr ? a.nbr[(int64_t)(k_begin + k) * a.nbr_stride + row] : (int)row);
       idx_lds[k * BM + (r % RPP) * 4 + (r / RPP)] = idx;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -262,6 +262,42 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
     Frag f0, f1;
     Src src;
     i32x4 ix;
+    // ---- short launches (k = 1 products: linear layers, row-list tiles; nstages = cin / 32 <= 8): the long pipeline below
+    // keeps its loop branch-free by re-loading the last stage up to three more times and draining them before the epilogue -
+    // for a two-stage launch that is 5 stage loads for 2 stages of work.  Here every stage is loaded exactly once: the DMA of
+    // stage s + 2 goes into the buffer stage s was read from, the last waits are vmcnt(0) -----------------------------------
+    if (nstages <= 8 && !(a.ablate & 1)) {
+      auto wait_landed = [&](bool younger_in_flight) {
+        if (younger_in_flight) {
+          if (L == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+          else if (L == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+      };
+      prep(0, load_idx(0), src);
+      fire(src, 0);
+      if (nstages > 1) {
+        prep(1, load_idx(1), src);
+        fire(src, 1);
+      }
+      for (int s = 0; s < nstages; ++s) {
+        const int buf = s & 1;
+        wait_landed(s + 1 < nstages);                  // stage s landed (stage s + 1 may still fly)
+        readfrag(buf, f0);
+        if (s + 2 < nstages) {                         // buffer `buf` is free once every wave holds its fragments
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          prep(s + 2, load_idx(s + 2), src);
+          fire(src, buf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(f0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     prep(0, load_idx(0), src);
     fire(src, 0);
     prep(1, load_idx(1), src);
@@ -310,6 +346,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail loads: nothing may land after the epilogue starts
+    }
 #undef DMA_WAIT_STAGE
 #undef DMA_READS_DONE
   }
@@ -361,6 +398,10 @@ const char *ph_dma_zero_line() {
   return zero[dev];
 }
 
+// scratch the caller offered for splits over the kernel offsets (ph_conv_desc.splitk_ws), carried in the argument block
+static inline void *g_tail_ws(const ConvArgsH &a) { return a.tail_ws; }
+static inline int64_t g_tail_ws_bytes(const ConvArgsH &a) { return a.tail_ws_bytes; }
+
 // Takes the launch when the shape fits the DMA pipeline; returns -1 when the caller should use k_conv_h2.
 // `a` arrives fully prepared (tile-independent fields, ksplit / partial chosen by the caller for 128-row tiles).
 int ph_conv_dma_try(const ConvArgsH &a_in, int bn, hipStream_t st) {
@@ -370,13 +411,48 @@ int ph_conv_dma_try(const ConvArgsH &a_in, int bn, hipStream_t st) {
   if (zero == nullptr) return -1;
   ConvArgsH a = a_in;
   a.zero = zero;
-  a.ablate = g_dma_ablate;
+  a.ablate = g_dma_ablate & 1;      // bit 0 (experiment switch, tools/layer_ab.py): 1 = the long pipeline for short launches too
+  // timing experiments (wrong results by design): 0x10 drops the per-axis table residual, 0x40 the dense residual
+  if (g_dma_ablate & 0x10) a.axis_table = nullptr;
+  if (g_dma_ablate & 0x40) a.residual = nullptr;
   // 256-row tiles (8 waves, one workgroup per CU) when they still cover every CU about twice; else 128-row tiles
   const int64_t ncol = (a.cout + bn - 1) / bn;
   const bool tall = bn >= 64 && ((a.n_out + 255) / 256) * ncol * a.ksplit >= 2 * 256 && g_dma_tall;
   if (bn == 32) return launch_dma<4, 4, 1, 1, 1>(a, st);
   if (bn == 64) return tall ? launch_dma<8, 8, 1, 1, 2>(a, st) : launch_dma<4, 4, 1, 1, 2>(a, st);
-  return tall ? launch_dma<8, 4, 2, 2, 2>(a, st) : launch_dma<4, 2, 2, 2, 2>(a, st);
+  if (tall) return launch_dma<8, 4, 2, 2, 2>(a, st);
+  // ---- tail split (128-wide tiles, two workgroups per CU = 512 resident tiles): every tile of a launch does the same work
+  // (all kvol offsets, whatever the map's sparsity), so a launch of T tiles runs in ceil(T / 512) rounds and a small last
+  // round leaves most of the chip idle for a whole tile time (559 tiles: 2 rounds for 1.09 rounds of work).  When fewer than
+  // half a round of row tiles is left over, they go into a second launch that is split over the kernel offsets so that it
+  // fills the chip with short workgroups; only those rows pay the partial-sum reduction. ----------------------------------
+  static const bool tail_on = [] { const char *e = getenv("PASCO_CONV_TAIL"); return e == nullptr || atoi(e) != 0; }();
+  const int64_t trow = (a.n_out + 127) / 128;
+  const int64_t slots = 512 / ncol;               // row tiles of one full round
+  const int64_t rounds = trow / slots, rest = trow - rounds * slots;
+  if (tail_on && a.ksplit == 1 && a.tile_k == nullptr && a.nbr != nullptr && a.kvol >= 8 && !a.win_gather && rounds >= 1 &&
+      rest > 0 && 2 * rest <= slots && a_in.partial == nullptr && g_tail_ws(a_in) != nullptr) {
+    int ks = (int)(slots / rest);
+    if (ks > a.kvol / 3) ks = a.kvol / 3;
+    if (ks > 16) ks = 16;
+    const int64_t r0 = (trow - rest) * 128, tail_rows = a.n_out - r0;
+    if (ks >= 2 && (int64_t)ks * tail_rows * a.cout * 4 <= g_tail_ws_bytes(a_in)) {
+      ConvArgsH head = a;
+      head.n_out = r0;
+      if (int rc = launch_dma<4, 2, 2, 2, 2>(head, st)) return rc;
+      ConvArgsH tail = a;
+      tail.n_out = tail_rows;
+      tail.nbr = a.nbr + r0;
+      if (tail.out) tail.out = a.out + r0 * a.cout;
+      if (tail.out_split) tail.out_split = a.out_split + r0 * a.cout * 2;
+      if (tail.residual) tail.residual = a.residual + r0 * a.cout;
+      if (tail.axis_coords) tail.axis_coords = a.axis_coords + r0 * 4;
+      tail.ksplit = ks;
+      tail.partial = (float *)g_tail_ws(a_in);
+      return launch_dma<4, 2, 2, 2, 2>(tail, st);     // records its configuration: the launch reads as "ksplit"
+    }
+  }
+  return launch_dma<4, 2, 2, 2, 2>(a, st);
 }
 
 // development hook (tools/occupancy.py): resident workgroups per CU of the main instantiations

@@ -702,6 +702,9 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.ablate = 0;
   a.out_rows = nullptr;
   a.tile_k = nullptr;
+  a.nbr_stride = d->n_out;
+  a.tail_ws = d->splitk_ws;
+  a.tail_ws_bytes = d->splitk_ws_bytes;
   a.win_rows = d->win_rows;
   a.win_cnt = d->win_cnt;
   a.win_slots = d->win_slots;

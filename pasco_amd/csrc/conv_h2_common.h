@@ -55,6 +55,10 @@ struct ConvArgsH {
   // row lists (ph_conv_desc.rl_*): output row of tile row r = out_rows[r] (-1 = padding), kernel offset of row tile t = tile_k[t]
   const int32_t *out_rows, *tile_k;
   int par_vec;                // every per-channel vector (bias, epi*, osp*) is 16-byte aligned: the epilogue loads them as float4
+  void *tail_ws;              // host-side only: the caller's split scratch (ph_conv_desc.splitk_ws) for ph_conv_dma_try's tail split
+  int64_t tail_ws_bytes;
+  int64_t nbr_stride;         // k_conv_dma: rows of one offset's segment of `nbr` (= the map's n_out; a launch over a row range of
+                              // the map has its own, smaller n_out and row-shifted pointers - ph_conv_dma_try's tail split)
 };
 
 // element offsets of the three table rows (x, y, z) of one output row (coordinates clamped to the table)

@@ -476,8 +476,11 @@ class CBackend:
             d.split_exp2 = SPLIT_ACT_EXP2
             d.w_unscale = float(unscale) * 2.0 ** (-SPLIT_ACT_EXP2)
             d.status = _ptr(self.status_word(dev))
-            if n_out * cout <= (1 << 23):          # few-row layer: offer scratch for a split over the offsets
-                need = 8 * n_out * cout * 4
+            if kvol > 1 or n_out * cout <= (1 << 23):
+                # scratch for a split over the kernel offsets: few-row layers split whole (8 partial copies), big maps only
+                # their last partial round of row tiles (ph_conv_dma_try's tail split: slices x tail tiles <= the 512 resident
+                # 128 x 128 tiles of one round = 32 MiB of fp32 partial sums whatever the width)
+                need = 8 * n_out * cout * 4 if n_out * cout <= (1 << 23) else 512 * 128 * 128 * 4
                 key = ("splitk",) + self._stream_key(dev)
                 sk = self._ws.get(key)
                 if sk is None or sk.numel() < need:
