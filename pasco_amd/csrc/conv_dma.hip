@@ -203,23 +203,17 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
       }
     };
     auto mfma = [&](const Frag &f) {
-      // weights first: transposed accumulator block (lane = output row); per accumulator the smallest terms first, the
-      // three products of one accumulator TM * TN issues apart (no MFMA waits on its predecessor)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[ks][j], f.al[ks][i], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[ks][j], f.ah[ks][i], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[ks][j], f.ah[ks][i], acc[i][j], 0, 0, 0);
-      }
+          for (int j = 0; j < TN; ++j) {
+            // weights first: transposed accumulator block (lane = output row); smallest terms first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[ks][j], f.al[ks][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[ks][j], f.ah[ks][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[ks][j], f.ah[ks][i], acc[i][j], 0, 0, 0);
+          }
     };
     // INTER: the DMA instructions of a stage issued BETWEEN its matrix instructions (one DMA, then its share of the MFMAs)
     // instead of all in front of them
@@ -241,7 +235,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = t * NM / ND; m < (t + 1) * NM / ND; ++m) {
-          const int ij = m % (TM * TN), p = (m / (TM * TN)) % 3, ks = m / (3 * TM * TN);   // dependent products TM * TN issues apart
+          const int p = m % 3, ij = (m / 3) % (TM * TN), ks = m / (3 * TM * TN);
           const int i = ij / TN, j = ij % TN;
           if (p == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[ks][j], f.al[ks][i], acc[i][j], 0, 0, 0);
           else if (p == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[ks][j], f.ah[ks][i], acc[i][j], 0, 0, 0);
