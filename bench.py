@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (matrix) = vector rate
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA peak
 HBM_PEAK_GBS = 8000.0
-SPLIT_KERNELS = ("k_conv_dma", "k_conv_h2", "k_conv_f16x3", "k_conv_rl", "k_conv_win")   # 3 f16 MFMAs per product
+SPLIT_KERNELS = ("k_conv_dma", "k_conv_h2", "k_conv_f16x3", "k_conv_rl", "k_conv_win", "k_conv_wide")   # 3 f16 MFMAs per product
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -243,6 +243,11 @@ def cpu_baseline(n_infers, in_channels, timed=3):
     from pasco_amd.me import backend
     from pasco_amd.me.backend import CBackend
     from pasco_amd.graph.synth import make_scene, TeacherKeep
+    if hasattr(os, "sched_setaffinity"):           # the GPU loop was pinned to its GPU's socket: the CPU baseline gets the whole host
+        try:
+            os.sched_setaffinity(0, range(os.cpu_count() or 1))
+        except OSError:
+            pass
     cores = physical_cores()
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)     # the oracle's OpenMP runtime starts with its first call, below
@@ -339,7 +344,11 @@ def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False, 
         if unfused:
             fused.set_fusion(True)
             fused.set_conv_precision("f16x3")
-    return {"scenes_per_s": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": 1}
+    row = {"scenes_per_s": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": 1}
+    redone = {k: int(getattr(net, k, 0)) for k in ("range_fallbacks", "input_fallbacks", "optimistic_fallbacks") if getattr(net, k, 0)}
+    if redone:          # steps that ran twice (a fallback of PascoNet.forward): the row is then not a clean measurement
+        row["redone_steps"] = redone
+    return row
 
 
 def main():

@@ -601,11 +601,13 @@ struct ConvHKnobs {
   bool win256 = false;     // PASCO_CONV_WIN256=1: 256-wide window workgroups for 256-channel layers (measured: 568 vs 547 us
                            // for the gather kernel once its DMA is issued between the MFMAs)
   bool dma_on = true;      // PASCO_CONV_DMA=0: keep every launch on the register-staged k_conv_h2 (A/B comparisons)
+  bool wide_on = true;     // PASCO_CONV_WIDE=0: no 256 x 256 tiles (conv_wide.hip) for the 256-output-channel gather launches
   ConvHKnobs() {
     if (const char *e = getenv("PASCO_CONV_DMA")) {
       dma_on = atoi(e) != 0;
       dma_all = atoi(e) == 2;      // 2: every tile width on the DMA kernel
     }
+    if (const char *e = getenv("PASCO_CONV_WIDE")) wide_on = atoi(e) != 0;
     if (const char *e = getenv("PASCO_CONVH_MID")) mid_on = atoi(e) != 0;
     if (const char *e = getenv("PASCO_CONV_WIN")) {
       win_on = atoi(e) != 0;
@@ -797,6 +799,10 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   // default for pre-split operands: the LDS-DMA pipelined kernel (conv_dma.hip; 128-row tiles, parallelism of few-row
     // layers from the split over the offsets chosen above); it declines slices of more than 32 offsets
     // measured (profiles/README.md, round 2): 6-9 % faster than k_conv_h2 on 128-channel-wide tiles, a few % slower on 64-wide
+    if (pre && knobs.wide_on && !env && bn == 128 && d->cout == 256 && d->kvol >= 8 && d->nbr != nullptr) {
+      const int rc = ph_conv_wide_try(a, st);
+      if (rc >= 0) return rc;
+    }
     if (pre && knobs.dma_on && !env && (bn == 128 || knobs.dma_all)) {
       ConvArgsH b = a;
       if (bm != 128) {        // the choice above was made for a shorter tile: redo the split decision for 128 rows

@@ -122,6 +122,8 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st);
 int ph_launch_splitk_epilogue(const ConvArgsH &args, hipStream_t st);
 // conv_dma.hip: the LDS-DMA pipelined kernel; -1 = shape not served (caller falls back to k_conv_h2)
 int ph_conv_dma_try(const ConvArgsH &a, int bn, hipStream_t st);
+// conv_wide.hip: 256 x 256 tiles, 8 waves, one workgroup per CU (256 output channels); -1 = shape not served
+int ph_conv_wide_try(const ConvArgsH &a, hipStream_t st);
 
 // hi / lo halves of four values -> the [hi x32 | lo x32] group layout (dst points at the run's hi slot)
 __device__ __forceinline__ bool emit_split4(const float v[4], const float *sc, const float *sh, int has, float neg,

@@ -224,6 +224,9 @@ class DecoderGenerativeSepConvV2(nn.Module):
             h = fused.conv(xi, vf[0], epi_bn=vf[1], epi_act=ACT_RELU)
             xs_infers[scale].append(fused.conv(h, vf[3]))
         batched = {s: batch_sparse_tensor(v, pad_to[s]) for s, v in xs_infers.items()}
+        # rows of every subnet at every scale, for the transformer's host-side "is there a padded row" decisions
+        batched["_meta"] = {"lens": {"fine": [int(t.F.shape[0]) for t in xs_infers[1]],
+                                     "level": {s: [int(t.F.shape[0]) for t in v] for s, v in xs_infers.items()}}}
         sem_F, sem_C = batch_sparse_tensor(sem_logits_pruneds, pad_to[1])
         keep_pad = ((sem_F != 0).sum(-1) + (sem_C != 0).sum(-1)) != 0
         panop = self.transformer_predictor(batched, (sem_F, sem_C), min_Cs, max_Cs, keep_pad, subnets=subnets,

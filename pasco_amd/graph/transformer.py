@@ -455,33 +455,37 @@ class TransformerPredictorV2(nn.Module):
         # dense -> index whenever no coordinate lies outside the subnet's [min, max] box (then the reference's dense
         # indexing wraps negative indices: the path below reproduces that); the test is made on the device and read once.
         if be.has("bits_block_or") and os.environ.get("PASCO_MASK_BLOCK", "1") != "0":
-            if cache is not None and "bounds" in cache:
-                mn32, mx32, fine_bad = cache["bounds"]
-            else:
-                mn32 = torch.stack([torch.as_tensor(m) for m in min_Cs]).to(dev).to(torch.int32).contiguous()    # [B, 3]
-                mx32 = torch.stack([torch.as_tensor(m) for m in max_Cs]).to(dev).to(torch.int32).contiguous()
-                vc = voxel_coord.reshape(B, P, 4)[..., 1:].to(torch.int32)
-                fine_bad = ((vc < mn32[:, None]) | (vc > mx32[:, None])).any()
-                if cache is not None:
-                    cache["bounds"] = (mn32, mx32, fine_bad)
             fine = mgr._maps[key1]
-            opt = fused_mod.optimistic_word(dev)
-            if opt is not None:
-                # no host read: the kernel ORs its range flag into the stream's optimistic word and `fine_bad` is folded into
-                # it once per forward; the end-of-step check redoes the step on the exact path below should either be set
-                if cache is None or not cache.get("fine_bad_folded"):
-                    opt.bitwise_or_(fine_bad.to(torch.int32))
+            # Host-side decision where the host knows the boxes (UNet3DV2.forward read them once): every REAL voxel of the
+            # fine map and of the level lies inside its subnet's box (the panoptic branch prunes with exactly that test,
+            # decoder_v3.py:151-158,415-420), so only PADDED rows - coordinate (0, 0, 0) - can lie outside, and they do iff
+            # the subnet has padding and 0 is outside [min, max] on some axis.  No device read, no speculation.
+            hmin, hmax = getattr(min_Cs, "host", None), getattr(max_Cs, "host", None)
+            lens = cache.get("lens") if cache is not None else None
+            if hmin is not None and hmax is not None and lens is not None and len(hmin) == B:
+                pad_out = any(lens["fine"][b] < P or lens["level"][src_scale][b] < N for b in range(B)
+                              if any(lo > 0 for lo in hmin[b]) or any(hi < 0 for hi in hmax[b]))
+                if not pad_out:
+                    out = be.bits_block_or(src_C.reshape(B * N, 4).to(torch.int32).contiguous(), N, src_scale, fine.tkeys,
+                                           fine.tvals, bits1.contiguous())
+                    bits = out.reshape(B, N, 4)
+                    return bits, be.bits_or_reduce(bits)
+                # a padded row outside its box: the exact dense-index path below (python-style wrap of negative indices)
+            else:       # boxes only on the device: test there, one read
+                if cache is not None and "bounds" in cache:
+                    mn32, mx32, fine_bad = cache["bounds"]
+                else:
+                    mn32 = torch.stack([torch.as_tensor(m) for m in min_Cs]).to(dev).to(torch.int32).contiguous()    # [B, 3]
+                    mx32 = torch.stack([torch.as_tensor(m) for m in max_Cs]).to(dev).to(torch.int32).contiguous()
+                    vc = voxel_coord.reshape(B, P, 4)[..., 1:].to(torch.int32)
+                    fine_bad = ((vc < mn32[:, None]) | (vc > mx32[:, None])).any()
                     if cache is not None:
-                        cache["fine_bad_folded"] = True
-                out = be.bits_block_or(src_C.reshape(B * N, 4).to(torch.int32).contiguous(), N, src_scale, fine.tkeys,
-                                       fine.tvals, bits1.contiguous(), mn32, mx32, range_word=opt)
-                bits = out.reshape(B, N, 4)
-                return bits, be.bits_or_reduce(bits)
-            out, rng = be.bits_block_or(src_C.reshape(B * N, 4).to(torch.int32).contiguous(), N, src_scale, fine.tkeys,
-                                        fine.tvals, bits1.contiguous(), mn32, mx32, want_range=True)
-            if not bool(((rng != 0) | fine_bad).item()):
-                bits = out.reshape(B, N, 4)
-                return bits, be.bits_or_reduce(bits)
+                        cache["bounds"] = (mn32, mx32, fine_bad)
+                out, rng = be.bits_block_or(src_C.reshape(B * N, 4).to(torch.int32).contiguous(), N, src_scale, fine.tkeys,
+                                            fine.tvals, bits1.contiguous(), mn32, mx32, want_range=True)
+                if not bool(((rng != 0) | fine_bad).item()):
+                    bits = out.reshape(B, N, 4)
+                    return bits, be.bits_or_reduce(bits)
         if src_scale != 1:
             pool = self.max_pools[str(src_scale)]
             keyp = mgr.stride(key1, pool.stride)
@@ -582,6 +586,8 @@ class TransformerPredictorV2(nn.Module):
         vf_shape = (B, P, D)
         predictions_class, predictions_mask = [], []
         mask_cache = {}
+        if "lens" in xs.get("_meta", {}):       # rows of every subnet at every scale (host ints from the caller)
+            mask_cache["lens"] = xs["_meta"]["lens"]
         head_mode = 2 if absorbed is not None else (vf_split is not None)
         output, *qs = self.query_step(-1, output.contiguous(), query_embed, head_mode)
         oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape, query_side=qs, absorbed=absorbed)

@@ -140,6 +140,28 @@ def merge_subnet_inputs(in_feat: ME.SparseTensor, n_infers: int) -> ME.SparseTen
     return ME.SparseTensor(out.contiguous(), coords)
 
 
+class BoundsList(list):
+    """The per-subnet box corners (device tensors, as the batch dict holds them) plus `.host`: the same numbers as Python ints,
+    read once per forward."""
+    host = None
+
+
+def host_bounds(in_feat, global_min_coords, global_max_coords, min_Cs, max_Cs):
+    """-> (min_Cs, max_Cs as BoundsList with .host = [[x, y, z], ...], {"gmin", "gmax", "in_max"}) from ONE device read."""
+    dev = in_feat.device
+    parts = [torch.as_tensor(global_min_coords).reshape(-1), torch.as_tensor(global_max_coords).reshape(-1)]
+    parts += [torch.as_tensor(t).reshape(-1) for t in min_Cs] + [torch.as_tensor(t).reshape(-1) for t in max_Cs]
+    parts = [t.to(device=dev, dtype=torch.int64) for t in parts]
+    c = in_feat.C
+    parts.append(c[:, 1:].max(dim=0)[0].to(torch.int64) if c.shape[0] else torch.zeros(3, dtype=torch.int64, device=dev))
+    hv = torch.cat(parts).tolist()
+    m = len(min_Cs)
+    mn, mx = BoundsList(min_Cs), BoundsList(max_Cs)
+    mn.host = [hv[6 + 3 * i: 9 + 3 * i] for i in range(m)]
+    mx.host = [hv[6 + 3 * m + 3 * i: 9 + 3 * m + 3 * i] for i in range(m)]
+    return mn, mx, {"gmin": hv[0:3], "gmax": hv[3:6], "in_max": hv[6 + 6 * m: 9 + 6 * m]}
+
+
 class UNet3DV2(nn.Module):
     def __init__(self, in_channels, n_classes, transformer_predictor, n_infers, f_maps, heavy_decoder=True,
                  dense3d_dropout=0.0, decoder_dropouts=(0.0, 0.0, 0.0), encoder_dropouts=(0.0, 0.0, 0.0)):
@@ -154,17 +176,21 @@ class UNet3DV2(nn.Module):
         self.encoder = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(self.encoder)
         self.decoder_generative = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(self.decoder_generative)
 
-    def dense_bottleneck(self, deepest: ME.SparseTensor, bs, global_min_coords, global_max_coords):
+    def dense_bottleneck(self, deepest: ME.SparseTensor, bs, global_min_coords, global_max_coords, host=None):
         """stride-8 features -> dense grid -> SPCDense3Dv2 -> back to a sparse tensor that shares the
         encoder's coordinate manager (unet3d_sparse_v2.py:182-214)."""
         scale = deepest.tensor_stride[0]
         dev = deepest.device
         gmin = global_min_coords.to(dev)
-        max_c = deepest.C[:, 1:].max(dim=0)[0].to(torch.int64)
-        # ONE host read for everything the host needs here (bounds + the largest stride-8 coordinate)
-        hv = torch.cat([gmin.reshape(-1).to(torch.int64), global_max_coords.to(dev).reshape(-1).to(torch.int64), max_c]).tolist()
-        gmin_h = hv[0:3]
-        gmax_h = [max(a, b) for a, b in zip(hv[3:6], hv[6:9])]
+        if host is not None:     # read at the top of the forward; the largest stride-`scale` coordinate = floor of the input's
+            gmin_h = host["gmin"]
+            gmax_h = [max(a, (b // scale) * scale) for a, b in zip(host["gmax"], host["in_max"])]
+        else:
+            max_c = deepest.C[:, 1:].max(dim=0)[0].to(torch.int64)
+            # ONE host read for everything the host needs here (bounds + the largest stride-8 coordinate)
+            hv = torch.cat([gmin.reshape(-1).to(torch.int64), global_max_coords.to(dev).reshape(-1).to(torch.int64), max_c]).tolist()
+            gmin_h = hv[0:3]
+            gmax_h = [max(a, b) for a, b in zip(hv[3:6], hv[6:9])]
         size = [-(-(mx - mn + 1) // scale) for mn, mx in zip(gmin_h, gmax_h)]      # compute_scene_size(...) // scale
         # channels-last rows of the dense grid (sites in lexicographic order = ME.to_sparse order);
         # the reference goes sparse -> dense [1,C,X,Y,Z] -> Conv3d stack -> ME.to_sparse, this is the
@@ -200,8 +226,12 @@ class UNet3DV2(nn.Module):
     def forward(self, in_feat, bs, global_min_coords, global_max_coords, min_Cs, max_Cs,
                 is_predict_panop=True, keep_override=None, subnets=None):
         assert not self.training, "inference only"
+        # ONE host read for every small quantity the host decides with (scene bounds, subnet boxes, the largest input
+        # coordinate): the bottleneck's grid extent and the attention mask's "padded row outside its subnet's box" test
+        # need no device read of their own later
+        min_Cs, max_Cs, hb = host_bounds(in_feat, global_min_coords, global_max_coords, min_Cs, max_Cs)
         feats = self.encoder(in_feat)
-        deepest = self.dense_bottleneck(feats[-1], bs, global_min_coords, global_max_coords)
+        deepest = self.dense_bottleneck(feats[-1], bs, global_min_coords, global_max_coords, host=hb)
         return self.decoder_generative(deepest, feats[:-1], global_min_coords, global_max_coords, min_Cs, max_Cs,
                                        is_predict_panop=is_predict_panop, keep_override=keep_override,
                                        subnets=subnets)

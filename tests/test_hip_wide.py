@@ -1,0 +1,83 @@
+"""k_conv_wide (conv_wide.hip: 256 x 256 tiles, 8 waves, one workgroup per CU) on 256-output-channel maps: against the oracle,
+bit for bit against k_conv_dma where no split over the offsets is involved (same per-accumulator product order), operand
+emission, split over the offsets on few-row maps, ragged row counts.  Reference layers: the stride-4 residual blocks and
+per-subnet voxel features (mink.py:625-638, decoder_v3.py:267-282)."""
+import ctypes
+
+import pytest
+import torch
+
+from pasco_amd.me.core import kernel_offsets
+
+pytestmark = pytest.mark.gpu
+
+
+def scene(n, extent, seed):
+    g = torch.Generator().manual_seed(seed)
+    sites = torch.randperm(extent[0] * extent[1] * extent[2], generator=g)[:n]
+    xyz = torch.stack([sites // (extent[1] * extent[2]), (sites // extent[2]) % extent[1], sites % extent[2]], dim=1)
+    return torch.cat([torch.zeros(n, 1, dtype=torch.long), xyz], dim=1).int()
+
+
+@pytest.fixture()
+def wide_hook(hip):
+    fn = hip.lib.ph_conv_wide_all
+    fn.argtypes = [ctypes.c_int]
+    yield fn
+    fn(0)
+
+
+@pytest.mark.parametrize("n,extent,cin,kind", [(13001, (40, 40, 16), 256, "k3"), (3000, (24, 24, 10), 256, "k3"),
+                                               (700, (12, 12, 8), 128, "k3"), (20000, (48, 48, 16), 64, "k2")])
+def test_wide_matches_oracle_and_the_gather_kernel(hip, oracle, wide_hook, n, extent, cin, kind):
+    coords = scene(n, extent, n)
+    g = torch.Generator().manual_seed(n + 1)
+    x = torch.randn(n, cin, generator=g)
+    if kind == "k3":
+        offs = kernel_offsets(3, 1)
+        out_coords = coords
+    else:                      # strided k = 2: coarse output map
+        offs = kernel_offsets(2, 1)
+        out_coords = torch.unique(torch.cat([coords[:, :1], coords[:, 1:] // 2 * 2], dim=1), dim=0).int()
+    w = torch.randn(len(offs), cin, 256, generator=g) / (len(offs) * cin) ** 0.5
+    bias, res = torch.randn(256, generator=g), torch.randn(out_coords.shape[0], 256, generator=g)
+    es, eb = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    tk, tv, _, _, _ = oracle.map_insert(coords.contiguous(), dedup=False)
+    nbr = oracle.nbr_build(out_coords.contiguous(), tk, tv, offs)
+    m = out_coords.shape[0]
+    exp = oracle.conv_fwd(x, w, nbr, m, bias=bias, epi_scale=es, epi_shift=eb, epi_act=1, residual=res, res_act=1)
+    xc, wc, nb = x.cuda(), w.cuda(), nbr.cuda()
+    split, xs = hip.split_weight_rows(wc), hip.split_rows(xc)
+    kw = dict(bias=bias.cuda(), epi_scale=es.cuda(), epi_shift=eb.cuda(), epi_act=1, residual=res.cuda(), res_act=1)
+    wide_hook(1)
+    got = hip.conv_fwd(xc, wc, nb, m, split=split, in_split=xs, **kw)
+    cfg = hip.conv_last_config()
+    assert cfg["kernel"] == 6 and cfg["bm"] == 256 and cfg["bn"] == 256, cfg
+    err = float((got.cpu() - exp).abs().max()) / float(exp.abs().mean())
+    assert err < 1e-4, err
+    # operand emission: the second output equals ph_split_rows of the first
+    osc, osh = (torch.rand(256, generator=g) + 0.5).cuda(), (torch.randn(256, generator=g) * 0.1).cuda()
+    out2, osp = hip.conv_fwd(xc, wc, nb, m, split=split, in_split=xs, emit_split=(osc, osh, 1), **kw)
+    assert torch.equal(osp.view(torch.int16), hip.split_rows(out2, pro_scale=osc, pro_shift=osh, pro_act=1).view(torch.int16))
+    assert torch.equal(out2, got)
+    wide_hook(-1)
+    ref = hip.conv_fwd(xc, wc, nb, m, split=split, in_split=xs, **kw)
+    cfg2 = hip.conv_last_config()
+    assert cfg2["kernel"] != 6
+    if cfg["ksplit"] == 1 and cfg2["ksplit"] == 1:
+        assert torch.equal(got, ref), "same products in the same per-accumulator order: bit-identical to the gather kernel"
+    else:
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-5)
+
+
+def test_wide_default_dispatch_by_size(hip, wide_hook):
+    """Default routing: 256 x 256 tiles from 48 row tiles (12 288 rows) up, k_conv_dma below (measured crossover)."""
+    wide_hook(0)
+    for n, want in ((12500, 6), (9000, 4)):
+        coords = scene(n, (40, 40, 16), n).cuda()
+        tk, tv, _, _, _ = hip.map_insert(coords.contiguous(), dedup=False)
+        nbr = hip.nbr_build(coords, tk, tv, kernel_offsets(3, 1))
+        x = torch.randn(n, 256, device="cuda")
+        w = torch.randn(27, 256, 256, device="cuda") / 80
+        hip.conv_fwd(x, w, nbr, n, split=hip.split_weight_rows(w), in_split=hip.split_rows(x))
+        assert hip.conv_last_config()["kernel"] == want

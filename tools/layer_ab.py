@@ -54,7 +54,7 @@ with torch.no_grad():
     be.conv_fwd = inner
 lib = be.lib
 lib.ph_conv_dma_set_ablate.argtypes = [C.c_int]
-KN = {0: "mfma", 1: "f16x3", 2: "h2", 3: "rl", 4: "dma", 5: "win|dma"}
+KN = {0: "mfma", 1: "f16x3", 2: "h2", 3: "rl", 4: "dma", 5: "win|dma", 6: "wide"}
 
 
 def timed(rec, mask):
