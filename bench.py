@@ -235,6 +235,19 @@ def physical_cores():
 
 
 def cpu_baseline(n_infers, in_channels, timed=3):
+    """The CPU baseline in a FRESH process with the whole host's CPUs: this process (and every thread pool it has started) is
+    pinned to its GPU's socket, which would halve the baseline's cores."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--n-infers", str(n_infers), "--in-channels",
+           str(in_channels), "--cpu-baseline-scenes", str(timed)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMP_NUM_THREADS")}
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1800)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if out.returncode != 0 or not lines:
+        raise RuntimeError(f"cpu baseline process failed ({out.returncode}): {out.stderr[-400:]}")
+    return json.loads(lines[-1])
+
+
+def cpu_baseline_here(n_infers, in_channels, timed=3):
     """Same graph, oracle backend (C + OpenMP) + torch CPU for the dense parts, host cores only: ONE warm-up scene on the
     same 256x256x32 grid (thread pools, page faults, weight operand caches), then `timed` full S10 scenes (seeds 0, 1, 2),
     median reported (warm-up + timed scenes, median; 3 instead of 5 scenes keeps the default run within
@@ -371,6 +384,8 @@ def main():
     ap.add_argument("--no-exact", action="store_true", help="skip the extra exact-fp32-MFMA timing")
     ap.add_argument("--no-configs", action="store_true", help="skip the short rows of the other configurations")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-scenes", type=int, default=3, help=argparse.SUPPRESS)
     ap.add_argument("--conv-precision", choices=["f32", "f16x3"], default="f16x3",
                     help="f16x3 (default) = conv products as 3 x f16 split MFMA with fp32 accumulation (error vs fp64 <= "
                          "the fp32-MFMA path); f32 = every product on the exact fp32 MFMA")
@@ -378,6 +393,9 @@ def main():
     if args.n_infers is None:
         args.n_infers = 8 if args.mode == "subnet-heads" else 3
 
+    if args.cpu_baseline_only:           # child of `cpu_baseline`: nothing but the oracle + torch-CPU graph, all host CPUs
+        print(json.dumps(cpu_baseline_here(args.n_infers, args.in_channels, args.cpu_baseline_scenes)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 

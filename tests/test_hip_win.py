@@ -102,7 +102,7 @@ def test_window_conv_equals_gather_conv(hip, cin, cout):
     finally:
         _force(hip, 0)
     cfg = hip.conv_last_config()
-    assert cfg_ref["kernel"] in (2, 4) and cfg["kernel"] == 5
+    assert cfg_ref["kernel"] in (2, 4, 6) and cfg["kernel"] == 5      # 6: k_conv_wide serves the 256-channel map at this size
     # same products, different fp32 summation order (chunk-major vs offset-major): rounding-level agreement, measured
     # against the largest magnitude the sums reach
     big = float(ref.abs().max())
