@@ -799,7 +799,7 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   // default for pre-split operands: the LDS-DMA pipelined kernel (conv_dma.hip; 128-row tiles, parallelism of few-row
     // layers from the split over the offsets chosen above); it declines slices of more than 32 offsets
     // measured (profiles/README.md, round 2): 6-9 % faster than k_conv_h2 on 128-channel-wide tiles, a few % slower on 64-wide
-    if (pre && knobs.wide_on && !env && bn == 128 && d->cout == 256 && d->kvol >= 8 && d->nbr != nullptr) {
+    if (pre && knobs.wide_on && !env && bn == 128 && (d->cout == 256 || d->cout == 128) && d->kvol >= 8 && d->nbr != nullptr) {
       const int rc = ph_conv_wide_try(a, st);
       if (rc >= 0) return rc;
     }

@@ -25,19 +25,21 @@
 
 constexpr int WIDE_KMAX = 27;     // kernel offsets one workgroup walks (index table in LDS); more -> split over the offsets
 
-template <bool EMIT>
+// TN = 4: 256 x 256 tiles (256 output channels); TN = 2: 256 x 128 tiles (128 output channels: the address unit is busy 62 %
+// of the matrix time instead of 42 % - still the better side of k_conv_dma's 83 % where the map fills the chip in whole rounds)
+template <int TN, bool EMIT>
 __global__ void __launch_bounds__(512, 2) k_conv_wide(ConvArgsH a) {
-  constexpr int WM = 4, WN = 2, TM = 2, TN = 4;
+  constexpr int WM = 4, WN = 2, TM = 2;
   constexpr int NT = 512;
   constexpr int BM = WM * TM * 32;           // 256
-  constexpr int BN = WN * TN * 32;           // 256
+  constexpr int BN = WN * TN * 32;           // 256 or 128
   constexpr int RPP = NT / 8;                // tile rows one DMA pass covers: 8 waves x 8 rows x 128 B
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
-  constexpr int L = A_PASSES + B_PASSES;     // DMA instructions per thread and stage (8)
-  constexpr int NMH = TM * TN * 3;           // MFMAs per wave and half stage (24)
-  constexpr int NRH = (TM + TN) * 2;         // fragment reads per wave and half stage (12)
-  static_assert(A_PASSES == 4 && L == 8, "one 16-byte index read per thread and stage");
+  constexpr int L = A_PASSES + B_PASSES;     // DMA instructions per thread and stage (8 / 6)
+  constexpr int NMH = TM * TN * 3;           // MFMAs per wave and half stage (24 / 12)
+  constexpr int NRH = (TM + TN) * 2;         // fragment reads per wave and half stage (12 / 8)
+  static_assert(A_PASSES == 4 && (L == 8 || L == 6), "one 16-byte index read per thread and stage");
   __shared__ __attribute__((aligned(128))) char lds[2 * STAGE + WIDE_KMAX * BM * 4];
 
   const int nwg = gridDim.x;
@@ -211,7 +213,8 @@ __global__ void __launch_bounds__(512, 2) k_conv_wide(ConvArgsH a) {
     prep(1, src);
     fire_all(src, b1);
     prep(2, src);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stage 0 landed (stage 1 may fly)
+    if (L == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stage 0 landed (stage 1 may fly)
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int r = 0; r < NRH; ++r) read_one(b0, 0, r);
@@ -244,39 +247,52 @@ __global__ void __launch_bounds__(512, 2) k_conv_wide(ConvArgsH a) {
 static int g_wide_all = 0;      // test / experiment hook (tests/test_hip_wide.py): 1 = every served shape whatever its size, -1 = none
 extern "C" void ph_conv_wide_all(int mode) { g_wide_all = mode; }
 
+template <int TN>
 static int launch_wide(const ConvArgsH &a, hipStream_t st) {
+  constexpr int BN = 2 * TN * 32;
   ConvArgsH args = a;
   args.n_row_tiles = (int)((a.n_out + 255) / 256);
-  args.n_col_tiles = (a.cout + 255) / 256;
+  args.n_col_tiles = (a.cout + BN - 1) / BN;
   const int ntiles = args.n_row_tiles * args.n_col_tiles;
   const int grid = ((ntiles + 7) / 8) * 8;
   const bool emit = args.out_split != nullptr && args.ksplit == 1;
-  if (emit) hipLaunchKernelGGL((k_conv_wide<true>), dim3(grid, 1), dim3(512), 0, st, args);
-  else hipLaunchKernelGGL((k_conv_wide<false>), dim3(grid, args.ksplit), dim3(512), 0, st, args);
+  if (emit) hipLaunchKernelGGL((k_conv_wide<TN, true>), dim3(grid, 1), dim3(512), 0, st, args);
+  else hipLaunchKernelGGL((k_conv_wide<TN, false>), dim3(grid, args.ksplit), dim3(512), 0, st, args);
   PH_LAUNCH_CHECK();
   if (args.ksplit > 1) {
     if (int rc = ph_launch_splitk_epilogue(args, st)) return rc;
   }
-  ph_record_cfg(2, 256, 256, 32, args.ksplit, emit ? 1 : 0, 6, 8);
+  ph_record_cfg(2, 256, BN, 32, args.ksplit, emit ? 1 : 0, 6, 8);
   return 0;
 }
 
-// Takes gather launches with 256 output channels and >= 8 kernel offsets; -1 = not served (the caller goes on to k_conv_dma).
-// One workgroup per CU: maps with at least ~160 row tiles run unsplit (one round); fewer row tiles are split over the kernel
-// offsets so that the launch has about one workgroup per CU, each slice at most WIDE_KMAX offsets.
+// Takes gather launches with 256 or 128 output channels and >= 8 kernel offsets; -1 = not served (the caller goes on to
+// k_conv_dma).  One workgroup per CU.  256 channels: maps with at least ~160 row tiles run unsplit (one round); fewer row
+// tiles are split over the kernel offsets so that the launch has about one workgroup per CU, each slice at most WIDE_KMAX
+// offsets.  128 channels: only where the row tiles fill the CUs in (nearly) whole rounds - k_conv_dma's two workgroups per
+// CU and its tail split serve the other sizes better.
 int ph_conv_wide_try(const ConvArgsH &a_in, hipStream_t st) {
-  if (a_in.cout != 256 || a_in.kvol < 8 || a_in.tile_k != nullptr || a_in.win_gather || (a_in.cpad & 31) || a_in.nbr == nullptr)
+  if ((a_in.cout != 256 && a_in.cout != 128) || a_in.kvol < 8 || a_in.tile_k != nullptr || a_in.win_gather || (a_in.cpad & 31) ||
+      a_in.nbr == nullptr)
     return -1;
+  const int64_t trow = (a_in.n_out + 255) / 256;
   // measured (profiles/r3n_layer_ab_wide.txt): 477 vs 520 us at 53 k rows, 162 vs 188 us at 15.6 k rows; below ~12 k rows
   // (fewer than 48 row tiles: a deep split over the offsets) and on the bottleneck's 245 / 75-offset products k_conv_dma's
   // smaller tiles win
-  if (g_wide_all < 0 || (g_wide_all == 0 && ((a_in.n_out + 255) / 256 < 48 || a_in.kvol > WIDE_KMAX))) return -1;
+  if (g_wide_all < 0) return -1;
+  if (g_wide_all == 0) {
+    if (a_in.kvol > WIDE_KMAX) return -1;
+    if (a_in.cout == 256 && trow < 48) return -1;
+    if (a_in.cout == 128) {      // whole rounds only: the last round at least ~60 % full, no split over the offsets
+      const int64_t rest = trow % 256;
+      if (trow < 150 || (rest != 0 && rest < 150)) return -1;
+    }
+  }
   const char *zero = ph_dma_zero_line();
   if (zero == nullptr) return -1;
   ConvArgsH a = a_in;
   a.zero = zero;
   a.ablate = 0;
-  const int64_t trow = (a.n_out + 255) / 256;
   int ks = (a.kvol + WIDE_KMAX - 1) / WIDE_KMAX;                     // what the index table demands
   if (trow * ks < 160) {                                             // well under one workgroup per CU: split further
     int want = (int)((256 + trow / 2) / trow);
@@ -291,5 +307,5 @@ int ph_conv_wide_try(const ConvArgsH &a_in, hipStream_t st) {
     a.ksplit = ks;
     a.partial = (float *)a.tail_ws;
   }
-  return launch_wide(a, st);
+  return a.cout == 256 ? launch_wide<4>(a, st) : launch_wide<2>(a, st);
 }

@@ -308,6 +308,9 @@ class CBackend:
         self._chk(nbr, torch.int32, "nbr")
         kvol, n_out = nbr.shape
         pin, pout, counts = self.kmap_compact(nbr)
+        # the caller's promise "exactly one pair per output row": a map that breaks it would leave output rows unwritten.
+        # Checked on the device (pairs != rows -> status bit 5, reported by the end-of-step check); no host read here.
+        self.status_word(nbr.device).bitwise_or_((counts.sum() != n_out).to(torch.int32) * 32)
         cap = (n_out + kvol * 127 + 127) // 128 * 128
         tcap = cap // 128
         dev = nbr.device
@@ -542,6 +545,8 @@ class CBackend:
            "pasco_amd.graph.fused.set_conv_precision('f32'); PascoNet.forward does so by itself)",
         2: "a coordinate outside the packable range (batch index 0..1023, coordinates -131072..131071) was inserted into a "
            "coordinate map; it would alias another voxel",
+        32: "a kernel map handed over as one-pair-per-output-row (fused.conv(..., one_pair=True): row lists of a generative "
+            "transposed convolution) has another number of pairs than rows: output rows would stay unwritten (PASCO_CONV_RL=0)",
         16: "an optimistic shortcut of the graph did not hold (a fast path taken without the host read that would justify it: "
             "attention-mask block lookups with a coordinate outside its subnet's box, kept rows that are not the leading rows, "
             "an all-zero bottleneck site); PASCO_OPTIMISTIC=0 takes the checked paths; PascoNet.forward redoes the step by itself",
@@ -567,9 +572,9 @@ class CBackend:
             v |= 16
         if v == 0:
             return
-        msgs = [self.STATUS_TEXT[b] for b in (1, 2, 4, 8, 16) if v & b]
-        if v & ~31:
-            msgs.append(f"unknown status bits {v & ~31:#x}")
+        msgs = [self.STATUS_TEXT[b] for b in (1, 2, 4, 8, 16, 32) if v & b]
+        if v & ~63:
+            msgs.append(f"unknown status bits {v & ~63:#x}")
         text = f"pasco_amd: device status {v:#x}: " + "; ".join(msgs)
         raise (F16RangeError if v == 1 else StatusError)(v, text)
 

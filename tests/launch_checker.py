@@ -178,8 +178,16 @@ class LaunchChecker:
             cfg2 = hip.conv_last_config()
             assert (cfg2["kernel"], cfg2["bm"], cfg2["bn"], cfg2["kc"]) == (cfg["kernel"], cfg["bm"], cfg["bn"], cfg["kc"])
             p1 = self.inner(x, weight, nbr, n_out, split=hip.split_weight_f16(weight))
-            assert hip.conv_last_config()["mma_mode"] == 1
-            assert torch.equal(p1, p2), f"{key} k{kvol} {cin}->{cout} n={n_out}: differs from the in-kernel split " \
-                                        f"(max {float((p1 - p2).abs().max()):.3e})"
-            self.seen[key][3].add((kvol, cin, cout))
+            cfg1 = hip.conv_last_config()
+            assert cfg1["mma_mode"] == 1
+            if cfg1["ksplit"] == 1:
+                assert torch.equal(p1, p2), f"{key} k{kvol} {cin}->{cout} n={n_out}: differs from the in-kernel split " \
+                                            f"(max {float((p1 - p2).abs().max()):.3e})"
+                self.seen[key][3].add((kvol, cin, cout))
+            else:
+                # the mode-1 kernel splits this map over the kernel offsets where the checked kernel (k_conv_wide, one
+                # workgroup per CU) does not: other fp32 summation order, not bit-comparable - fp32 reorder noise only
+                d = float((p1 - p2).abs().max()) / (float(p1.abs().mean()) + 1e-12)
+                assert d < 1e-4, f"{key} k{kvol} {cin}->{cout} n={n_out}: in-kernel split (ksplit {cfg1['ksplit']}) differs " \
+                                 f"by {d:.2e} of mean |y|"
         return worst

@@ -27,9 +27,11 @@ def wide_hook(hip):
     fn(0)
 
 
-@pytest.mark.parametrize("n,extent,cin,kind", [(13001, (40, 40, 16), 256, "k3"), (3000, (24, 24, 10), 256, "k3"),
-                                               (700, (12, 12, 8), 128, "k3"), (20000, (48, 48, 16), 64, "k2")])
-def test_wide_matches_oracle_and_the_gather_kernel(hip, oracle, wide_hook, n, extent, cin, kind):
+@pytest.mark.parametrize("n,extent,cin,cout,kind", [(13001, (40, 40, 16), 256, 256, "k3"), (3000, (24, 24, 10), 256, 256, "k3"),
+                                                    (700, (12, 12, 8), 128, 256, "k3"), (20000, (48, 48, 16), 64, 256, "k2"),
+                                                    (40001, (64, 64, 16), 128, 128, "k3"), (2500, (24, 24, 10), 64, 128, "k3"),
+                                                    (65536, (64, 64, 24), 128, 128, "k3")])   # 512 row tiles: k_conv_dma unsplit
+def test_wide_matches_oracle_and_the_gather_kernel(hip, oracle, wide_hook, n, extent, cin, cout, kind):
     coords = scene(n, extent, n)
     g = torch.Generator().manual_seed(n + 1)
     x = torch.randn(n, cin, generator=g)
@@ -39,9 +41,9 @@ def test_wide_matches_oracle_and_the_gather_kernel(hip, oracle, wide_hook, n, ex
     else:                      # strided k = 2: coarse output map
         offs = kernel_offsets(2, 1)
         out_coords = torch.unique(torch.cat([coords[:, :1], coords[:, 1:] // 2 * 2], dim=1), dim=0).int()
-    w = torch.randn(len(offs), cin, 256, generator=g) / (len(offs) * cin) ** 0.5
-    bias, res = torch.randn(256, generator=g), torch.randn(out_coords.shape[0], 256, generator=g)
-    es, eb = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    w = torch.randn(len(offs), cin, cout, generator=g) / (len(offs) * cin) ** 0.5
+    bias, res = torch.randn(cout, generator=g), torch.randn(out_coords.shape[0], cout, generator=g)
+    es, eb = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
     tk, tv, _, _, _ = oracle.map_insert(coords.contiguous(), dedup=False)
     nbr = oracle.nbr_build(out_coords.contiguous(), tk, tv, offs)
     m = out_coords.shape[0]
@@ -52,11 +54,11 @@ def test_wide_matches_oracle_and_the_gather_kernel(hip, oracle, wide_hook, n, ex
     wide_hook(1)
     got = hip.conv_fwd(xc, wc, nb, m, split=split, in_split=xs, **kw)
     cfg = hip.conv_last_config()
-    assert cfg["kernel"] == 6 and cfg["bm"] == 256 and cfg["bn"] == 256, cfg
+    assert cfg["kernel"] == 6 and cfg["bm"] == 256 and cfg["bn"] == cout, cfg
     err = float((got.cpu() - exp).abs().max()) / float(exp.abs().mean())
     assert err < 1e-4, err
     # operand emission: the second output equals ph_split_rows of the first
-    osc, osh = (torch.rand(256, generator=g) + 0.5).cuda(), (torch.randn(256, generator=g) * 0.1).cuda()
+    osc, osh = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.1).cuda()
     out2, osp = hip.conv_fwd(xc, wc, nb, m, split=split, in_split=xs, emit_split=(osc, osh, 1), **kw)
     assert torch.equal(osp.view(torch.int16), hip.split_rows(out2, pro_scale=osc, pro_shift=osh, pro_act=1).view(torch.int16))
     assert torch.equal(out2, got)
@@ -71,13 +73,15 @@ def test_wide_matches_oracle_and_the_gather_kernel(hip, oracle, wide_hook, n, ex
 
 
 def test_wide_default_dispatch_by_size(hip, wide_hook):
-    """Default routing: 256 x 256 tiles from 48 row tiles (12 288 rows) up, k_conv_dma below (measured crossover)."""
+    """Default routing: 256 channels - 256 x 256 tiles from 48 row tiles (12 288 rows) up, k_conv_dma below (measured
+    crossover); 128 channels - 256 x 128 tiles only where the row tiles fill the CUs in (nearly) whole rounds."""
     wide_hook(0)
-    for n, want in ((12500, 6), (9000, 4)):
-        coords = scene(n, (40, 40, 16), n).cuda()
+    for n, c, extent, want in ((12500, 256, (40, 40, 16), 6), (9000, 256, (40, 40, 16), 4), (45000, 128, (64, 64, 16), 6),
+                               (70000, 128, (64, 64, 24), 4)):
+        coords = scene(n, extent, n).cuda()
         tk, tv, _, _, _ = hip.map_insert(coords.contiguous(), dedup=False)
         nbr = hip.nbr_build(coords, tk, tv, kernel_offsets(3, 1))
-        x = torch.randn(n, 256, device="cuda")
-        w = torch.randn(27, 256, 256, device="cuda") / 80
+        x = torch.randn(n, c, device="cuda")
+        w = torch.randn(27, c, c, device="cuda") / 80
         hip.conv_fwd(x, w, nbr, n, split=hip.split_weight_rows(w), in_split=hip.split_rows(x))
-        assert hip.conv_last_config()["kernel"] == want
+        assert hip.conv_last_config()["kernel"] == want, (n, c)

@@ -187,3 +187,23 @@ def test_stride_chain_equals_step_by_step_strides(oracle_registered):
     n1 = ma.kernel_map(chain[0], chain[1], 2)
     n2 = mb.kernel_map(mb.stride(b.coordinate_map_key, 2), mb.stride(mb.stride(b.coordinate_map_key, 2), 2), 2)
     assert torch.equal(n1, n2)
+
+
+def test_rowlist_promise_is_checked_on_the_device(oracle):
+    """Row lists serve maps with exactly one pair per output row; a 3x3x3 map handed over as such raises status bit 5 at the
+    next check instead of leaving rows unwritten."""
+    from pasco_amd.me.backend import StatusError
+    from pasco_amd.me.core import kernel_offsets
+    dev = torch.device("cpu")
+    oracle.status_word(dev).zero_()
+    c = torch.cat([torch.zeros(200, 1, dtype=torch.long), torch.randint(0, 6, (200, 3), generator=torch.Generator().manual_seed(4))], 1).int()
+    tk, tv, _, uq, nu = oracle.map_insert(c.contiguous())
+    cu = c[uq.long()].contiguous()
+    nbr = oracle.nbr_build(cu, tk, tv, kernel_offsets(3, 1))          # many pairs per row
+    oracle.rowlist_build(nbr)
+    with pytest.raises(StatusError) as ei:
+        oracle.check_status(dev)
+    assert ei.value.bits == 32 and "one-pair" in str(ei.value)
+    ident = torch.arange(cu.shape[0], dtype=torch.int32).reshape(1, -1).contiguous()      # a one-pair map: silent
+    oracle.rowlist_build(ident)
+    oracle.check_status(dev)
