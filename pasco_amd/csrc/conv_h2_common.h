@@ -1,11 +1,14 @@
 // Shared pieces of the split-precision convolution kernels (conv_f16x3.hip: k_conv_f16x3 / k_conv_h2,
 // conv_dma.hip: k_conv_dma): argument block, activation / range helpers, the tile epilogue.
 #pragma once
+#include <type_traits>
+
 #include "ph_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HV_THREADS = 256;
 // KC input channels per stage (32 or 64); LDS rows hold KC + 8 f16 (80 / 144 bytes: 16-byte aligned and
@@ -152,8 +155,14 @@ __device__ __forceinline__ bool emit_split4(const float v[4], const float *sc, c
 
 
 // Where the epilogue reads the per-channel vectors from: global memory (default), or a copy the kernel staged in LDS
-// (a persistent kernel whose waves must not wait on vector-memory loads between their stores).  `which`: 0 bias,
-// 1 epi_scale, 2 epi_shift, 3 epi2_scale, 4 epi2_shift, 5 osp_scale, 6 osp_shift.
+// (h2_stage_params).  `which`: 0 bias, 1 epi_scale, 2 epi_shift, 3 epi2_scale, 4 epi2_shift, 5 osp_scale, 6 osp_shift.
+//
+// Why the staged forms exist (round 3, profiles/README.md "epilogue round trips"): vector loads and stores share the in-order
+// vmcnt counter, and the stores of the epilogue may alias anything the compiler knows - so in the plain form the loads of the
+// second group of channels (per-channel vectors, table rows, residual) wait for the STORES of the first to complete, and so
+// on: four store round trips per tile (~2.5 us each under load), 10 of the 20 us a workgroup of a k = 1 launch lives.  Staged:
+// every load of the epilogue is issued before its first store (per-channel vectors cooperatively into LDS, each lane's table +
+// residual values into LDS slots of its own), then the stores go out back to back.
 struct ParGlobal {
   __device__ __forceinline__ void get(const ConvArgsH &a, int which, const float *p, int col, bool ok, float dflt,
                                       float (&dst)[4]) const {
@@ -161,16 +170,96 @@ struct ParGlobal {
     ph_par4(a, p, col, ok, dflt, dst);
   }
 };
+typedef __attribute__((address_space(3))) float lds_float;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4 lds_float4;
+constexpr int H2_PAR_VECS = 7;
+struct ParLds {          // [H2_PAR_VECS][bn] floats in LDS, defaults filled in (absent vector, channel past the last)
+  const lds_float *base;
+  int n0, bn;
+  __device__ __forceinline__ void get(const ConvArgsH &a, int which, const float *p, int col, bool ok, float dflt,
+                                      float (&dst)[4]) const {
+    (void)a; (void)p; (void)ok; (void)dflt;
+    const f32x4 v = *reinterpret_cast<const lds_float4 *>(base + which * bn + (col - n0));
+    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+  }
+};
+// every thread of the workgroup (nt of them, nt >= bn) calls it; a barrier must follow before ParLds is used
+__device__ __forceinline__ void h2_stage_params(const ConvArgsH &a, int n0, int bn, int tid, lds_float *dst) {
+  if (tid >= bn) return;
+  const int col = n0 + tid;
+  const bool ok = col < a.cout;
+#define H2_STAGE_ONE(v, ptr, dflt) dst[(v) * bn + tid] = ((ptr) != nullptr && ok) ? (ptr)[col] : (dflt)
+  H2_STAGE_ONE(0, a.bias, 0.f);
+  H2_STAGE_ONE(1, a.epi_scale, 1.f);
+  H2_STAGE_ONE(2, a.epi_shift, 0.f);
+  H2_STAGE_ONE(3, a.epi2_scale, 1.f);
+  H2_STAGE_ONE(4, a.epi2_shift, 0.f);
+  H2_STAGE_ONE(5, a.osp_scale, 1.f);
+  H2_STAGE_ONE(6, a.osp_shift, 0.f);
+#undef H2_STAGE_ONE
+}
 
-// Epilogue of the transposed-accumulator tile (shared by k_conv_h2 and k_conv_dma): raw partial sums for a split over
-// the kernel offsets, else bias / BN / activation / residual tail as float4 stores and, with EMIT, the next
-// convolution's split operand.
-// `axis_vals` (optional): the table residual already summed by the caller, float4 per [i][j][m][u] (for a caller that
-// fetches the table rows ahead of its stores).
-template <int TM, int TN, bool EMIT, class PAR = ParGlobal>
+// The tail's per-element addends (table rows + dense residual, summed in the plain form's order) of one lane: read where they
+// are used (TailInline), or from LDS slots the lane filled before its first store (h2_stage_tail).
+struct TailInline {
+  static constexpr bool staged = false;
+  __device__ __forceinline__ float4 get(int slot) const { (void)slot; return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+struct TailLds {
+  static constexpr bool staged = true;
+  const lds_float4 *slots;   // [slot][nt] float4, this lane's column: slots + tid
+  int nt;
+  __device__ __forceinline__ float4 get(int slot) const {
+    const f32x4 v = slots[slot * nt];
+    return make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+// slot of (i, j, m, u) within passes of JB column blocks: ((i * JB + (j - j0)) * 2 + m) * 2 + u
+template <int TM, int TN, int JB>
+__device__ __forceinline__ void h2_stage_tail(const ConvArgsH &a, int64_t m0, int n0, int wm, int wn, int h, int l31, int j0,
+                                              lds_float4 *slots, int nt) {
+  const int cout = a.cout;
+  int64_t orow[TM];
+  int64_t axis_off[TM][3];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t r = m0 + (wm * TM + i) * 32 + l31;
+    orow[i] = r < a.n_out ? (a.out_rows ? (int64_t)a.out_rows[r] : r) : -1;
+    axis_off[i][0] = axis_off[i][1] = axis_off[i][2] = 0;
+    if (a.axis_table && orow[i] >= 0 && j0 == 0) {
+      if (ph_axis_offsets(a, orow[i], axis_off[i]) && a.status != nullptr) atomicOr(a.status, 4);
+    } else if (a.axis_table && orow[i] >= 0) {
+      ph_axis_offsets(a, orow[i], axis_off[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int col = n0 + (wn * TN + j0 + jj) * 32 + 16 * m + 8 * u + 4 * h;
+          const bool ok = orow[i] >= 0 && col < cout;
+          float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.residual && ok) rs = *reinterpret_cast<const float4 *>(a.residual + orow[i] * cout + col);
+          if (a.axis_table && ok) {
+            const float4 t = ph_axis_residual4(a, axis_off[i], col);
+            rs = make_float4(t.x + rs.x, t.y + rs.y, t.z + rs.z, t.w + rs.w);
+          }
+          f32x4 v;
+          v[0] = rs.x; v[1] = rs.y; v[2] = rs.z; v[3] = rs.w;
+          slots[(((i * JB + jj) * 2 + m) * 2 + u) * nt] = v;
+        }
+}
+
+// `J0`, `JB`: the column blocks j = J0 .. J0 + JB - 1 of the wave's TN (a staged tail whose slots do not all fit in LDS goes
+// in passes; the raw-partial-sum form ignores them and must be called with the full range).
+template <int TM, int TN, bool EMIT, class PAR = ParGlobal, class TAILV = TailInline, int J0 = 0, int JB = TN>
 __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm,
-                                              int wn, int h, int l31, const int64_t (*axis_pre)[3] = nullptr,
-                                              const PAR &par = PAR(), const float4 *axis_vals = nullptr) {
+                                              int wn, int h, int l31, const PAR &par = PAR(), const TAILV &tailv = TAILV()) {
   const int cout = a.cout;
   // accumulator layout (transposed block): acc[i][j][4g + q] = out[row = m0 + (wm*TM+i)*32 + l31]
   //                                                          [col = n0 + (wn*TN+j)*32 + 8g + 4h + q]
@@ -202,22 +291,48 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
   }
   // table residual: the three table rows of each of this lane's rows, found once per tile (or by the caller: axis_pre)
   int64_t axis_off[TM][3];
-  if (a.axis_table && axis_vals == nullptr) {
+  if (a.axis_table && !TAILV::staged) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int64_t row = orow[i];
-      if (axis_pre) {
-        axis_off[i][0] = axis_pre[i][0]; axis_off[i][1] = axis_pre[i][1]; axis_off[i][2] = axis_pre[i][2];
-      } else if (row >= 0) {
+      if (row >= 0) {
         if (ph_axis_offsets(a, row, axis_off[i]) && a.status != nullptr) atomicOr(a.status, 4);
       } else {
         axis_off[i][0] = axis_off[i][1] = axis_off[i][2] = 0;
       }
     }
   }
-  bool obad = false;
+  // VALU diet (round 3: the k = 1 launches are bound by the epilogue's VALU work - ~35 instructions per output value before):
+  // identity activations are skipped (h_act(v, 1) == v bit for bit), the range flag is one compare into a wave mask, the
+  // half-wave exchange is one v_permlane32_swap per pair of values
+  unsigned long long obad = 0;
+  // row base pointers, once per tile (the 64-bit row products do not belong next to every store)
+  float *out_row[TM];
+  _Float16 *osp_row[TM];
+  const int colbase = n0 + wn * TN * 32 + 4 * h;
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
+  for (int i = 0; i < TM; ++i) {
+    if (TM * TN > 4) {
+      out_row[i] = nullptr, osp_row[i] = nullptr;
+      continue;
+    }
+    const int64_t row = orow[i] >= 0 ? orow[i] : 0;
+    out_row[i] = a.out + row * cout + colbase;
+    osp_row[i] = EMIT ? a.out_split + row * (cout >> 5) * 64 + (colbase >> 5) * 64 + (colbase & 31) + 4 * h : nullptr;
+    if (TM * TN <= 4) {      // keep them in registers (the compiler would re-derive them at every store)
+      asm volatile("" : "+v"(out_row[i]));
+      if (EMIT) asm volatile("" : "+v"(osp_row[i]));
+    }
+  }
+  // instances: with / without activations, with / without an operand prologue (no per-value branches or selects)
+  // (the 256 x 256 tiles of k_conv_wide have no registers to spare: there the prologue stays a run-time flag and the
+  // addresses are derived at the stores - the extra instances and the pinned pointers cost it spills INSIDE its main loop)
+  constexpr bool FULL = TM * TN <= 4;
+  auto body = [&](auto acts_tag, auto osp_tag) {
+  constexpr bool ACTS = decltype(acts_tag)::value;
+  const bool OSP = decltype(osp_tag)::value == 2 ? a.osp_has != 0 : decltype(osp_tag)::value == 1;
+#pragma unroll
+  for (int j = J0; j < J0 + JB; ++j)
 #pragma unroll
     for (int m = 0; m < 2; ++m) {       // pairs of 4-channel runs: g = 2m, 2m + 1
       const int cbase = n0 + (wn * TN + j) * 32 + 16 * m;
@@ -239,7 +354,7 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
       if (EMIT) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) sc[q] = 1.f, sh[q] = 0.f;
-        if (a.osp_has) {
+        if (OSP) {
           float t4[4];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
@@ -262,56 +377,125 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
           const int g = 2 * m + u;
           const int col = cbase + 8 * u + 4 * h;
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            v[u][q] = h_act((acc[i][j][4 * g + q] * a.w_unscale + bias[u][q]) * es[u][q] + eb[u][q], a.epi_neg);
+          for (int q = 0; q < 4; ++q) v[u][q] = (acc[i][j][4 * g + q] * a.w_unscale + bias[u][q]) * es[u][q] + eb[u][q];
+          if (ACTS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[u][q] = h_act(v[u][q], a.epi_neg);
+          }
           if (a.has_tail) {
             float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.residual && rok && cok[u]) rs = *reinterpret_cast<const float4 *>(a.residual + row * cout + col);
-            if (a.axis_table && rok && cok[u]) {   // table rows first, then the dense residual (as the C restatement)
-              const float4 t = axis_vals ? axis_vals[((i * TN + j) * 2 + m) * 2 + u] : ph_axis_residual4(a, axis_off[i], col);
-              rs = make_float4(t.x + rs.x, t.y + rs.y, t.z + rs.z, t.w + rs.w);
+            if (TAILV::staged) {
+              rs = tailv.get(((i * JB + (j - J0)) * 2 + m) * 2 + u);
+            } else {
+              if (a.residual && rok && cok[u]) rs = *reinterpret_cast<const float4 *>(a.residual + row * cout + col);
+              if (a.axis_table && rok && cok[u]) {   // table rows first, then the dense residual (as the C restatement)
+                const float4 t = ph_axis_residual4(a, axis_off[i], col);
+                rs = make_float4(t.x + rs.x, t.y + rs.y, t.z + rs.z, t.w + rs.w);
+              }
             }
             const float r4[4] = {rs.x, rs.y, rs.z, rs.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[u][q] = h_act(v[u][q] * es2[u][q] + eb2[u][q] + r4[q], a.res_neg);
+            for (int q = 0; q < 4; ++q) v[u][q] = v[u][q] * es2[u][q] + eb2[u][q] + r4[q];
+            if (ACTS) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[u][q] = h_act(v[u][q], a.res_neg);
+            }
           }
           if ((!EMIT || a.out) && rok && cok[u])
-            *reinterpret_cast<float4 *>(a.out + row * cout + col) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+            *reinterpret_cast<float4 *>(FULL ? out_row[i] + (j * 32 + 16 * m + 8 * u) : a.out + row * cout + col) =
+                make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
         }
         if (EMIT) {
           // lanes l and l ^ 32 hold the same row: h = 0 keeps run u = 0 and takes the partner's u = 0 (channels
           // +4..7); h = 1 takes the partner's u = 1 (channels +8..11) and keeps its own u = 1
+          // (v_permlane32_swap: lanes 32..63 of the first register <-> lanes 0..31 of the second)
           float w8[8];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float send = h ? v[0][q] : v[1][q];
-            const float recv = __shfl_xor(send, 32);
-            w8[q] = h ? recv : v[0][q];
-            w8[4 + q] = h ? v[1][q] : recv;
+            const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0][q]), __float_as_uint(v[1][q]), false, false);
+            w8[q] = __uint_as_float(sw[0]);
+            w8[4 + q] = __uint_as_float(sw[1]);
           }
           if (rok) {
             f16x8 hi, lo;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
               float t = w8[q];
-              if (a.osp_has) {   // separate multiply and add, like ph_split_rows and the C restatement
+              if (OSP) {   // separate multiply and add, like ph_split_rows and the C restatement
 #pragma clang fp contract(off)
                 const float mm = t * sc[q];
-                t = h_act(mm + sh[q], a.osp_neg);
+                t = mm + sh[q];
+                if (ACTS) t = h_act(t, a.osp_neg);
               }
               t *= a.act_pow2;
-              obad |= h_out_of_range(t);
+              obad |= __builtin_amdgcn_fcmpf(fabsf(t), 65504.f, 10);     // unordered or greater: |t| > 65504 or NaN
               const _Float16 th = (_Float16)t;
               hi[q] = th;
               lo[q] = (_Float16)(t - (float)th);
             }
+            // column cbase + 8 h of the row: group (col >> 5), slot (col & 31); osp_row holds the lane's part
             const int col8 = cbase + 8 * h;
-            _Float16 *dst = a.out_split + (row * (cout >> 5) + (col8 >> 5)) * 64 + (col8 & 31);
+            _Float16 *dst = FULL ? osp_row[i] + j * 64 + 16 * m : a.out_split + (row * (cout >> 5) + (col8 >> 5)) * 64 + (col8 & 31);
             *reinterpret_cast<f16x8 *>(dst) = hi;
             *reinterpret_cast<f16x8 *>(dst + 32) = lo;
           }
         }
       }
     }
-  if (EMIT && a.status != nullptr && obad) atomicOr(a.status, 1);
+  };
+  const bool acts = a.epi_neg != 1.f || a.res_neg != 1.f || a.osp_neg != 1.f;
+  typedef std::integral_constant<int, 0> osp_off;
+  typedef std::integral_constant<int, 1> osp_on;
+  typedef std::integral_constant<int, 2> osp_runtime;
+  if (!FULL) {
+    if (acts) body(std::true_type(), osp_runtime());
+    else body(std::false_type(), osp_runtime());
+  } else if (EMIT && a.osp_has) {
+    if (acts) body(std::true_type(), osp_on());
+    else body(std::false_type(), osp_on());
+  } else {
+    if (acts) body(std::true_type(), osp_off());
+    else body(std::false_type(), osp_off());
+  }
+  if (EMIT && a.status != nullptr && obad != 0) atomicOr(a.status, 1);
+}
+
+// Staged epilogue of a one-tile workgroup (see ParGlobal): `scratch` = SCRATCH bytes of LDS that nothing reads or writes any
+// more once every wave has arrived here (the stage buffers and index table of the main loop).  NT threads, BN-wide tile.
+template <int TM, int TN, bool EMIT, int NT, int BN, int SCRATCH, int J0 = 0>
+__device__ __forceinline__ void h2_staged_passes(const ConvArgsH &a, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm, int wn,
+                                                 int h, int l31, const ParLds &pl, lds_float4 *slots) {
+  constexpr int PAR_BYTES = H2_PAR_VECS * BN * 4;
+  constexpr int PER_J = TM * 4 * NT * 16;
+  constexpr int FIT = (SCRATCH - PAR_BYTES) / PER_J;
+  static_assert(FIT >= 1, "LDS scratch too small for one column block of tail slots");
+  constexpr int JB = FIT < TN - J0 ? FIT : TN - J0;
+  h2_stage_tail<TM, TN, JB>(a, m0, n0, wm, wn, h, l31, J0, slots, NT);
+  if (J0 == 0) {   // the per-channel vectors every thread staged: visible after the barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  h2_store_tile<TM, TN, EMIT, ParLds, TailLds, J0, JB>(a, acc, m0, n0, wm, wn, h, l31, pl, TailLds{slots, NT});
+  if constexpr (J0 + JB < TN) h2_staged_passes<TM, TN, EMIT, NT, BN, SCRATCH, J0 + JB>(a, acc, m0, n0, wm, wn, h, l31, pl, slots);
+}
+template <int TM, int TN, bool EMIT, int NT, int BN, int SCRATCH>
+__device__ __forceinline__ void h2_store_tile_staged(const ConvArgsH &a, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm,
+                                                     int wn, int h, int l31, int tid, char *scratch) {
+  if (a.ksplit > 1) {
+    h2_store_tile<TM, TN, EMIT>(a, acc, m0, n0, wm, wn, h, l31);
+    return;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // every wave is done with the main loop's LDS
+  lds_float *par = (lds_float *)scratch;
+  h2_stage_params(a, n0, BN, tid, par);
+  const ParLds pl{par, n0, BN};
+  if (a.residual == nullptr && a.axis_table == nullptr) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    h2_store_tile<TM, TN, EMIT, ParLds>(a, acc, m0, n0, wm, wn, h, l31, pl);
+    return;
+  }
+  lds_float4 *slots = (lds_float4 *)(scratch + H2_PAR_VECS * BN * 4) + tid;
+  h2_staged_passes<TM, TN, EMIT, NT, BN, SCRATCH>(a, acc, m0, n0, wm, wn, h, l31, pl, slots);
 }

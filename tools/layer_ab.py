@@ -4,7 +4,11 @@
 
 Every distinct convolution launch of a step (kernel volume, channels, rows, flags) is captured with its operands and
 replayed alone under each variant (min of 5 timed launches, HIP events); per layer the launches per step are counted so the
-last line is the variant's convolution time per step."""
+last line is the variant's convolution time per step.
+
+LAYER_AB_BASE=<other libpascohip .so> (tools/build_base_lib.sh builds one from a git revision): every launch is also replayed
+through that library in the same process, interleaved - column [base]; run-to-run differences between GPU boxes (several %)
+do not enter the comparison."""
 import ctypes as C
 import os
 import sys
@@ -14,7 +18,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from pasco_amd.graph.synth import TeacherKeep, make_scene
-from pasco_amd.me.backend import hip_backend
+from pasco_amd.me.backend import CBackend, hip_backend
 
 out_path = sys.argv[1] if len(sys.argv) > 1 else None
 masks = [int(v, 0) for v in sys.argv[2:]] or [0, 1]
@@ -54,17 +58,25 @@ with torch.no_grad():
     be.conv_fwd = inner
 lib = be.lib
 lib.ph_conv_dma_set_ablate.argtypes = [C.c_int]
+base = None
+if os.environ.get("LAYER_AB_BASE"):
+    base = CBackend(os.path.abspath(os.environ["LAYER_AB_BASE"]), "ph_", "cuda")
+    masks = ["base"] + masks
 KN = {0: "mfma", 1: "f16x3", 2: "h2", 3: "rl", 4: "dma", 5: "win|dma", 6: "wide"}
 
 
 def timed(rec, mask):
     x, weight, nbr, n_out, kw = rec
-    lib.ph_conv_dma_set_ablate(mask)
+    fwd = inner
+    if mask == "base":
+        fwd = base.conv_fwd
+    else:
+        lib.ph_conv_dma_set_ablate(mask)
     ts = []
     for _ in range(6):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        inner(x, weight, nbr, n_out, **kw)
+        fwd(x, weight, nbr, n_out, **kw)
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
@@ -86,10 +98,10 @@ for _, key, cnt, t in sorted(rows, key=lambda r: -r[0]):
         continue
     flags = ("E" if emit else "-") + ("A" if axis else "-") + ("R" if res else "-")
     line = f"k{shape[0]:<3d} {shape[1]:3d}->{shape[2]:<3d} n={n_out:7d} {KN.get(kern, kern):7s} bn={bn:3d} ks={ksplit} {flags} x{cnt:2d}  " + \
-        "  ".join(f"[{m:#x}] {t[m]:7.1f}" for m in masks)
+        "  ".join(f"[{m if m == 'base' else hex(m)}] {t[m]:7.1f}" for m in masks)
     print(line, flush=True)
     lines.append(line)
-line = "conv us/step: " + "  ".join(f"[{m:#x}] {tot[m]:9.1f}" for m in masks)
+line = "conv us/step: " + "  ".join(f"[{m if m == 'base' else hex(m)}] {tot[m]:9.1f}" for m in masks)
 print(line)
 lines.append(line)
 if out_path:
