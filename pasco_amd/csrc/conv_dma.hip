@@ -351,8 +351,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
 #undef DMA_READS_DONE
   }
 
-  if (a.ablate & 2) h2_store_tile<TM, TN, EMIT>(a, acc, m0, n0, wm, wn, h, l31);     // the plain epilogue (A/B: tools/layer_ab.py 0 2)
-  else h2_store_tile_staged<TM, TN, EMIT, NT, BN, 2 * STAGE + DMA_KMAX * BM * 4>(a, acc, m0, n0, wm, wn, h, l31, tid, lds);
+  // every load of the epilogue ahead of its first store (conv_h2_common.h, ParGlobal): 600 -> 510 us on the 64 -> 384 projections
+  // together with the epilogue's VALU diet, 547 without the staging (profiles/r3s_layer_ab_epilogue_diet_vs_base.txt)
+  h2_store_tile_staged<TM, TN, EMIT, NT, BN, 2 * STAGE + DMA_KMAX * BM * 4>(a, acc, m0, n0, wm, wn, h, l31, tid, lds);
 }
 
 template <int WAVES, int WM, int WN, int TM, int TN>
@@ -412,7 +413,7 @@ int ph_conv_dma_try(const ConvArgsH &a_in, int bn, hipStream_t st) {
   if (zero == nullptr) return -1;
   ConvArgsH a = a_in;
   a.zero = zero;
-  a.ablate = g_dma_ablate & 3;      // bit 1: the plain epilogue; bit 0 (experiment switch, tools/layer_ab.py): 1 = the long pipeline for short launches too
+  a.ablate = g_dma_ablate & 1;      // bit 0 (experiment switch, tools/layer_ab.py): 1 = the long pipeline for short launches too
   // timing experiments (wrong results by design): 0x10 drops the per-axis table residual, 0x40 the dense residual
   if (g_dma_ablate & 0x10) a.axis_table = nullptr;
   if (g_dma_ablate & 0x40) a.residual = nullptr;

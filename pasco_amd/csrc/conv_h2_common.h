@@ -307,8 +307,13 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
   // half-wave exchange is one v_permlane32_swap per pair of values
   unsigned long long obad = 0;
   // row base pointers, once per tile (the 64-bit row products do not belong next to every store)
-  float *out_row[TM];
-  _Float16 *osp_row[TM];
+  // (typed as global memory: a pointer that went through the register pin below would otherwise be stored through with
+  // FLAT instructions, which count on lgkmcnt as well - every LDS read after them would wait for the stores)
+  typedef __attribute__((address_space(1))) float gfloat;
+  typedef __attribute__((address_space(1))) _Float16 ghalf;
+  typedef __attribute__((address_space(1))) f16x8 ghalf8;
+  gfloat *out_row[TM];
+  ghalf *osp_row[TM];
   const int colbase = n0 + wn * TN * 32 + 4 * h;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -317,8 +322,8 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
       continue;
     }
     const int64_t row = orow[i] >= 0 ? orow[i] : 0;
-    out_row[i] = a.out + row * cout + colbase;
-    osp_row[i] = EMIT ? a.out_split + row * (cout >> 5) * 64 + (colbase >> 5) * 64 + (colbase & 31) + 4 * h : nullptr;
+    out_row[i] = (gfloat *)(a.out + row * cout + colbase);
+    osp_row[i] = EMIT ? (ghalf *)(a.out_split + row * (cout >> 5) * 64 + (colbase >> 5) * 64 + (colbase & 31) + 4 * h) : nullptr;
     if (TM * TN <= 4) {      // keep them in registers (the compiler would re-derive them at every store)
       asm volatile("" : "+v"(out_row[i]));
       if (EMIT) asm volatile("" : "+v"(osp_row[i]));
@@ -328,8 +333,9 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
   // (the 256 x 256 tiles of k_conv_wide have no registers to spare: there the prologue stays a run-time flag and the
   // addresses are derived at the stores - the extra instances and the pinned pointers cost it spills INSIDE its main loop)
   constexpr bool FULL = TM * TN <= 4;
-  auto body = [&](auto acts_tag, auto osp_tag) {
+  auto body = [&](auto acts_tag, auto osp_tag, auto tail_tag) {
   constexpr bool ACTS = decltype(acts_tag)::value;
+  const bool TAIL = decltype(tail_tag)::value == 2 ? a.has_tail != 0 : decltype(tail_tag)::value == 1;
   const bool OSP = decltype(osp_tag)::value == 2 ? a.osp_has != 0 : decltype(osp_tag)::value == 1;
 #pragma unroll
   for (int j = J0; j < J0 + JB; ++j)
@@ -382,7 +388,7 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[u][q] = h_act(v[u][q], a.epi_neg);
           }
-          if (a.has_tail) {
+          if (TAIL) {
             float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
             if (TAILV::staged) {
               rs = tailv.get(((i * JB + (j - J0)) * 2 + m) * 2 + u);
@@ -402,8 +408,12 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
             }
           }
           if ((!EMIT || a.out) && rok && cok[u])
-            *reinterpret_cast<float4 *>(FULL ? out_row[i] + (j * 32 + 16 * m + 8 * u) : a.out + row * cout + col) =
-                make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+          {
+            f32x4 o;
+            o[0] = v[u][0]; o[1] = v[u][1]; o[2] = v[u][2]; o[3] = v[u][3];
+            if (FULL) *reinterpret_cast<__attribute__((address_space(1))) f32x4 *>(out_row[i] + (j * 32 + 16 * m + 8 * u)) = o;
+            else *reinterpret_cast<f32x4 *>(a.out + row * cout + col) = o;
+          }
         }
         if (EMIT) {
           // lanes l and l ^ 32 hold the same row: h = 0 keeps run u = 0 and takes the partner's u = 0 (channels
@@ -435,27 +445,37 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
             }
             // column cbase + 8 h of the row: group (col >> 5), slot (col & 31); osp_row holds the lane's part
             const int col8 = cbase + 8 * h;
-            _Float16 *dst = FULL ? osp_row[i] + j * 64 + 16 * m : a.out_split + (row * (cout >> 5) + (col8 >> 5)) * 64 + (col8 & 31);
-            *reinterpret_cast<f16x8 *>(dst) = hi;
-            *reinterpret_cast<f16x8 *>(dst + 32) = lo;
+            if (FULL) {
+              ghalf *dst = osp_row[i] + j * 64 + 16 * m;
+              *reinterpret_cast<ghalf8 *>(dst) = hi;
+              *reinterpret_cast<ghalf8 *>(dst + 32) = lo;
+            } else {
+              _Float16 *dst = a.out_split + (row * (cout >> 5) + (col8 >> 5)) * 64 + (col8 & 31);
+              *reinterpret_cast<f16x8 *>(dst) = hi;
+              *reinterpret_cast<f16x8 *>(dst + 32) = lo;
+            }
           }
         }
       }
     }
   };
   const bool acts = a.epi_neg != 1.f || a.res_neg != 1.f || a.osp_neg != 1.f;
-  typedef std::integral_constant<int, 0> osp_off;
-  typedef std::integral_constant<int, 1> osp_on;
-  typedef std::integral_constant<int, 2> osp_runtime;
+  typedef std::integral_constant<int, 0> off_t;
+  typedef std::integral_constant<int, 1> on_t;
+  typedef std::integral_constant<int, 2> runtime_t;
+  auto with_acts = [&](auto osp_tag, auto tail_tag) {
+    if (acts) body(std::true_type(), osp_tag, tail_tag);
+    else body(std::false_type(), osp_tag, tail_tag);
+  };
   if (!FULL) {
-    if (acts) body(std::true_type(), osp_runtime());
-    else body(std::false_type(), osp_runtime());
+    if (a.has_tail) with_acts(runtime_t(), on_t());
+    else with_acts(runtime_t(), off_t());
   } else if (EMIT && a.osp_has) {
-    if (acts) body(std::true_type(), osp_on());
-    else body(std::false_type(), osp_on());
+    if (a.has_tail) with_acts(on_t(), on_t());
+    else with_acts(on_t(), off_t());
   } else {
-    if (acts) body(std::true_type(), osp_off());
-    else body(std::false_type(), osp_off());
+    if (a.has_tail) with_acts(off_t(), on_t());
+    else with_acts(off_t(), off_t());
   }
   if (EMIT && a.status != nullptr && obad != 0) atomicOr(a.status, 1);
 }
