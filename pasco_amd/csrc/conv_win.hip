@@ -330,11 +330,18 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_win(ConvArgsH a) {
   };
   // activation fragments come from the window through the slot map: entry (k, row) -> window row slot - base, or the
   // zero row when the entry is empty / belongs to another pass
-  auto readfrag = [&](int k, int buf, int base, int wp, Frag &f) {
+  // the slot of stage k + 1 is read one stage ahead (slot_next): the dependent LDS round trip slot -> fragment address is
+  // not waited for at the head of every stage
+  uint32_t slot_next[TM];
+  auto slot_of = [&](int k, int i) -> uint32_t {
     const int kc = k < WIN_KV - 1 ? k : WIN_KV - 1;
+    return slot_lds[kc * BM + (wm * TM + i) * 32 + l31];
+  };
+  auto readfrag = [&](int k, int buf, int base, int wp, Frag &f) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const uint32_t slot = slot_lds[kc * BM + (wm * TM + i) * 32 + l31];
+      const uint32_t slot = slot_next[i];
+      slot_next[i] = slot_of(k + 1, i);
       const uint32_t local = slot - (uint32_t)base;
       const uint32_t wr = local < (uint32_t)wp ? local : (uint32_t)WMAX;
       const uint32_t abase = wr * 128u;
@@ -404,6 +411,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_win(ConvArgsH a) {
       //   then one rendezvous certifies both "every wave has finished reading that buffer" (lgkmcnt) and "every wave's
       //   weight DMA of stage k + 2 has landed in the other buffer" (vmcnt) - after it the buffer just read is refilled
       //   with stage k + 3 and the next iteration may read stage k + 2.
+#pragma unroll
+      for (int i = 0; i < TM; ++i) slot_next[i] = slot_of(0, i);
       readfrag(0, 0, base, wp, f0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
