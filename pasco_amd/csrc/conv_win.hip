@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ n
   __shared__ int32_t uniq[4096];                 // distinct rows (sort path) | word prefix sums (bitmap path: 8192 u16 halves)
   __shared__ int32_t count, s_min, s_max;
   __shared__ int32_t wsum[256];
+  __shared__ int32_t ent[WIN_CAP];               // the tile's 27 x 128 neighbour entries: read from global memory ONCE
   const int tid = threadIdx.x;
   const int64_t tile = blockIdx.x;
   const int64_t m0 = tile * WIN_BM;
@@ -64,6 +65,7 @@ __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ n
       const int k = e / WIN_BM, r = e - k * WIN_BM;
       const int64_t row = m0 + r;
       const int idx = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+      ent[e] = idx;
       if (idx >= 0) {
         lo = idx < lo ? idx : lo;
         hi = idx > hi ? idx : hi;
@@ -84,9 +86,7 @@ __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ n
     for (int i = tid; i < nwords; i += 256) keys[i] = 0;
     __syncthreads();
     for (int e = tid; e < WIN_CAP; e += 256) {
-      const int k = e / WIN_BM, r = e - k * WIN_BM;
-      const int64_t row = m0 + r;
-      const int idx = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+      const int idx = ent[e];
       if (idx >= 0) atomicOr(&keys[(idx - base) >> 5], 1 << ((idx - base) & 31));
     }
     __syncthreads();
@@ -121,9 +121,7 @@ __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ n
       atomicAdd(&stats[1], cnt > 0 ? (cnt + wmax_b - 1) / wmax_b : 1);
     }
     for (int e = tid; e < WIN_CAP; e += 256) {
-      const int k = e / WIN_BM, r = e - k * WIN_BM;
-      const int64_t row = m0 + r;
-      const int idx = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+      const int idx = ent[e];
       uint16_t s = 0xFFFFu;
       if (idx >= 0) {
         const int off = idx - base, w = off >> 5;
@@ -138,9 +136,7 @@ __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ n
   __syncthreads();
   // distinct input rows of the tile: LDS hash set, first inserter appends
   for (int e = tid; e < WIN_CAP; e += 256) {
-    const int k = e / WIN_BM, r = e - k * WIN_BM;
-    const int64_t row = m0 + r;
-    const int idx = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+    const int idx = ent[e];
     if (idx < 0) continue;
     uint32_t h = win_hash((uint32_t)idx) & (HT - 1);
     for (;;) {
@@ -183,9 +179,7 @@ __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ n
   }
   // slot of every (offset, row) entry: rank of its input row in the sorted list
   for (int e = tid; e < WIN_CAP; e += 256) {
-    const int k = e / WIN_BM, r = e - k * WIN_BM;
-    const int64_t row = m0 + r;
-    const int idx = row < n_out ? nbr[(int64_t)k * n_out + row] : -1;
+    const int idx = ent[e];
     uint16_t s = 0xFFFFu;
     if (idx >= 0) {
       int lo = 0, hi = cnt - 1;

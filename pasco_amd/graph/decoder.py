@@ -30,10 +30,27 @@ from .blocks import BasicGenerativeDeconvolutionBlock, ResidualBlock, SpatialDro
 from .fused import ACT_NONE, ACT_RELU
 
 
+def _corner(v, coords: torch.Tensor) -> torch.Tensor:
+    """A box corner as a [1, 3] tensor of the coordinates' dtype on their device; the cast of a device tensor is kept on it
+    (`_ph_corner`: the same corner tensor of the batch dict is tested against at every level - one cast kernel, not one per
+    call)."""
+    if torch.is_tensor(v):
+        hit = getattr(v, "_ph_corner", None)
+        if hit is not None and hit.dtype == coords.dtype and hit.device == coords.device and hit._ph_version == v._version:
+            return hit
+        out = v.to(device=coords.device, dtype=coords.dtype).reshape(1, 3)
+        out._ph_version = v._version
+        try:
+            v._ph_corner = out
+        except AttributeError:
+            pass
+        return out
+    return torch.as_tensor(v, device=coords.device).to(coords.dtype).reshape(1, 3)
+
+
 def inside_bounds(coords: torch.Tensor, lo, hi) -> torch.Tensor:
     """Inclusive box test on int32 [N,4] coordinates (decoder_v3.py:151-158, misc.py:16-27)."""
-    lo = torch.as_tensor(lo, device=coords.device).to(coords.dtype).reshape(1, 3)
-    hi = torch.as_tensor(hi, device=coords.device).to(coords.dtype).reshape(1, 3)
+    lo, hi = _corner(lo, coords), _corner(hi, coords)
     xyz = coords[:, 1:]
     return ((xyz >= lo) & (xyz <= hi)).all(dim=1)
 
@@ -44,11 +61,15 @@ def batch_sparse_tensor(tensors: List[ME.SparseTensor], n_max: Optional[int] = N
     the padded rows take part in the attention - SURVEY.md section 9 item 5)."""
     n_max = max([t.F.shape[0] for t in tensors] + ([n_max] if n_max is not None else []))
     f0, c0 = tensors[0].F, tensors[0].C
-    bf = f0.new_zeros((len(tensors), n_max, f0.shape[1]))
-    bc = c0.new_zeros((len(tensors), n_max, c0.shape[1]))
-    for i, t in enumerate(tensors):
-        bf[i, : t.F.shape[0]] = t.F
-        bc[i, : t.F.shape[0]] = t.C
+    bf = f0.new_empty((len(tensors), n_max, f0.shape[1]))
+    bc = c0.new_empty((len(tensors), n_max, c0.shape[1]))
+    for i, t in enumerate(tensors):          # rows copied once, only the padding is zero-filled
+        n = t.F.shape[0]
+        bf[i, :n] = t.F
+        bc[i, :n] = t.C
+        if n < n_max:
+            bf[i, n:].zero_()
+            bc[i, n:].zero_()
     return bf, bc
 
 
@@ -212,6 +233,15 @@ class DecoderGenerativeSepConvV2(nn.Module):
             pruned = mgr.prune_batch([(x.coordinate_map_key, keep) for _, _, x, keep in todo])
         else:
             pruned = [x.coordinate_manager.prune(x.coordinate_map_key, keep) for _, _, x, keep in todo]
+        # the per-subnet voxel features go straight into the zero-padded [M, Nmax, C] batch the transformer reads
+        # (batch_sparse_tensor's layout): the second convolution of each pair writes its slice, only the padding is filled
+        infer_ids = list(range(self.n_infers) if subnets is None else subnets)
+        n_rows = {(i, scale): x.coordinate_manager.size(out_key) for (i, scale, x, keep), (out_key, rows) in zip(todo, pruned)}
+        batch_f, batch_c = {}, {}
+        for scale, x in xs.items():
+            n_max = max([n_rows[(i, scale)] for i in infer_ids] + ([pad_to[scale]] if pad_to[scale] is not None else []))
+            batch_f[scale] = x.F.new_empty((len(infer_ids), n_max, x.F.shape[1]))
+            batch_c[scale] = x.C.new_empty((len(infer_ids), n_max, x.C.shape[1]))
         for (i, scale, x, keep), (out_key, rows) in zip(todo, pruned):
             mgr = x.coordinate_manager
             be = mgr.backend()
@@ -221,9 +251,17 @@ class DecoderGenerativeSepConvV2(nn.Module):
                                                           coordinate_manager=mgr))
             xi = ME.SparseTensor(be.gather_rows(x.F.contiguous(), rows), coordinate_map_key=out_key, coordinate_manager=mgr)
             vf = self.voxel_feats[f"scale{scale}_infer{i}"]
-            h = fused.conv(xi, vf[0], epi_bn=vf[1], epi_act=ACT_RELU)
-            xs_infers[scale].append(fused.conv(h, vf[3]))
-        batched = {s: batch_sparse_tensor(v, pad_to[s]) for s, v in xs_infers.items()}
+            # the first convolution's only reader is the second: it writes that operand and no fp32 rows
+            h = fused.conv(xi, vf[0], epi_bn=vf[1], epi_act=ACT_RELU, emit_next=(None, ACT_NONE), split_only=True)
+            slot = infer_ids.index(i)
+            n = n_rows[(i, scale)]
+            y = fused.conv(h, vf[3], out=batch_f[scale][slot, :n])
+            batch_c[scale][slot, :n] = y.C
+            if n < batch_f[scale].shape[1]:
+                batch_f[scale][slot, n:].zero_()
+                batch_c[scale][slot, n:].zero_()
+            xs_infers[scale].append(y)
+        batched = {s: (batch_f[s], batch_c[s]) for s in xs_infers}
         # rows of every subnet at every scale, for the transformer's host-side "is there a padded row" decisions
         batched["_meta"] = {"lens": {"fine": [int(t.F.shape[0]) for t in xs_infers[1]],
                                      "level": {s: [int(t.F.shape[0]) for t in v] for s, v in xs_infers.items()}}}

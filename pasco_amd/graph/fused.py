@@ -382,7 +382,7 @@ def _split_key(F, ps, pb, pro_act, slope):
 def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NONE, epi_bn=None,
          epi_act: int = ACT_NONE, epi2_bn=None, residual: Optional[torch.Tensor] = None,
          res_act: int = ACT_NONE, slope: float = 0.01, out_key=None, nbr=None, emit_next=None,
-         split_only: bool = False, one_pair: bool = False):
+         split_only: bool = False, one_pair: bool = False, out: Optional[torch.Tensor] = None):
     """One fused launch of a Minkowski-style convolution module on `x`.
 
     out = act_res( act_epi(BN_epi(conv(act_pro(BN_pro(x))) + bias)) -> BN_epi2 -> (+ residual) )
@@ -394,11 +394,17 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     apply, a normal SparseTensor comes back.  `x` may itself be a `SplitRows`.
     `one_pair`: the caller guarantees that every output row of the map has exactly one (offset, input row) pair (the
     generative transposed convolutions: each child has its one parent) - the launch then runs as k = 1 products over row
-    lists grouped by offset instead of walking all offsets of every row."""
+    lists grouped by offset instead of walking all offsets of every row.
+    `out`: a contiguous fp32 [n_out, out_channels] buffer the result is written into (a slice of a batch the caller assembles:
+    no copy afterwards)."""
     mgr = x.coordinate_manager
     if not _FUSION:
         assert not isinstance(x, SplitRows)
-        return _conv_unfused(x, mod, pro_bn, pro_act, epi_bn, epi_act, epi2_bn, residual, res_act, slope, out_key, nbr)
+        y = _conv_unfused(x, mod, pro_bn, pro_act, epi_bn, epi_act, epi2_bn, residual, res_act, slope, out_key, nbr)
+        if out is not None:
+            out.copy_(y.F)
+            y = SparseTensor(out, coordinate_map_key=y.coordinate_map_key, coordinate_manager=mgr)
+        return y
     if out_key is None:
         out_key, nbr = mod._maps(x)
     n_out = mgr.size(out_key)
@@ -438,11 +444,14 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     if one_pair and in_split is not None and nbr is not None and nbr.shape[0] <= 8 and n_out >= MIN_ROWS_LINEAR and \
             be.device_type == "cuda" and os.environ.get("PASCO_CONV_RL", "1") != "0":
         rowlist = mgr.kernel_rowlist(nbr)
+    if out is not None:
+        assert not only and out.is_contiguous() and tuple(out.shape) == (n_out, mod.out_channels) and out.dtype == torch.float32
     out = be.conv_fwd(
         x_rows, mod.kernel.detach(), nbr, n_out, xshape=xshape, bias=bias,
         pro_scale=ps, pro_shift=pb, pro_act=pro_act, epi_scale=es, epi_shift=eb, epi_act=epi_act,
         epi2_scale=e2s, epi2_shift=e2b, residual=residual, res_act=res_act, slope=slope, split=split,
-        in_split=in_split, emit_split=emit, want_out=not only, win=win, in_split_has_prologue=True, rowlist=rowlist)
+        in_split=in_split, emit_split=emit, want_out=not only, win=win, in_split_has_prologue=True, rowlist=rowlist,
+        out=out if n_out > 0 else None)
     if emit is None:
         return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
     out, out_split = out
