@@ -746,6 +746,27 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
     int want = (int)(2048 / (t128 > 0 ? t128 : 1));
     if (want > 8) want = 8;
     if (want > d->kvol / 4) want = d->kvol / 4;
+    // round 3: the number of slices by a cost model instead (128-wide tiles; both operand modes, so that they keep choosing alike): the launch runs in
+    // ceil(tiles x slices / 512) rounds of resident workgroups, a round lasts as long as its longest slice, and every slice
+    // adds a partial-sum round trip - e.g. 146 tiles x 27 offsets: 6 slices = 2 rounds of 5 offsets, 3 slices = ONE round of 9
+    // (profiles/r3z_layer_ab_ksplit_model.txt).  PASCO_CONVH_KSPLIT_MODEL=0: the rule above.
+    static const bool model_on = [] { const char *e = getenv("PASCO_CONVH_KSPLIT_MODEL"); return e == nullptr || atoi(e) != 0; }();
+    if (model_on && bn == 128 && t128 < 2 * 256 && d->kvol >= 8 && d->splitk_ws != nullptr) {
+      const double stage_us = 1.3, fixed_us = 5.0;           // one 32-channel stage of a workgroup sharing its CU; launch / prologue
+      const double nchunks = (double)(a.cpad / 32);
+      int best = 1;
+      double best_us = 1e30;
+      for (int ks = 1; ks <= 12 && ks <= d->kvol / 3; ++ks) {
+        const int kper = (d->kvol + ks - 1) / ks;
+        if (kper > 32 || (d->kvol + kper - 1) / kper != ks) continue;      // beyond the index table / same as fewer slices
+        if (ks > 1 && d->splitk_ws_bytes < (int64_t)ks * d->n_out * d->cout * 4) continue;
+        const double rounds = (double)((t128 * ks + 511) / 512);
+        double us = rounds * (kper * nchunks * stage_us + fixed_us);
+        if (ks > 1) us += (double)ks * (double)d->n_out * d->cout * 4.0 / 3.0e6 + fixed_us;   // the reduction: 3 TB/s
+        if (us < best_us) best_us = us, best = ks;
+      }
+      want = best;
+    }
     if (se) want = knobs.ksplit;
     const bool room = d->splitk_ws != nullptr && d->splitk_ws_bytes >= (int64_t)want * d->n_out * d->cout * 4;
     if (bn == 128 && t128 < 2 * 256 && want >= 2 && room && !env) {

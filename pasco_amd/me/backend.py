@@ -480,10 +480,10 @@ class CBackend:
             d.w_unscale = float(unscale) * 2.0 ** (-SPLIT_ACT_EXP2)
             d.status = _ptr(self.status_word(dev))
             if kvol > 1 or n_out * cout <= (1 << 23):
-                # scratch for a split over the kernel offsets: few-row layers split whole (8 partial copies), big maps only
+                # scratch for a split over the kernel offsets: few-row layers split whole (up to 12 partial copies), big maps only
                 # their last partial round of row tiles (ph_conv_dma_try's tail split: slices x tail tiles <= the 512 resident
                 # 128 x 128 tiles of one round = 32 MiB of fp32 partial sums whatever the width)
-                need = 8 * n_out * cout * 4 if n_out * cout <= (1 << 23) else 512 * 128 * 128 * 4
+                need = 12 * n_out * cout * 4 if n_out * cout <= (1 << 23) else 512 * 128 * 128 * 4
                 key = ("splitk",) + self._stream_key(dev)
                 sk = self._ws.get(key)
                 if sk is None or sk.numel() < need:
