@@ -249,7 +249,10 @@ class DecoderGenerativeSepConvV2(nn.Module):
                 logits = sem_logits_at_scales[scale][i]
                 sem_logits_pruneds.append(ME.SparseTensor(be.gather_rows(logits.F.contiguous(), rows), coordinate_map_key=out_key,
                                                           coordinate_manager=mgr))
-            xi = ME.SparseTensor(be.gather_rows(x.F.contiguous(), rows), coordinate_map_key=out_key, coordinate_manager=mgr)
+            # the subnet's rows of the level, as the first convolution's operand (the level is split once for all subnets)
+            xi = fused.gathered_split(x, rows, out_key)
+            if xi is None:
+                xi = ME.SparseTensor(be.gather_rows(x.F.contiguous(), rows), coordinate_map_key=out_key, coordinate_manager=mgr)
             vf = self.voxel_feats[f"scale{scale}_infer{i}"]
             # the first convolution's only reader is the second: it writes that operand and no fp32 rows
             h = fused.conv(xi, vf[0], epi_bn=vf[1], epi_act=ACT_RELU, emit_next=(None, ACT_NONE), split_only=True)

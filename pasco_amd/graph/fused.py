@@ -186,6 +186,22 @@ def split_input(x: SparseTensor, be, ps, pb, pro_act, slope):
     return hit
 
 
+def gathered_split(x: SparseTensor, rows: torch.Tensor, out_key):
+    """The rows `rows` of `x` as the pre-split operand of a following `conv` (a `SplitRows` on the map `out_key`): the
+    operand of `x` is made once (cached on `x`, shared by every gather from it) and its ROWS are gathered - splitting is
+    row-wise, so split(gather(x)) == gather(split(x)) bit for bit - instead of gathering fp32 rows and splitting each
+    gathered copy.  None when the split path does not apply (the caller gathers fp32 rows)."""
+    mgr = x.coordinate_manager
+    be = mgr.backend()
+    c = x.F.shape[1]
+    if not (_FUSION and _PRESPLIT and conv_precision() == "f16x3" and be.split_supported(c, c) and x.F.shape[0] > 0):
+        return None
+    op = split_input(x, be, None, None, ACT_NONE, 0.01)                     # [n, cpad / 32, 2, 32] f16
+    n, cpad = op.shape[0], op.shape[1] * 32
+    got = be.gather_rows(op.view(torch.float32).view(n, cpad), rows)         # 4 bytes per channel: rows of cpad "floats"
+    return SplitRows(got.view(torch.float16).view(got.shape[0], cpad // 32, 2, 32), c, out_key, mgr)
+
+
 def split_rows_2d(x2d: torch.Tensor):
     """Pre-split operand of a tall [N, cin] matrix for several `linear_rows` calls on it (None when the split
     path does not apply)."""
@@ -464,4 +480,4 @@ def conv(x: SparseTensor, mod: _ConvBase, *, pro_bn=None, pro_act: int = ACT_NON
     return y
 
 
-__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "precision_override", "optimistic", "optimistic_override", "set_fusion", "fusion", "linear_rows", "split_rows_2d", "batched_rows_matmul", "prepare_batched_weights", "linear_bn_act", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]
+__all__ = ["fold_bn", "conv", "set_conv_precision", "conv_precision", "precision_override", "optimistic", "optimistic_override", "set_fusion", "fusion", "linear_rows", "split_rows_2d", "gathered_split", "batched_rows_matmul", "prepare_batched_weights", "linear_bn_act", "ACT_NONE", "ACT_RELU", "ACT_LEAKY"]
