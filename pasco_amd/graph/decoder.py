@@ -35,13 +35,18 @@ def _corner(v, coords: torch.Tensor) -> torch.Tensor:
     (`_ph_corner`: the same corner tensor of the batch dict is tested against at every level - one cast kernel, not one per
     call)."""
     if torch.is_tensor(v):
-        hit = getattr(v, "_ph_corner", None)
-        if hit is not None and hit.dtype == coords.dtype and hit.device == coords.device and hit._ph_version == v._version:
-            return hit
+        # keyed by stream as well: the cast made on another scene thread's stream may not have run yet when this one reads it
+        stream = torch.cuda.current_stream(coords.device).cuda_stream if coords.device.type == "cuda" else 0
+        key = (coords.dtype, coords.device, stream, v._version)
+        cache = getattr(v, "_ph_corner", None)
+        if cache is not None and key in cache:
+            return cache[key]
         out = v.to(device=coords.device, dtype=coords.dtype).reshape(1, 3)
-        out._ph_version = v._version
         try:
-            v._ph_corner = out
+            if cache is None or len(cache) > 8:
+                cache = {}
+                v._ph_corner = cache
+            cache[key] = out
         except AttributeError:
             pass
         return out
@@ -53,6 +58,24 @@ def inside_bounds(coords: torch.Tensor, lo, hi) -> torch.Tensor:
     lo, hi = _corner(lo, coords), _corner(hi, coords)
     xyz = coords[:, 1:]
     return ((xyz >= lo) & (xyz <= hi)).all(dim=1)
+
+
+_FIRST_ROWS = {}
+
+
+def _first_rows(n: int, device, k: int = 1000) -> torch.Tensor:
+    """bool [n]: the first k rows (the reference's "nothing kept" fallback selection); one tensor per (n, device, stream)
+    instead of an arange + compare per call."""
+    # per stream: a tensor made on another scene thread's stream may not have been written yet when this stream reads it
+    stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+    key = (n, str(device), k, stream)
+    hit = _FIRST_ROWS.get(key)
+    if hit is None:
+        if len(_FIRST_ROWS) > 64:
+            _FIRST_ROWS.clear()
+        hit = torch.arange(n, device=device) < k
+        _FIRST_ROWS[key] = hit
+    return hit
 
 
 def batch_sparse_tensor(tensors: List[ME.SparseTensor], n_max: Optional[int] = None):
@@ -215,7 +238,7 @@ class DecoderGenerativeSepConvV2(nn.Module):
             keep = keep_override.member(scale, i, x.C) if keep_override is not None else self._occupied(logits)
             # reference fallback (decoder_v3.py:415-418): nothing kept -> keep the first 1000 rows.  Selected on the
             # device (no host read of the count)
-            first = torch.arange(keep.shape[0], device=keep.device) < 1000
+            first = _first_rows(keep.shape[0], keep.device)
             keep = torch.where(keep.any(), keep, first)
             return keep & inside_bounds(x.C, min_Cs[i], max_Cs[i])
 
