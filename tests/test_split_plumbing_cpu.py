@@ -85,3 +85,26 @@ def test_launch_checker_formulas_on_the_oracle(split_checker):
         del split_checker.conv_fwd
     launches = sum(v[0] for v in chk.seen.values())
     assert launches > 60 and all(v[0] == v[1] for v in chk.seen.values())
+
+
+def test_gathered_split_equals_split_of_gathered_rows(split_checker):
+    """`fused.gathered_split`: the operand of a tensor is made once and its ROWS gathered - bit for bit the operand of the
+    gathered fp32 rows (splitting is row-wise), with -1 rows giving zero rows, odd channel counts padded to a group."""
+    import pasco_amd.me as ME
+    split_checker.checker_split = True
+    g = torch.Generator().manual_seed(5)
+    for c in (32, 40, 64):
+        n = 301
+        coords = torch.cat([torch.zeros(n, 1, dtype=torch.int32), torch.arange(n, dtype=torch.int32)[:, None].repeat(1, 3)], dim=1)
+        mgr = ME.CoordinateManager(D=3, device=torch.device("cpu"))
+        key = mgr.insert_unique(coords.contiguous(), 1)
+        x = ME.SparseTensor(torch.randn(n, c, generator=g), coordinate_map_key=key, coordinate_manager=mgr)
+        rows = torch.randperm(n, generator=g)[:97].int().contiguous()
+        got = fused.gathered_split(x, rows, key)
+        assert got is not None and got.channels == c
+        want = split_checker.split_rows(split_checker.gather_rows(x.F.contiguous(), rows))
+        assert torch.equal(got.split.view(torch.int16), want.view(torch.int16))
+        again = fused.gathered_split(x, rows, key)          # the level's operand is cached on the tensor
+        assert len(x.__dict__["_ph_in_split"]) == 1 and torch.equal(again.split.view(torch.int16), want.view(torch.int16))
+    with fused.precision_override("f32"):
+        assert fused.gathered_split(x, rows, key) is None
