@@ -421,7 +421,8 @@ __global__ void __launch_bounds__(256) k_attn_split(AttnSplitArgs s) {
     force = 0u;
     if (a.any != nullptr && qv) force = ((a.any[b * 4 + qt] >> l31) & 1u) ? 0u : 1u;
   }
-  const float s_unscale = s.kv_unscale * (1.f / AS_QSCALE);
+  // scores are kept in the log2 domain (the unscale carries log2(e)): p = exp2(s - m) is one v_exp_f32, no multiply per value
+  const float s_unscale = s.kv_unscale * (1.f / AS_QSCALE) * 1.4426950408889634f;
 
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 oacc[2];
@@ -502,30 +503,47 @@ __global__ void __launch_bounds__(256) k_attn_split(AttnSplitArgs s) {
     }
     if (INTER && pre) fire_mask(t + 2);
     // ---- mask + online softmax: this lane's query is qq; register 4g + r is key nb + 8g + 4 h2 + r ----------------------
+    // sv stays in the accumulator's raw scale: the maximum does not care, and the unscale (log2 domain) rides in the one fma
+    // that forms the exponent; the 2^12 scale of P is part of that fma's addend
     float sv[16];
     float tmax = -INFINITY;
+    if (nvalid == AS_KT) {      // full tile (uniform): no key-validity test; mask bit and the all-masked rule in one v_and_or
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const unsigned wr[4] = {mw[g][0], mw[g][1], mw[g][2], mw[g][3]};
+      for (int g = 0; g < 4; ++g) {
+        const unsigned wr[4] = {mw[g][0], mw[g][1], mw[g][2], mw[g][3]};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        bool ok = 8 * g + r + 4 * h2 < nvalid;
-        if (MASK) ok = ok && (force || (wr[r] & lanebit));
-        const float x = ok ? sacc[4 * g + r] * s_unscale : -INFINITY;
-        sv[4 * g + r] = x;
-        tmax = fmaxf(tmax, x);
+        for (int r = 0; r < 4; ++r) {
+          const unsigned keep = MASK ? ((wr[r] & lanebit) | force) : 1u;
+          const float x = keep ? sacc[4 * g + r] : -INFINITY;
+          sv[4 * g + r] = x;
+          tmax = fmaxf(tmax, x);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const unsigned wr[4] = {mw[g][0], mw[g][1], mw[g][2], mw[g][3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          bool ok = 8 * g + r + 4 * h2 < nvalid;
+          if (MASK) ok = ok && (force || (wr[r] & lanebit));
+          const float x = ok ? sacc[4 * g + r] : -INFINITY;
+          sv[4 * g + r] = x;
+          tmax = fmaxf(tmax, x);
+        }
       }
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m_run, tmax);
+    const float m_new = fmaxf(m_run, tmax);                            // raw scale
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __expf(m_run - m_safe);      // m_run = -inf -> 0 (nothing accumulated yet)
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_safe) * s_unscale);      // m_run = -inf -> 0 (nothing accumulated yet)
     m_run = m_new;
+    const float e_off = 12.f - m_safe * s_unscale;                     // log2(AS_PSCALE) - m in the log2 domain
     h16x8 ph[2], pl[2];
     float psum = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float p = __expf(sv[i] - m_safe) * AS_PSCALE;
+      const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[i], s_unscale, e_off));
       psum += p;
       const _Float16 th = (_Float16)p;
       ph[i >> 3][i & 7] = th;
@@ -572,7 +590,7 @@ __global__ void __launch_bounds__(256) k_attn_split(AttnSplitArgs s) {
   float *row = a.part + (w * a.qp + qq) * (48 + 4);
   float lt = l_run + __shfl_xor(l_run, 32);
   if (h2 == 0) {
-    row[48] = m_run;
+    row[48] = m_run * s_unscale * 0.6931471805599453f;      // raw scale -> log2 domain -> natural log (k_attn_merge's domain)
     row[49] = lt;
   }
 #pragma unroll
