@@ -537,9 +537,15 @@ def main():
     elapsed = time.perf_counter() - t0
     out, panop = last["out"], last["panop"]
     prof.enabled = False
+    rounds_ms = []
     if rank == 0:
         per = [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])]
         print(f"[bench] per-step host ms: {per}", file=sys.stderr, flush=True)
+        # the timed steps in groups of `in_flight` completions: a box that goes through a slow period (seen twice this round:
+        # the HBM-bound launches 6 x slower for ~0.3 s, then normal again) shows here, not only in the mean
+        g = max(args.in_flight, 1)
+        rounds_ms = [round((marks[min(i + g, len(marks) - 1)] - marks[i]) * 1e3 / (min(i + g, len(marks) - 1) - i), 2)
+                     for i in range(0, len(marks) - 1, g)]
     one_in_flight = None
     if args.in_flight > 1 and world == 1:          # the same K steps, one scene at a time on one stream
         window = []
@@ -622,6 +628,12 @@ def main():
                                  "(= Net.forward(return_ensemble=True) + its input stage)",
                        "pruning": "teacher-forced", "parallelism": par},
         }
+        if rounds_ms:
+            srt = sorted(rounds_ms)
+            res["step_ms_by_round"] = {"group": max(args.in_flight, 1), "median": srt[len(srt) // 2], "min": srt[0], "max": srt[-1],
+                                       "rounds": rounds_ms,
+                                       "note": "ms per step over each group of `group` consecutive completions of the timed loop "
+                                               "(value / ms_per_step are the mean over all of them)"}
         if heads:
             res["bound_note"] = ("trunk replicated on every rank: speed-up over 1 GPU is bounded by (T + 8 H) / (T + H) "
                                  "~ 2.2x at S10 (T ~ 2.1 TFLOP trunk, H ~ 0.43 TFLOP per subnet head; SURVEY.md 8(e))")
