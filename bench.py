@@ -334,6 +334,20 @@ def dry_run(args, world, rank):
         dist.destroy_process_group()
 
 
+def allocator_state(device):
+    """Caching-allocator numbers that explain a slow run: memory reserved / in use, and how often an allocation only succeeded
+    after the allocator had to give its cached blocks back to the driver (every big tensor after that is a fresh hipMalloc)."""
+    try:
+        st = torch.cuda.memory_stats(device)
+        return {"reserved_GB": round(st.get("reserved_bytes.all.current", 0) / 2 ** 30, 2),
+                "reserved_peak_GB": round(st.get("reserved_bytes.all.peak", 0) / 2 ** 30, 2),
+                "allocated_peak_GB": round(st.get("allocated_bytes.all.peak", 0) / 2 ** 30, 2),
+                "alloc_retries": int(st.get("num_alloc_retries", 0)), "ooms": int(st.get("num_ooms", 0)),
+                "device_mallocs": int(st.get("num_device_alloc", 0)), "device_frees": int(st.get("num_device_free", 0))}
+    except Exception as e:      # diagnostics only
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False, heavy=False):
     """Short timed row of another BASELINE.json configuration on this GPU (1 warm-up + `steps` scenes)."""
     from pasco_amd.graph import fused
@@ -357,7 +371,8 @@ def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False, 
         if unfused:
             fused.set_fusion(True)
             fused.set_conv_precision("f16x3")
-    row = {"scenes_per_s": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": 1}
+    row = {"scenes_per_s": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": 1,
+           "allocator": allocator_state(device)}
     redone = {k: int(getattr(net, k, 0)) for k in ("range_fallbacks", "input_fallbacks", "optimistic_fallbacks") if getattr(net, k, 0)}
     if redone:          # steps that ran twice (a fallback of PascoNet.forward): the row is then not a clean measurement
         row["redone_steps"] = redone
@@ -529,12 +544,14 @@ def main():
     gc_was_on = gc.isenabled()
     if os.environ.get("PASCO_BENCH_GC", "0") != "1":
         gc.disable()
+    alloc_log = {"after_warmup": allocator_state(device)}
     barrier()
     t0 = time.perf_counter()
     marks = [t0]
     last = run_steps(0, args.steps, args.in_flight, window, marks)
     barrier()
     elapsed = time.perf_counter() - t0
+    alloc_log["after_timed_loop"] = allocator_state(device)
     out, panop = last["out"], last["panop"]
     prof.enabled = False
     rounds_ms = []
@@ -558,6 +575,7 @@ def main():
         prof.enabled = False
         one_in_flight = {"value": round(1.0 / dt1, 4), "unit": "scenes/s", "ms_per_step": round(dt1 * 1e3, 3),
                          "steps": args.steps}
+        alloc_log["after_in_flight_1"] = allocator_state(device)
         if window:      # the reference's own timing window (`self.unet3d`, README.md:448-449), one scene at a time
             one_in_flight["unet_window_ms"] = round(sum(a.elapsed_time(b) for a, b in window) / len(window), 3)
     if gc_was_on:
@@ -628,6 +646,7 @@ def main():
                                  "(= Net.forward(return_ensemble=True) + its input stage)",
                        "pruning": "teacher-forced", "parallelism": par},
         }
+        res["allocator"] = alloc_log
         if rounds_ms:
             srt = sorted(rounds_ms)
             res["step_ms_by_round"] = {"group": max(args.in_flight, 1), "median": srt[len(srt) // 2], "min": srt[0], "max": srt[-1],
