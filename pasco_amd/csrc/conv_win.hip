@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t win_hash(uint32_t k) {
 // prefix sums + popcount): no hash probes, no sort.  Wider spans (maps without locality) take the hash set + bitonic sort.
 __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ nbr, int64_t n_out, int32_t *__restrict__ win_rows,
                                                      int32_t *__restrict__ win_cnt, uint16_t *__restrict__ slots,
-                                                     int32_t *__restrict__ stats, int wmax_a, int wmax_b) {
+                                                     int32_t *__restrict__ stats, int wmax_a, int wmax_b, int only_marked) {
   constexpr int HT = 8192;                       // hash slots (>= 2 x WIN_CAP) = bitmap words of the fast path
   constexpr int SPAN_MAX = HT * 32;              // 262 144 indices
   __shared__ int32_t keys[HT];                   // hash keys | bitmap words
@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ n
   const int tid = threadIdx.x;
   const int64_t tile = blockIdx.x;
   const int64_t m0 = tile * WIN_BM;
+  if (only_marked && win_cnt[tile] != -1) return;      // k_win_build_fast served this tile (it marks the others with -1)
   if (tid == 0) {
     count = 0;
     s_min = 0x7FFFFFFF;
@@ -194,6 +195,114 @@ __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ n
   }
 }
 
+// The common case in a kernel of its own (round 3): tiles whose input rows span < 2^17 indices (every tile of the decoder's
+// octree-ordered maps).  Same bitmap rank as above with 24 KB of LDS instead of 63 (six workgroups per CU instead of two: the
+// kernel is bound by the latency of its few dependent phases, not by bytes), the 14 neighbour entries of a thread loaded
+// back to back, the span and the word prefix reduced inside the waves (2 barriers instead of 18).  A wider tile is marked
+// with win_cnt = -1 and left to k_win_build.
+constexpr int WINF_WORDS = 4096;                 // bitmap words: spans below 131 072 indices
+__global__ void __launch_bounds__(256) k_win_build_fast(const int32_t *__restrict__ nbr, int64_t n_out, int32_t *__restrict__ win_rows,
+                                                          int32_t *__restrict__ win_cnt, uint16_t *__restrict__ slots,
+                                                          int32_t *__restrict__ stats, int wmax_a, int wmax_b) {
+  constexpr int PER_T = (WIN_CAP + 255) / 256;   // 14 entries per thread, kept in registers through every phase
+  __shared__ uint32_t bm[WINF_WORDS];
+  __shared__ uint16_t pre[WINF_WORDS];
+  __shared__ int32_t s_min, s_max;
+  __shared__ int32_t wave_sum[4];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int64_t tile = blockIdx.x;
+  const int64_t m0 = tile * WIN_BM;
+  if (tid == 0) {
+    s_min = 0x7FFFFFFF;
+    s_max = -1;
+  }
+  int v[PER_T];
+#pragma unroll
+  for (int i = 0; i < PER_T; ++i) {              // all loads in flight before the first use
+    const int e = tid + 256 * i;
+    const int k = e / WIN_BM, r = e - k * WIN_BM;
+    const int64_t row = m0 + r;
+    v[i] = (e < WIN_CAP && row < n_out) ? nbr[(int64_t)k * n_out + row] : -1;
+  }
+  __syncthreads();
+  int lo = 0x7FFFFFFF, hi = -1;
+#pragma unroll
+  for (int i = 0; i < PER_T; ++i) {
+    if (v[i] >= 0) {
+      lo = v[i] < lo ? v[i] : lo;
+      hi = v[i] > hi ? v[i] : hi;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const int ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
+    lo = ol < lo ? ol : lo;
+    hi = oh > hi ? oh : hi;
+  }
+  if (lane == 0 && hi >= 0) {
+    atomicMin(&s_min, lo);
+    atomicMax(&s_max, hi);
+  }
+  __syncthreads();
+  const int base = s_min, top = s_max;
+  if (top >= 0 && top - base >= WINF_WORDS * 32) {          // uniform: k_win_build takes the tile
+    if (tid == 0) win_cnt[tile] = -1;
+    return;
+  }
+  const int nwords = top < 0 ? 0 : ((top - base) >> 5) + 1;
+  for (int i = tid; i < nwords; i += 256) bm[i] = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PER_T; ++i)
+    if (v[i] >= 0) atomicOr(&bm[(v[i] - base) >> 5], 1u << ((v[i] - base) & 31));
+  __syncthreads();
+  // exclusive prefix of the word popcounts: thread t owns words [t * per, (t + 1) * per); scan inside the wave, then over
+  // the four wave totals
+  const int per = (nwords + 255) / 256;
+  int mine = 0;
+  for (int w = tid * per; w < (tid + 1) * per && w < nwords; ++w) mine += __popc(bm[w]);
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wave_sum[wave] = incl;
+  __syncthreads();
+  int run = incl - mine;
+  for (int w = 0; w < wave; ++w) run += wave_sum[w];
+  const int cnt = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+  int32_t *wr = win_rows + tile * WIN_CAP;
+  uint16_t *sl = slots + tile * WIN_CAP;
+  for (int w = tid * per; w < (tid + 1) * per && w < nwords; ++w) {
+    pre[w] = (uint16_t)run;
+    unsigned bits = bm[w];
+    while (bits) {                                // the distinct rows in ascending order
+      const int b = __ffs(bits) - 1;
+      wr[run++] = base + (w << 5) + b;
+      bits &= bits - 1;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    win_cnt[tile] = cnt;
+    atomicAdd(&stats[0], cnt > 0 ? (cnt + wmax_a - 1) / wmax_a : 1);
+    atomicAdd(&stats[1], cnt > 0 ? (cnt + wmax_b - 1) / wmax_b : 1);
+  }
+#pragma unroll
+  for (int i = 0; i < PER_T; ++i) {
+    const int e = tid + 256 * i;
+    if (e >= WIN_CAP) continue;
+    uint16_t sv = 0xFFFFu;
+    if (v[i] >= 0) {
+      const int off = v[i] - base, w = off >> 5;
+      sv = (uint16_t)(pre[w] + __popc(bm[w] & ((1u << (off & 31)) - 1u)));
+    }
+    sl[e] = sv;
+  }
+}
+
 // window capacities (rows) of the two kernel shapes: 64-wide tiles keep two workgroups per CU, 128-wide one
 constexpr int WIN_MAX_64 = 416;
 constexpr int WIN_MAX_128 = 512;
@@ -207,8 +316,15 @@ extern "C" int ph_win_build(const int32_t *nbr, int32_t kvol, int64_t n_out, int
   const int64_t ntiles = (n_out + WIN_BM - 1) / WIN_BM;
   hipStream_t st = ph_stream(stream);
   PH_CHECK_HIP(hipMemsetAsync(win_stats, 0, 4 * sizeof(int32_t), st));
+  static const bool fast_on = [] { const char *e = getenv("PASCO_WIN_BUILD_FAST"); return e == nullptr || atoi(e) != 0; }();
+  if (fast_on) {
+    hipLaunchKernelGGL(k_win_build_fast, dim3((unsigned)ntiles), dim3(256), 0, st, nbr, n_out, win_rows, win_cnt, win_slots,
+                       win_stats, WIN_MAX_64, WIN_MAX_128);
+    PH_LAUNCH_CHECK();
+  }
+  // every tile (PASCO_WIN_BUILD_FAST=0), or the tiles the fast kernel marked: wide spans, maps without locality
   hipLaunchKernelGGL(k_win_build, dim3((unsigned)ntiles), dim3(256), 0, st, nbr, n_out, win_rows, win_cnt, win_slots,
-                     win_stats, WIN_MAX_64, WIN_MAX_128);
+                     win_stats, WIN_MAX_64, WIN_MAX_128, fast_on ? 1 : 0);
   PH_LAUNCH_CHECK();
   return 0;
 }

@@ -334,9 +334,11 @@ class CBackend:
         dev = nbr.device
         t = (n_out + 127) // 128
         win = {"rows": torch.empty((max(t, 1), 27 * 128), dtype=torch.int32, device=dev),
-               "cnt": torch.zeros(max(t, 1), dtype=torch.int32, device=dev),
+               # cnt: every tile is written by the build; stats: cleared by ph_win_build itself (n_out == 0: nothing to clear)
+               "cnt": torch.empty(max(t, 1), dtype=torch.int32, device=dev) if n_out > 0 else torch.zeros(1, dtype=torch.int32, device=dev),
                "slots": torch.empty((max(t, 1), 27, 128), dtype=torch.int16, device=dev),     # uint16 bit patterns
-               "stats": torch.zeros(4, dtype=torch.int32, device=dev), "n_out": n_out}
+               "stats": torch.empty(4, dtype=torch.int32, device=dev) if n_out > 0 else torch.zeros(4, dtype=torch.int32, device=dev),
+               "n_out": n_out}
         rc = self.fn["win_build"](_ptr(nbr), kvol, n_out, _ptr(win["rows"]), _ptr(win["cnt"]), _ptr(win["slots"]),
                                   _ptr(win["stats"]), self.stream(dev))
         self._check(rc, "win_build")
