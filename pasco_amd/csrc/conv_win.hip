@@ -37,6 +37,21 @@ __device__ __forceinline__ uint32_t win_hash(uint32_t k) {
   return k;
 }
 
+// stats[i] = sum over the tiles of their window passes at capacity i.  Nearly every tile has ONE pass: the "1" of all tiles
+// is added once per launch (by the first workgroup of the kernel that sees every tile) and a tile adds only
+// its EXCESS passes - two same-address atomics per tile were what the 5 334-tile build spent most of its time on.
+__device__ __forceinline__ void win_count_all_tiles(int32_t *stats) {      // thread 0 of workgroup 0, first thing in the kernel
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    atomicAdd(&stats[0], (int)gridDim.x);
+    atomicAdd(&stats[1], (int)gridDim.x);
+  }
+}
+__device__ __forceinline__ void win_count_passes(int32_t *stats, int cnt, int wmax_a, int wmax_b) {
+  const int pa = cnt > 0 ? (cnt + wmax_a - 1) / wmax_a : 1, pb = cnt > 0 ? (cnt + wmax_b - 1) / wmax_b : 1;
+  if (pa > 1) atomicAdd(&stats[0], pa - 1);
+  if (pb > 1) atomicAdd(&stats[1], pb - 1);
+}
+
 // one workgroup per 128-row tile.  Fast path: the tile's input rows span < 2^18 consecutive indices (octree-ordered maps:
 // median span 44 k on the 683 k-row map) -> a bitmap of the span in LDS; the rank of an index = set bits below it (word
 // prefix sums + popcount): no hash probes, no sort.  Wider spans (maps without locality) take the hash set + bitonic sort.
@@ -53,6 +68,7 @@ __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ n
   const int tid = threadIdx.x;
   const int64_t tile = blockIdx.x;
   const int64_t m0 = tile * WIN_BM;
+  if (!only_marked) win_count_all_tiles(stats);
   if (only_marked && win_cnt[tile] != -1) return;      // k_win_build_fast served this tile (it marks the others with -1)
   if (tid == 0) {
     count = 0;
@@ -118,8 +134,7 @@ __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ n
     __syncthreads();
     if (tid == 0) {
       win_cnt[tile] = cnt;
-      atomicAdd(&stats[0], cnt > 0 ? (cnt + wmax_a - 1) / wmax_a : 1);
-      atomicAdd(&stats[1], cnt > 0 ? (cnt + wmax_b - 1) / wmax_b : 1);
+      win_count_passes(stats, cnt, wmax_a, wmax_b);
     }
     for (int e = tid; e < WIN_CAP; e += 256) {
       const int idx = ent[e];
@@ -175,8 +190,7 @@ __global__ void __launch_bounds__(256) k_win_build(const int32_t *__restrict__ n
   for (int i = tid; i < cnt; i += 256) wr[i] = uniq[i];
   if (tid == 0) {
     win_cnt[tile] = cnt;
-    atomicAdd(&stats[0], cnt > 0 ? (cnt + wmax_a - 1) / wmax_a : 1);
-    atomicAdd(&stats[1], cnt > 0 ? (cnt + wmax_b - 1) / wmax_b : 1);
+    win_count_passes(stats, cnt, wmax_a, wmax_b);
   }
   // slot of every (offset, row) entry: rank of its input row in the sorted list
   for (int e = tid; e < WIN_CAP; e += 256) {
@@ -213,6 +227,7 @@ __global__ void __launch_bounds__(256) k_win_build_fast(const int32_t *__restric
   const int lane = tid & 63, wave = tid >> 6;
   const int64_t tile = blockIdx.x;
   const int64_t m0 = tile * WIN_BM;
+  win_count_all_tiles(stats);
   if (tid == 0) {
     s_min = 0x7FFFFFFF;
     s_max = -1;
@@ -287,8 +302,7 @@ __global__ void __launch_bounds__(256) k_win_build_fast(const int32_t *__restric
   __syncthreads();
   if (tid == 0) {
     win_cnt[tile] = cnt;
-    atomicAdd(&stats[0], cnt > 0 ? (cnt + wmax_a - 1) / wmax_a : 1);
-    atomicAdd(&stats[1], cnt > 0 ? (cnt + wmax_b - 1) / wmax_b : 1);
+    win_count_passes(stats, cnt, wmax_a, wmax_b);
   }
 #pragma unroll
   for (int i = 0; i < PER_T; ++i) {
