@@ -459,80 +459,47 @@ def main():
     import gc
     import threading
 
-    streams = [torch.cuda.Stream(device=device) for _ in range(max(args.in_flight, 1))]
-    if args.in_flight > 1:
-        # worker threads hand the interpreter over every 0.5 ms instead of every 5 ms: a scene whose stream has run dry gets
-        # to enqueue sooner (PASCO_BENCH_SWITCH_MS overrides)
-        sys.setswitchinterval(float(os.environ.get("PASCO_BENCH_SWITCH_MS", "0.5")) * 1e-3)
+    from pasco_amd.graph.serve import SceneServer, vet_cached_blocks
+    if heads and world > 1:
+        args.in_flight = 1                  # one communicator: collectives are issued from one thread
+    ctx = {"window": None}
+
+    def one_step(i):
+        """Step i of the loop: scene i mod #scenes through the whole hot path."""
+        j = i % len(scenes)
+        if heads and world > 1:
+            return step_fn(net, scenes[j], teachers[j])
+        return run_scene(net, scenes[j], teachers[j], ctx["window"])
+
+    # worker threads, each bound to its own HIP stream, draw step numbers from a shared counter (pasco_amd/graph/serve.py)
+    server = SceneServer(device, one_step, in_flight=args.in_flight,
+                         switch_interval_ms=float(os.environ.get("PASCO_BENCH_SWITCH_MS", "0.5")))
 
     def run_steps(first, count, in_flight, window=None, marks=None):
-        """Steps first .. first + count - 1 (scene = step mod #scenes).  in_flight == 1: on the current stream, one after the
-        other.  Else: `in_flight` worker threads, each bound to its own stream, draw step numbers from a shared counter;
-        returns after every worker's stream has drained."""
+        """Steps first .. first + count - 1 (scene = step mod #scenes), `in_flight` at a time (1 = on the current stream)."""
+        ctx["window"] = window
         last = {}
-        if in_flight <= 1:
-            with torch.no_grad():
-                for i in range(first, first + count):
-                    j = i % len(scenes)
-                    if heads and world > 1:
-                        last["out"], last["panop"] = step_fn(net, scenes[j], teachers[j])
-                    else:
-                        last["out"], last["panop"] = run_scene(net, scenes[j], teachers[j], window)
-                    if marks is not None:
-                        marks.append(time.perf_counter())
-            return last
-        lock = threading.Lock()
-        state = {"next": first}
-        errors = []
 
-        def worker(w):
-            try:
-                torch.cuda.set_device(device)
-                with torch.cuda.stream(streams[w]), torch.no_grad():
-                    while True:
-                        with lock:
-                            i = state["next"]
-                            state["next"] += 1
-                        if i >= first + count:
-                            break
-                        j = i % len(scenes)
-                        if heads and world > 1:
-                            o = step_fn(net, scenes[j], teachers[j])
-                        else:
-                            o = run_scene(net, scenes[j], teachers[j], window)
-                        with lock:
-                            last["out"], last["panop"] = o
-                            if marks is not None:
-                                marks.append(time.perf_counter())
-                streams[w].synchronize()
-            except BaseException as e:      # surface worker failures in the main thread
-                errors.append(e)
+        def done(i, o):
+            last["out"], last["panop"] = o
+            if marks is not None:
+                marks.append(time.perf_counter())
 
-        threads = [threading.Thread(target=worker, args=(w,)) for w in range(in_flight)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
+        server.run(range(first, first + count), in_flight=in_flight, on_done=done)
         return last
 
-    for s_ in streams:                      # the scenes / weights were uploaded on the default stream
-        s_.wait_stream(torch.cuda.current_stream(device))
-    # warm-up: every scene once on the main stream (kernel maps' shapes, operand caches), then on the worker streams
-    # (their query-side graphs and scratch buffers)
-    last = run_steps(0, args.warmup, 1)
-    if args.in_flight > 1:
-        for s_ in streams[:args.in_flight]:          # one stream at a time: graph captures do not overlap other launches
-            with torch.cuda.stream(s_):
-                run_steps(0, max(args.warmup, len(scenes)), 1)
-            s_.synchronize()
-        run_steps(0, 2 * args.in_flight, args.in_flight)
+    # warm-up (untimed): at least --warmup steps and every scene once on the main stream, every scene on every worker stream,
+    # then the in-flight loop until the caching allocator has stopped growing; then every large cached block is write-tested
+    last = run_steps(0, max(args.warmup, len(scenes)), 1)
+    warm_info = server.warm(range(len(scenes)))
+    vet = None
+    if os.environ.get("PASCO_BENCH_VET", "1") != "0":
+        vet = vet_cached_blocks(device, [torch.cuda.current_stream(device)] + server.streams)
+        if vet.get("replaced"):              # replacements are new blocks: let the pools settle again
+            warm_info["after_vet"] = server.warm(range(len(scenes)), max_rounds=3)
     out = last["out"]
     n1 = int(out["sem_logits_at_scales"][1][0].F.shape[0])
     window = []
-    if heads and world > 1:
-        args.in_flight = 1                  # one communicator: collectives are issued from one thread
     # per-launch HIP events only mean something when one scene runs at a time (kernels of two streams share the GPU):
     # with several scenes in flight the roofline comes from the one-at-a-time pass below
     prof.enabled = (not args.no_profile) and args.in_flight <= 1
@@ -554,15 +521,18 @@ def main():
     alloc_log["after_timed_loop"] = allocator_state(device)
     out, panop = last["out"], last["panop"]
     prof.enabled = False
-    rounds_ms = []
+    # the timed steps in groups of `in_flight` completions: a box that goes through a slow period (seen in rounds 2 - 3:
+    # the HBM-bound launches 6 x slower for ~0.3 s, then normal again) shows here, not only in the mean
+    g = max(args.in_flight, 1)
+    rounds_ms = [round((marks[min(i + g, len(marks) - 1)] - marks[i]) * 1e3 / (min(i + g, len(marks) - 1) - i), 2)
+                 for i in range(0, len(marks) - 1, g)]
+    per_rank_rounds = None
+    if world > 1:                           # every rank's rounds: a sub-linear curve can then be attributed to a rank / a period
+        per_rank_rounds = [None] * world
+        dist.all_gather_object(per_rank_rounds, rounds_ms)
     if rank == 0:
         per = [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])]
         print(f"[bench] per-step host ms: {per}", file=sys.stderr, flush=True)
-        # the timed steps in groups of `in_flight` completions: a box that goes through a slow period (seen twice this round:
-        # the HBM-bound launches 6 x slower for ~0.3 s, then normal again) shows here, not only in the mean
-        g = max(args.in_flight, 1)
-        rounds_ms = [round((marks[min(i + g, len(marks) - 1)] - marks[i]) * 1e3 / (min(i + g, len(marks) - 1) - i), 2)
-                     for i in range(0, len(marks) - 1, g)]
     one_in_flight = None
     if args.in_flight > 1 and world == 1:          # the same K steps, one scene at a time on one stream
         window = []
@@ -647,12 +617,19 @@ def main():
                        "pruning": "teacher-forced", "parallelism": par},
         }
         res["allocator"] = alloc_log
+        res["allocator"]["device_mallocs_in_timed_loop"] = (alloc_log["after_timed_loop"].get("device_mallocs", 0) -
+                                                            alloc_log["after_warmup"].get("device_mallocs", 0))
+        res["warmup_detail"] = warm_info
+        if vet is not None:
+            res["memory_vet"] = vet
         if rounds_ms:
             srt = sorted(rounds_ms)
             res["step_ms_by_round"] = {"group": max(args.in_flight, 1), "median": srt[len(srt) // 2], "min": srt[0], "max": srt[-1],
                                        "rounds": rounds_ms,
                                        "note": "ms per step over each group of `group` consecutive completions of the timed loop "
                                                "(value / ms_per_step are the mean over all of them)"}
+            if per_rank_rounds is not None:
+                res["step_ms_by_round"]["per_rank_rounds"] = per_rank_rounds
         if heads:
             res["bound_note"] = ("trunk replicated on every rank: speed-up over 1 GPU is bounded by (T + 8 H) / (T + H) "
                                  "~ 2.2x at S10 (T ~ 2.1 TFLOP trunk, H ~ 0.43 TFLOP per subnet head; SURVEY.md 8(e))")

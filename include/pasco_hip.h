@@ -367,6 +367,30 @@ int PH_FN(attn_cross_split)(const float *q, const void *k_split, const void *v_s
                             const uint32_t *bits, const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h,
                             int32_t qn, int32_t dh, void *ws, int64_t ws_bytes, int32_t *status, ph_stream_t stream);
 
+/* The same attention straight on a level's FEATURE operand: the keys and values of a cross-attention level are
+ * K = x A + a + pos W_k^T and V = x B + b + pos W_v^T (input projection and K / V projection composed; reference
+ * transformer_predictor_v2.py:150,167-173 + transformer/blocks.py:83-86, key = value = bb_feat + pos), so per head
+ * q_h K_h^T = (q_h A_h^T) x^T + const + position terms and P V_h = (P x) B_h + b_h + P (position terms): both products run
+ * on the rows [x | aug] and K / V are never formed (at the finest level of the benchmark scene: 2 x 970 MB less written
+ * and read, two projection launches less).
+ *   x_split [B*N, c/32, 2, 32] f16: the level's features as a split operand (value * 2^exp2; ph_split_rows)
+ *   aug     [B*N, 16] f16          : position columns of every key (pos_aug below), unscaled
+ *   q2      [B, H, Qn, c + 16]     : per head q_h [A_h^T | position coefficients] (host), 1/sqrt(Dh) included
+ *   out     [B, Qn, H * (c + 16)]  : Y = softmax(q2 [x | aug]^T + mask) [x | aug]; the caller applies (B_h ; position rows)
+ *                                    and the constants (folded into the output projection)
+ * The HIP library serves c = 64; bits / any / status as attn_cross_split; workspace = attn_workspace_bytes(.., dh = c + 16).
+ *
+ * pos_aug: aug[i] = ([c_x == 0], [c_y == 0], [c_z == 0], eps[c_x - tab_lo], eps[c_y - tab_lo], eps[c_z - tab_lo], 0 x 10)
+ * for coords [N, 4] (b, x, y, z).  The sine encoding normalises c / (c + 1e-6) * 2 pi (position_encoding.py:100-104): the
+ * angle is 0 for c = 0, exactly 2 pi for |c| >= 32 and 2 pi + eps_c in between, which is all a key's position term depends
+ * on (eps [tab_n] fp32 in the caller's scale, eps of the value 0 = 0).  A coordinate outside the table raises status bit 2. */
+int PH_FN(attn_cross_feat)(const float *q2, const void *x_split, const void *aug, int32_t c, int32_t exp2,
+                           const uint32_t *bits, const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h,
+                           int32_t qn, void *ws, int64_t ws_bytes, int32_t *status, ph_stream_t stream);
+
+int PH_FN(pos_aug)(const int32_t *coords, int64_t n, const float *eps, int32_t tab_lo, int32_t tab_n, void *aug,
+                   int32_t *status, ph_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Panoptic ensembling on the compacted union of occupied canonical sites (reference: pasco/models/ensembler.py:20-131,
  * which works on dense [100, 256, 256, 32] tensors per subnet).  sel [U] = canonical site id of every union row.

@@ -821,6 +821,83 @@ int pho_attn_cross_split(const float *q, const void *k_split, const void *v_spli
   return rc;
 }
 
+/* Attention on the level's feature operand (include/pasco_hip.h attn_cross_feat; reference transformer/blocks.py:83-92 with
+ * key = value = bb_feat + pos, transformer_predictor_v2.py:150,167-173): rows r = [x | aug] (x = hi + lo of the split operand
+ * times 2^-exp2, aug as stored), scores q2 . r, masked softmax over the keys, out = sum_keys p r.  Plain two-pass fp32. */
+static float f16_to_f32_at(const void *p, int64_t i) { return f16_bits_to_f32(((const uint16_t *)p)[i]); }
+
+int pho_attn_cross_feat(const float *q2, const void *x_split, const void *aug, int32_t c, int32_t exp2, const uint32_t *bits,
+                        const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h, int32_t qn, void *ws,
+                        int64_t ws_bytes, int32_t *status, ph_stream_t stream) {
+  (void)ws; (void)ws_bytes; (void)status; (void)stream;
+  if (c < 32 || c % 32 != 0) return fail("attn_cross_feat: channels must be a multiple of 32");
+  if (qn < 1 || qn > 128 || b < 1 || h < 1 || n < 1) return fail("attn_cross_feat: bad shape");
+  const int d = c + 16;
+  float *x = unsplit_rows(x_split, (int64_t)b * n, c, ldexpf(1.f, -exp2));
+  if (!x) return fail("attn_cross_feat: out of memory");
+#pragma omp parallel for collapse(2) schedule(dynamic)
+  for (int bi = 0; bi < b; ++bi)
+    for (int task = 0; task < h * qn; ++task) {
+      const int hi = task / qn, qi = task % qn;
+      const float *qv = q2 + (((int64_t)bi * h + hi) * qn + qi) * d;
+      int force = bits == NULL;
+      if (bits && any) force = !((any[bi * 4 + (qi >> 5)] >> (qi & 31)) & 1u);
+      float *sc = (float *)malloc(sizeof(float) * (size_t)n);
+      float mx = -INFINITY;
+      for (int64_t j = 0; j < n; ++j) {
+        const int64_t row = (int64_t)bi * n + j;
+        int ok = force || ((bits[row * 4 + (qi >> 5)] >> (qi & 31)) & 1u);
+        float s = -INFINITY;
+        if (ok) {
+          s = 0.f;
+          for (int ch = 0; ch < c; ++ch) s += qv[ch] * x[row * c + ch];
+          for (int ch = 0; ch < 16; ++ch) s += qv[c + ch] * f16_to_f32_at(aug, row * 16 + ch);
+        }
+        sc[j] = s;
+        if (s > mx) mx = s;
+      }
+      float *o = out + ((int64_t)bi * qn + qi) * ((int64_t)h * d) + (int64_t)hi * d;
+      for (int ch = 0; ch < d; ++ch) o[ch] = 0.f;
+      float l = 0.f;
+      if (mx > -INFINITY) {
+        for (int64_t j = 0; j < n; ++j) {
+          if (sc[j] == -INFINITY) continue;
+          const int64_t row = (int64_t)bi * n + j;
+          const float p = expf(sc[j] - mx);
+          l += p;
+          for (int ch = 0; ch < c; ++ch) o[ch] += p * x[row * c + ch];
+          for (int ch = 0; ch < 16; ++ch) o[c + ch] += p * f16_to_f32_at(aug, row * 16 + ch);
+        }
+        for (int ch = 0; ch < d; ++ch) o[ch] /= l;
+      }
+      free(sc);
+    }
+  free(x);
+  return 0;
+}
+
+
+int pho_pos_aug(const int32_t *coords, int64_t n, const float *eps, int32_t tab_lo, int32_t tab_n, void *aug, int32_t *status,
+                ph_stream_t stream) {
+  (void)stream;
+  if (n < 0 || tab_n < 1) return fail("pos_aug: bad shape");
+  uint16_t *o = (uint16_t *)aug;
+  for (int64_t i = 0; i < n; ++i) {
+    for (int k = 0; k < 16; ++k) o[i * 16 + k] = 0;
+    for (int ax = 0; ax < 3; ++ax) {
+      const int v = coords[i * 4 + 1 + ax];
+      int64_t t = (int64_t)v - tab_lo;
+      if (t < 0 || t >= tab_n) {
+        if (status) *status |= 4;
+        t = t < 0 ? 0 : tab_n - 1;
+      }
+      o[i * 16 + ax] = f32_to_f16_bits(v == 0 ? 1.f : 0.f);
+      o[i * 16 + 3 + ax] = f32_to_f16_bits(eps[t]);
+    }
+  }
+  return 0;
+}
+
 int pho_bits_orpool(const uint32_t *bits_in, const int32_t *nbr, int32_t kvol, int64_t n_out, uint32_t *bits_out,
                     ph_stream_t stream) {
   (void)stream;

@@ -604,6 +604,396 @@ __global__ void __launch_bounds__(256) k_attn_split(AttnSplitArgs s) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention straight on a level's FEATURE operand (ph_attn_cross_feat): K and V are never formed.
+//
+// A level's keys and values are K = x A + a + pos W_k^T, V = x B + b + pos W_v^T with x the level's C = 64 feature channels
+// (input projection and K / V projection composed, CrossAttentionLayer.composed_kv).  Per head h
+//     S = q_h K_h^T = (q_h A_h^T) x^T + [constant over the keys: drops out of the softmax] + q_h . (pos terms)
+//     O_h = P V_h   = (P x) B_h + b_h + P . (pos terms)
+// and the position term of a key depends on its three integer coordinates only, through the rows tab[t] of the sine table.
+// The reference's encoding normalises c / (c + 1e-6) * 2 pi (position_encoding.py:100-104), so tab[t] takes three kinds of
+// values: tab[0], the far value tab[inf] (every |t| >= 32: the ratio is exactly 1 in fp32), and tab[inf] + eps_t G for the
+// handful of small |t| (eps_t = the fp32 angle's offset from 2 pi, G = d tab / d angle; the second-order term is < 1e-10).
+// So a key carries, next to its 64 channels, 16 POSITION COLUMNS (ph_pos_aug): [c_a == 0] and eps_{c_a} for the three axes,
+// and both products run on the 80-column row [x | aug]:
+//     S^T[32 keys x 32 q]   = [x | aug] Q2^T           Q2 = q_h [A_h^T | D0 | G | 0]   (host, [Q, 80] per (subnet, head))
+//     Y^T[80 x 32 q]       += [x | aug]^T P             O_h = Y (B_h ; D0v ; Gv) + const (host, folded into out_proj)
+// ONE operand tile per 32 keys (8 KB + 1 KB) serves every head and both products; the 2 x 970 MB K / V operands of the
+// finest level (written once, read once) and their two projection launches are gone.
+//
+// LDS tile: nine 1 KB blocks (chunk of 16 channels, plane hi / lo; the position block has no lo plane) of 64 sixteen-byte
+// granules (key, half).  Granule position  pos = half * 32 + (key & 16) + (((key & 15) ^ (half << 2)) ^ ((chunk & 1) << 3)):
+// the key-row reads of the S product (ds_read_b128, lane = (key, half)) and the TRANSPOSED reads of the Y product
+// (ds_read_b64_tr_b16: a group of 16 lanes reads [4 keys x 16 channels], two groups per pass take the two chunks of a
+// 32-channel tile) are both bank-conflict free on the same copy.  LDS-DMA writes a block lane-linearly, so the permutation
+// lives in the global address each lane loads.
+struct AttnFeatArgs {
+  AttnArgs a;                 // q = Q2 [B, H, Qn, 80]; out [B, Qn, H * 80]; k / v unused
+  const _Float16 *xs;         // split feature operand [B*N, 2, 2, 32]
+  const _Float16 *aug;        // position columns [B*N, 16]
+  float kv_unscale;           // 2^-exp2 of the feature operand
+  float aug_scale;            // 2^exp2: the position columns are stored unscaled, their Q2 columns carry the operand's scale
+  int *status;
+  int groups;                 // B * splits
+};
+
+constexpr int AF_D = 80;                      // columns of a key row: 64 channels + 16 position columns
+constexpr int AF_X_BYTES = 8 * 1024;
+constexpr int AF_A_BYTES = 1024;
+constexpr int AF_M_BYTES = 4 * 32 * 4;
+constexpr int AF_STAGE = AF_X_BYTES + AF_A_BYTES + AF_M_BYTES;
+constexpr int AF_STAGES = 3;
+
+template <bool MASK>
+__global__ void __launch_bounds__(256, 2) k_attn_feat(AttnFeatArgs s) {
+  const AttnArgs &a = s.a;
+  __shared__ __attribute__((aligned(16))) char lds[AF_STAGE * AF_STAGES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, h2 = lane >> 5;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int group = (j / a.H) * 8 + xcd, h = j % a.H;
+  if (group >= s.groups) return;
+  const int b = group / a.splits, split = group - b * a.splits;
+  const int64_t ntile_all = (a.n + AS_KT - 1) / AS_KT;
+  const int64_t t0 = (int64_t)split * a.tiles_per_wave;
+  int64_t t1 = t0 + a.tiles_per_wave;
+  if (t1 > ntile_all) t1 = ntile_all;
+  const int ntile = (int)(t1 - t0);
+
+  // ---- DMA plan: blocks e = 0 .. 7 = (chunk e >> 1, plane e & 1) of the feature operand, e = 8 the position block; wave w
+  // carries blocks w and w + 4, wave 2 the position block, waves 0 and 1 the mask words (one 4-byte instruction each) ------
+  const int dh2 = lane >> 5;                                     // half of the granule this lane carries
+  int d_key[2], d_off[2];
+  const char *xbase = (const char *)s.xs + (int64_t)b * a.n * 256;
+  const char *abase = (const char *)s.aug + (int64_t)b * a.n * 32;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = wave + 4 * k, cc = e >> 1, plane = e & 1;
+    d_key[k] = (lane & 16) | (((lane & 15) ^ (dh2 << 2)) ^ ((cc & 1) << 3));
+    d_off[k] = (cc >> 1) * 128 + plane * 64 + (cc & 1) * 32 + dh2 * 16;
+  }
+  const int a_key = (lane & 16) | ((lane & 15) ^ (dh2 << 2));   // position block: chunk 4 (even)
+  const bool mask_wave = MASK && wave < 2;
+  const bool aug_wave = wave == 2;
+  const char *mbase = MASK ? (const char *)a.bits + (int64_t)b * a.n * 16 + (2 * wave + h2) * 4 : nullptr;
+  const int per_tile = wave == 3 ? 2 : ((mask_wave || aug_wave) ? 3 : 2);
+
+  auto fire_x = [&](int tile_local, int k) {
+    const int64_t nb = (t0 + tile_local) * AS_KT;
+    char *st = lds + (tile_local % AF_STAGES) * AF_STAGE;
+    int64_t key = nb + d_key[k];
+    if (key >= a.n) key = a.n - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(xbase + key * 256 + d_off[k]),
+                                     (__attribute__((address_space(3))) void *)(st + (wave + 4 * k) * 1024), 16, 0, 0);
+  };
+  auto fire_third = [&](int tile_local) {
+    const int64_t nb = (t0 + tile_local) * AS_KT;
+    char *st = lds + (tile_local % AF_STAGES) * AF_STAGE;
+    if (aug_wave) {
+      int64_t key = nb + a_key;
+      if (key >= a.n) key = a.n - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(abase + key * 32 + dh2 * 16),
+                                       (__attribute__((address_space(3))) void *)(st + AF_X_BYTES), 16, 0, 0);
+    } else if (mask_wave) {
+      int64_t key = nb + l31;
+      if (key >= a.n) key = a.n - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(mbase + key * 16),
+                                       (__attribute__((address_space(3))) void *)(st + AF_X_BYTES + AF_A_BYTES + wave * 256), 4, 0, 0);
+    }
+  };
+  auto fire = [&](int tile_local) {
+    fire_x(tile_local, 0);
+    fire_x(tile_local, 1);
+    fire_third(tile_local);
+  };
+
+  // ---- Q2 fragments of this wave's query tile: B[k = column][n = q]: lane (q = l31, columns 8 h2 .. + 7 of chunk c) ------
+  const int qt = wave;
+  const int qq = qt * 32 + l31;
+  const bool qv = qq < a.Qn;
+  const bool wave_live = qt * 32 < a.Qn;
+  h16x8 qh[5], ql[5];
+  bool qbad = false;
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    float v8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v8[i] = 0.f;
+    if (qv) {
+      const float *src = a.q + (((int64_t)b * a.H + h) * a.Qn + qq) * AF_D + 16 * c + 8 * h2;
+      const float4 x0 = *reinterpret_cast<const float4 *>(src), x1 = *reinterpret_cast<const float4 *>(src + 4);
+      v8[0] = x0.x; v8[1] = x0.y; v8[2] = x0.z; v8[3] = x0.w; v8[4] = x1.x; v8[5] = x1.y; v8[6] = x1.z; v8[7] = x1.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float t = v8[i] * (c == 4 ? AS_QSCALE * s.aug_scale : AS_QSCALE);
+      qbad |= !(fabsf(t) <= 65504.f);
+      const _Float16 th = (_Float16)t;
+      qh[c][i] = th;
+      ql[c][i] = (_Float16)(t - (float)th);
+    }
+  }
+  if (s.status != nullptr && qbad) atomicOr(s.status, 1);
+  unsigned force = 1u;
+  if (MASK) {
+    force = 0u;
+    if (a.any != nullptr && qv) force = ((a.any[b * 4 + qt] >> l31) & 1u) ? 0u : 1u;
+  }
+  const float s_unscale = s.kv_unscale * (1.f / AS_QSCALE) * 1.4426950408889634f;
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 oacc[3];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) oacc[0][i] = oacc[1][i] = oacc[2][i] = 0.f;
+
+  // ---- fragment read addresses (LDS byte addresses within stage 0) -------------------------------------------------------
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+  // key rows: granule (key = l31, half = h2) of block (chunk, plane): + (chunk * 2 + plane) * 1024, ^ 128 for odd chunks
+  const uint32_t k_rd = lds0 + (uint32_t)((h2 * 32 + (l31 & 16) + ((l31 & 15) ^ (h2 << 2))) * 16);
+  // transposed reads: the lane's group of 16 is (h2, dsel); lane (rr = key in quad, jp = 8-byte piece) -> granule
+  // (key 16 kc + 8 r + 4 h2 + rr, half jp >> 1) of chunk cc = 2 mt + dsel (position tile: chunk 4 | a finite stand-in)
+  const int i16 = lane & 15, dsel = (lane >> 4) & 1, rr = i16 >> 2, jp = i16 & 3, hq = jp >> 1;
+  uint32_t v_rd[3][2];                        // [dim tile][r]: + plane * 1024 + kc * 256
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt) {
+    const int cc = mt < 2 ? 2 * mt + dsel : (dsel ? 3 : 4);
+    const int par = cc & 1;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      v_rd[mt][r] = lds0 + (uint32_t)(cc * 2048 + (hq * 32 + 8 * (r ^ par) + 4 * (h2 ^ hq) + rr) * 16 + (jp & 1) * 8);
+  }
+  const uint32_t m_rd = lds0 + AF_X_BYTES + AF_A_BYTES + (qt * 32 + 4 * h2) * 4;   // + 32 g
+  const unsigned lanebit = 1u << l31;
+
+  if (ntile > 0) fire(0);
+  if (ntile > 1) fire(1);
+  for (int t = 0; t < ntile; ++t) {
+    if (t + 1 < ntile) {
+      if (per_tile == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const bool pre = t + 2 < ntile;
+    if (pre && !wave_live) fire(t + 2);          // idle query tiles still carry their share of the DMA
+    if (!wave_live) continue;
+    const uint32_t so = (uint32_t)((t % AF_STAGES) * AF_STAGE);
+    const int64_t nb = (t0 + t) * AS_KT;
+    const int nvalid = a.n - nb < AS_KT ? (int)(a.n - nb) : AS_KT;
+
+    // ---- S^T = [x | aug] Q2^T ------------------------------------------------------------------------------------------
+    h16x8 kh[4], kl[4], ka;
+    u32x4 mw[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t ad = so + (k_rd ^ (uint32_t)((c & 1) << 7)) + (uint32_t)(c * 2048);
+      kh[c] = as_rd128(ad);
+      kl[c] = as_rd128(ad + 1024);
+    }
+    ka = as_rd128(so + k_rd + 8 * 1024);
+    if (MASK) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) mw[g] = as_rd128u(so + m_rd + 32 * g);
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(kh[0]), "+v"(kh[1]), "+v"(kh[2]), "+v"(kh[3]), "+v"(kl[0]), "+v"(kl[1]), "+v"(kl[2]), "+v"(kl[3]),
+                     "+v"(ka), "+v"(mw[0]), "+v"(mw[1]), "+v"(mw[2]), "+v"(mw[3])::"memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(kh[0]), "+v"(kh[1]), "+v"(kh[2]), "+v"(kh[3]), "+v"(kl[0]), "+v"(kl[1]), "+v"(kl[2]), "+v"(kl[3]),
+                     "+v"(ka)::"memory");
+    }
+    // [x | aug]^T fragments of the whole tile: in flight under the score MFMAs and the softmax
+    s16x4 vt[2][2][2][2];                        // [dim tile][key chunk][plane][r]
+    s16x4 va[2][2];                              // position tile: [key chunk][r]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int plane = 0; plane < 2; ++plane)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) vt[mt][kc][plane][r] = as_rdtr(so + v_rd[mt][r] + (uint32_t)(plane * 1024 + kc * 256));
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) va[kc][r] = as_rdtr(so + v_rd[2][r] + (uint32_t)(kc * 256));
+    f32x16 sacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (pre) {
+        if (c < 2) fire_x(t + 2, c);
+        else if (c == 2) fire_third(t + 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[c], qh[c], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[c], ql[c], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[c], qh[c], sacc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qh[4], sacc, 0, 0, 0);
+    sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, ql[4], sacc, 0, 0, 0);
+    // ---- mask + online softmax (as k_attn_split) -----------------------------------------------------------------------
+    float sv[16];
+    float tmax = -INFINITY;
+    if (nvalid == AS_KT) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const unsigned wr[4] = {mw[g][0], mw[g][1], mw[g][2], mw[g][3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned keep = MASK ? ((wr[r] & lanebit) | force) : 1u;
+          const float x = keep ? sacc[4 * g + r] : -INFINITY;
+          sv[4 * g + r] = x;
+          tmax = fmaxf(tmax, x);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const unsigned wr[4] = {mw[g][0], mw[g][1], mw[g][2], mw[g][3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          bool ok = 8 * g + r + 4 * h2 < nvalid;
+          if (MASK) ok = ok && (force || (wr[r] & lanebit));
+          const float x = ok ? sacc[4 * g + r] : -INFINITY;
+          sv[4 * g + r] = x;
+          tmax = fmaxf(tmax, x);
+        }
+      }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_safe) * s_unscale);
+    m_run = m_new;
+    const float e_off = 12.f - m_safe * s_unscale;
+    h16x8 ph[2], pl[2];
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[i], s_unscale, e_off));
+      psum += p;
+      const _Float16 th = (_Float16)p;
+      ph[i >> 3][i & 7] = th;
+      pl[i >> 3][i & 7] = (_Float16)(p - (float)th);
+    }
+    l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.f)) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        oacc[0][i] *= alpha;
+        oacc[1][i] *= alpha;
+        oacc[2][i] *= alpha;
+      }
+    }
+    // ---- Y^T += [x | aug]^T P ------------------------------------------------------------------------------------------
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vt[0][0][0][0]), "+v"(vt[0][0][0][1]), "+v"(vt[0][0][1][0]), "+v"(vt[0][0][1][1]), "+v"(vt[0][1][0][0]),
+                   "+v"(vt[0][1][0][1]), "+v"(vt[0][1][1][0]), "+v"(vt[0][1][1][1]), "+v"(vt[1][0][0][0]), "+v"(vt[1][0][0][1]),
+                   "+v"(vt[1][0][1][0]), "+v"(vt[1][0][1][1]), "+v"(vt[1][1][0][0]), "+v"(vt[1][1][0][1]), "+v"(vt[1][1][1][0]),
+                   "+v"(vt[1][1][1][1]), "+v"(va[0][0]), "+v"(va[0][1]), "+v"(va[1][0]), "+v"(va[1][1])::"memory");
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        h16x8 vh, vl;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const h16x4 yh = __builtin_bit_cast(h16x4, vt[mt][kc][0][r]);
+          const h16x4 yl = __builtin_bit_cast(h16x4, vt[mt][kc][1][r]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vh[4 * r + e] = yh[e];
+            vl[4 * r + e] = yl[e];
+          }
+        }
+        oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[kc], oacc[mt], 0, 0, 0);
+        oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kc], oacc[mt], 0, 0, 0);
+        oacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[kc], oacc[mt], 0, 0, 0);
+      }
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      h16x8 vh;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const h16x4 yh = __builtin_bit_cast(h16x4, va[kc][r]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vh[4 * r + e] = yh[e];
+      }
+      oacc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[kc], oacc[2], 0, 0, 0);
+      oacc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kc], oacc[2], 0, 0, 0);
+    }
+  }
+
+  // ---- partial record of this (b, h, range): per query Y[80], m, l (k_attn_merge's format) -------------------------------
+  if (!wave_live) return;
+  const int64_t w = ((int64_t)b * a.H + h) * a.splits + split;
+  float *row = a.part + (w * a.qp + qq) * (AF_D + 4);
+  float lt = l_run + __shfl_xor(l_run, 32);
+  if (h2 == 0) {
+    row[AF_D] = m_run * s_unscale * 0.6931471805599453f;
+    row[AF_D + 1] = lt;
+  }
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = 32 * mt + 8 * g + 4 * h2;
+      if (d >= AF_D) continue;
+      // the position columns were written unscaled (ph_pos_aug): only the feature columns carry the operand's 2^exp2
+      const float us = mt < 2 ? s.kv_unscale : 1.f;
+      *reinterpret_cast<float4 *>(row + d) = make_float4(oacc[mt][4 * g] * us, oacc[mt][4 * g + 1] * us, oacc[mt][4 * g + 2] * us,
+                                                         oacc[mt][4 * g + 3] * us);
+    }
+}
+
+// Position columns of the keys (see k_attn_feat): aug[i] = [c_x == 0, c_y == 0, c_z == 0, eps[c_x], eps[c_y], eps[c_z], 0 ...]
+// as f16; eps [tab_n] (fp32, already in the caller's scale; eps of the value 0 must be 0) serves the coordinate values
+// tab_lo .. tab_lo + tab_n - 1; a coordinate outside raises status bit 2 (as the per-axis tables of ph_conv_desc do).
+__global__ void __launch_bounds__(256)
+    k_pos_aug(const int4 *__restrict__ coords, int64_t n, const float *__restrict__ eps, int tab_lo, int tab_n,
+              uint4 *__restrict__ aug, int *__restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = coords[i];
+  const int v[3] = {c.y, c.z, c.w};
+  _Float16 o[6];
+  bool bad = false;
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    unsigned t = (unsigned)(v[ax] - tab_lo);
+    if (t >= (unsigned)tab_n) {
+      bad = true;
+      t = t > 0x7fffffffu ? 0u : (unsigned)(tab_n - 1);
+    }
+    o[ax] = (_Float16)(v[ax] == 0 ? 1.f : 0.f);
+    o[3 + ax] = (_Float16)eps[t];
+  }
+  if (bad && status != nullptr) atomicOr(status, 4);
+  uint4 w0;
+  w0.x = (uint32_t)__builtin_bit_cast(uint16_t, o[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[1]) << 16);
+  w0.y = (uint32_t)__builtin_bit_cast(uint16_t, o[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[3]) << 16);
+  w0.z = (uint32_t)__builtin_bit_cast(uint16_t, o[4]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[5]) << 16);
+  w0.w = 0u;
+  aug[2 * i] = w0;
+  aug[2 * i + 1] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+extern "C" int ph_pos_aug(const int32_t *coords, int64_t n, const float *eps, int32_t tab_lo, int32_t tab_n, void *aug,
+                          int32_t *status, ph_stream_t stream) {
+  PH_REQUIRE(n >= 0 && tab_n >= 1, "pos_aug: bad shape");
+  if (n == 0) return 0;
+  PH_REQUIRE(coords && eps && aug, "pos_aug: null buffer");
+  hipLaunchKernelGGL(k_pos_aug, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ph_stream(stream), (const int4 *)coords, n, eps,
+                     tab_lo, tab_n, (uint4 *)aug, status);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
 // vals [R, Qn] -> bits [R, 4] ; any[b, 4] |= bits (R = B * N, b = row / N).  One wave64 per row: two
 // coalesced 256-byte loads, two ballots.
 __global__ void __launch_bounds__(256)
@@ -823,6 +1213,45 @@ extern "C" int ph_attn_cross_split(const float *q, const void *k_split, const vo
   else hipLaunchKernelGGL((k_attn_split<false, true>), grid, dim3(256), 0, st, s);
   PH_LAUNCH_CHECK();
   hipLaunchKernelGGL((k_attn_merge<4, 3>), dim3(bh, (qn + 15) / 16), dim3(256), 0, st, a);
+  PH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ph_attn_cross_feat(const float *q2, const void *x_split, const void *aug, int32_t c, int32_t exp2,
+                                  const uint32_t *bits, const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h,
+                                  int32_t qn, void *ws, int64_t ws_bytes, int32_t *status, ph_stream_t stream) {
+  PH_REQUIRE(q2 && x_split && aug && out, "attn_cross_feat: null tensor");
+  PH_REQUIRE(c == 64, "attn_cross_feat: %d feature channels not served (64)", c);
+  PH_REQUIRE(qn >= 1 && qn <= 128, "attn_cross_feat: %d queries not served (1..128)", qn);
+  PH_REQUIRE(b >= 1 && h >= 1 && n >= 1, "attn_cross_feat: bad shape");
+  PH_REQUIRE(exp2 >= -14 && exp2 <= 14, "attn_cross_feat: operand exponent %d", exp2);
+  PH_REQUIRE(ws_bytes >= ph_attn_workspace_bytes(n, b, h, qn, AF_D), "attn_cross_feat: workspace too small");
+  AttnFeatArgs s;
+  AttnArgs &a = s.a;
+  a.q = q2; a.k = nullptr; a.v = nullptr; a.bits = bits; a.any = any; a.part = (float *)ws; a.out = out;
+  a.n = n; a.B = b; a.H = h; a.Qn = qn; a.Dh = AF_D;
+  s.xs = (const _Float16 *)x_split; s.aug = (const _Float16 *)aug;
+  s.kv_unscale = ldexpf(1.f, -exp2);
+  s.aug_scale = ldexpf(1.f, exp2);
+  s.status = status;
+  const int64_t ntile = (n + AS_KT - 1) / AS_KT;
+  const int bh = b * h;
+  int64_t splits = 2048 / bh;      // at most the 2048 + 4 b h partial records the workspace holds
+  if (splits < 1) splits = 1;
+  if (splits > ntile) splits = ntile;
+  int64_t tpw = (ntile + splits - 1) / splits;
+  splits = (ntile + tpw - 1) / tpw;
+  a.splits = (int)splits;
+  a.tiles_per_wave = (int)tpw;
+  a.qp = qn <= 64 ? 64 : 128;
+  s.groups = b * (int)splits;
+  hipStream_t st = ph_stream(stream);
+  const int64_t groups8 = ((int64_t)s.groups + 7) / 8;
+  const dim3 grid((unsigned)(groups8 * h * 8));
+  if (bits != nullptr) hipLaunchKernelGGL((k_attn_feat<true>), grid, dim3(256), 0, st, s);
+  else hipLaunchKernelGGL((k_attn_feat<false>), grid, dim3(256), 0, st, s);
+  PH_LAUNCH_CHECK();
+  hipLaunchKernelGGL((k_attn_merge<4, 5>), dim3(bh, (qn + 15) / 16), dim3(256), 0, st, a);
   PH_LAUNCH_CHECK();
   return 0;
 }

@@ -81,6 +81,32 @@ class PositionEmbeddingSineSparse(nn.Module):
             self.__dict__["_table"] = tab
         return tab
 
+    EPS_EXP2 = 14        # the small angle offsets (<= 7e-6) are stored as eps * 2^14 so that they are normal f16 values
+
+    def angle_model(self, device):
+        """What a position term needs to know about a coordinate value (`ph_attn_cross_feat`): the encoding's angle is
+        c / (c + 1e-6) * scale in fp32 (position_encoding.py:100-104) = 0 for c = 0, exactly `scale` for every |c| from a few
+        dozen up (the ratio rounds to 1), and scale + eps_c in between.  -> (eps [T] fp32 = eps_c * 2^EPS_EXP2 with eps of the
+        value 0 set to 0, G [f] fp64 = d table / d angle at `scale`, index of the value 0, index of a far value)."""
+        hit = self.__dict__.get("_angle_model")
+        if hit is not None and hit[0].device == device:
+            return hit
+        lo, hi = self.TABLE_LO, self.TABLE_HI
+        c = torch.arange(lo, hi, dtype=torch.float32, device=device)
+        v = c / (c + 1e-6) * self.scale                                   # the reference's own fp32 sequence
+        far = torch.tensor(self.scale, dtype=torch.float32, device=device)
+        eps = (v.double() - far.double())
+        eps[-lo] = 0.0                                                     # the value 0 has its own column
+        d = self.dim_t(device).double()
+        half = self.num_pos_feats // 2
+        ang = far.double() / torch.cat([d[0::2], d[1::2]])                 # table layout: sin block, then cos block
+        G = torch.cat([ang[:half].cos() / d[0::2], -ang[half:].sin() / d[1::2]])
+        i_far = hi - lo - 1
+        assert float(eps[i_far]) == 0.0 and float(eps[0]) == 0.0, "the far angle must be exact at both ends of the table"
+        hit = ((eps * float(2 ** self.EPS_EXP2)).float().contiguous(), G, -lo, i_far)
+        self.__dict__["_angle_model"] = hit
+        return hit
+
     def block_table(self, device) -> torch.Tensor:
         """[3, T, 3 f]: axis a's table in channel block a, zeros elsewhere - the encoding itself as a per-axis table
         residual (ph_conv_desc.axis_table)."""
@@ -222,6 +248,74 @@ class CrossAttentionLayer(nn.Module):
                 out["t" + name] = torch.stack([t64 @ wx[:, a * f:(a + 1) * f].t() for a in range(3)]).float().contiguous()
         self.__dict__["_ph_composed"] = (ver, out)
         return out
+
+
+    def composed_feat(self, lin: nn.Linear, pe: "PositionEmbeddingSineSparse", exp2: int):
+        """Everything `attend_feat` needs around the kernel, composed in fp64 and rounded once (cached per parameter version):
+            w2 [H * (C + 16), D], b2: (q + query_pos) -> q2, i.e. query projection, 1/sqrt(dh) and
+                                      per head [A_h^T | D0k | Gk * 2^-e | 0] in one linear map;
+            mvo [H * (C + 16), D], co [D]: Y -> attention output, i.e. per head (B_h ; D0v ; Gv * 2^-e ; 0), the constants
+                                      (bias + far position rows of V) and the output projection in one linear map.
+        A = W_k W_p, B = W_v W_p (the level's input projection `lin` composed with the K / V projections); the position rows
+        tab[t] W^T of an axis are tab_far W^T + [t == 0] D0 + eps_t G W^T (`PositionEmbeddingSineSparse.angle_model`)."""
+        mha = self.multihead_attn
+        w, b = mha.in_proj_weight, mha.in_proj_bias
+        wo, bo = mha.out_proj.weight, mha.out_proj.bias
+        tab = pe.table(w.device)
+        ver = tuple((p._version, p.data_ptr()) for p in (w, b, wo, bo, lin.weight, lin.bias)) + (tab.data_ptr(), exp2)
+        hit = self.__dict__.get("_ph_composed_feat")
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        D = w.shape[1]
+        H = self.nhead
+        dh = D // H
+        f = tab.shape[1]
+        C = lin.weight.shape[1]
+        E = C + 16
+        _, G, i0, ifar = pe.angle_model(w.device)
+        es = float(2.0 ** -pe.EPS_EXP2)
+        with torch.no_grad():
+            wp, bp, t64 = lin.weight.double(), lin.bias.double(), tab.double()
+            wq, bq = w[:D].double(), b[:D].double()
+            sides = {}
+            for name, sl in (("k", slice(D, 2 * D)), ("v", slice(2 * D, 3 * D))):
+                wx, bx = w[sl].double(), b[sl].double()
+                A = wx @ wp                                                    # [D, C]
+                d0 = torch.stack([(t64[i0] - t64[ifar]) @ wx[:, a * f:(a + 1) * f].t() for a in range(3)])     # [3, D]
+                g = torch.stack([G @ wx[:, a * f:(a + 1) * f].t() for a in range(3)]) * es                      # [3, D]
+                far = sum(t64[ifar] @ wx[:, a * f:(a + 1) * f].t() for a in range(3)) + wx @ bp + bx            # [D]
+                M = torch.zeros((D, E), dtype=torch.float64, device=w.device)  # row = projection dim, column = key column
+                M[:, :C] = A
+                M[:, C:C + 3] = d0.t()
+                M[:, C + 3:C + 6] = g.t()
+                sides[name] = (M, far)
+            Mk, _ = sides["k"]             # the keys' constant (bias + far rows) is the same for every key: softmax drops it
+            Mv, cv = sides["v"]
+            scale = float(dh) ** -0.5
+            w2 = torch.zeros((H * E, D), dtype=torch.float64, device=w.device)
+            b2 = torch.zeros((H * E,), dtype=torch.float64, device=w.device)
+            mvo = torch.zeros((H * E, D), dtype=torch.float64, device=w.device)
+            for h in range(H):
+                hs = slice(h * dh, (h + 1) * dh)
+                w2[h * E:(h + 1) * E] = (Mk[hs].t() @ wq[hs]) * scale         # [E, dh] @ [dh, D]
+                b2[h * E:(h + 1) * E] = (Mk[hs].t() @ bq[hs]) * scale
+                mvo[h * E:(h + 1) * E] = Mv[hs].t() @ wo.double()[:, hs].t()   # [E, dh] @ [dh, D]
+            co = cv @ wo.double().t() + bo.double()
+            out = dict(w2=w2.float().contiguous(), b2=b2.float().contiguous(), mvo=mvo.float().contiguous(),
+                       co=co.float().contiguous(), E=E)
+        self.__dict__["_ph_composed_feat"] = (ver, out)
+        return out
+
+    def attend_feat(self, q_embed, comp, x_split, aug, n: int, query_pos, mask_bits):
+        """The layer on the level's feature operand (ph_attn_cross_feat): keys and values are never formed."""
+        q = self.norm(q_embed)
+        B, Q, D = q.shape
+        H, E = self.nhead, comp["E"]
+        q2 = F.linear(q if query_pos is None else q + query_pos, comp["w2"], comp["b2"])
+        q2 = q2.view(B, Q, H, E).transpose(1, 2).contiguous()
+        be = backend_for(q.device)
+        y = be.attn_cross_feat(q2, x_split, aug, n, mask_bits[0], mask_bits[1])            # [B, Q, H * E]
+        return q + torch.addmm(comp["co"], y.view(B * Q, H * E), comp["mvo"]).view(B, Q, D)
 
 
 class FFNLayer(nn.Module):
@@ -604,14 +698,26 @@ class TransformerPredictorV2(nn.Module):
             ci = src_Cs[i].reshape(-1, 4)
             bits, any_ = self.compute_mask_bits(om, voxel_coord, src_Cs[i], self.src_scales[i], min_Cs, max_Cs,
                                                 cache=mask_cache)
-            if fused_attn and use_tables and ci.dtype == torch.int32 and B * N_i >= fused_mod.MIN_ROWS_LINEAR:
-                # K and V straight from the level's features: input projection, position term and K / V projection
-                # composed into one launch each (CrossAttentionLayer.composed_kv)
-                cm = ca.composed_kv(lin, tab)
+            tall = fused_attn and use_tables and ci.dtype == torch.int32 and B * N_i >= fused_mod.MIN_ROWS_LINEAR
+            x2 = x_split = None
+            if tall:
                 x2 = srcs[i].reshape(-1, srcs[i].shape[-1])
                 # the finest level's features are the mask heads' operand too: split once
                 x_split = absorbed["x_split"] if (absorbed is not None and srcs[i] is x1) else split_rows_2d(x2)
                 ci = ci.contiguous()
+            if tall and x_split is not None and be.attn_feat_supported(Qn, x2.shape[1]) and \
+                    os.environ.get("PASCO_ATTN_FEAT", "1") != "0":
+                # attention straight on the level's feature operand: K and V (two [N, 384] operands written once and read
+                # once) and their projection launches do not exist (CrossAttentionLayer.composed_feat, ph_attn_cross_feat)
+                from ..me.backend import SPLIT_ACT_EXP2
+                comp = ca.composed_feat(lin, self.pe_layer, SPLIT_ACT_EXP2)
+                eps = self.pe_layer.angle_model(dev)[0]
+                aug = be.pos_aug(ci, eps, self.pe_layer.TABLE_LO)
+                output = ca.attend_feat(output, comp, x_split, aug, N_i, query_embed, (bits, any_))
+            elif tall:
+                # K and V straight from the level's features: input projection, position term and K / V projection
+                # composed into one launch each (CrossAttentionLayer.composed_kv)
+                cm = ca.composed_kv(lin, tab)
                 # ... written only as split f16 operands, which the attention kernel streams (ph_attn_cross_split)
                 kk, k_op = linear_rows(x2, cm["wk"], cm["bk"], ca, "ck", in_split=x_split, emit=True, want_out=False,
                                        axis=(cm["tk"], ci, self.pe_layer.TABLE_LO))

@@ -116,6 +116,8 @@ _SIGNATURES = {
     "ens_merge": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "ens_finish": [_vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp],
     "attn_cross_split": [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
+    "attn_cross_feat": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
+    "pos_aug": [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp],
     "points_bounds": [_vp, _i64, _vp, _vp],
     "points_mark": [_vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "mask_compact_rank": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
@@ -957,6 +959,45 @@ class CBackend:
         self._check(rc, "attn_cross_split")
         return out
 
+
+    POS_AUG_COLS = 16
+
+    def pos_aug(self, coords: torch.Tensor, eps: torch.Tensor, tab_lo: int) -> torch.Tensor:
+        """coords int32 [N, 4] -> position columns f16 [N, 16] of the keys (include/pasco_hip.h pos_aug): [c == 0] and
+        eps[c - tab_lo] per axis."""
+        self._chk(coords, torch.int32, "coords")
+        self._chk(eps, torch.float32, "eps")
+        n = coords.shape[0]
+        assert coords.shape[1] == 4
+        out = torch.empty((n, self.POS_AUG_COLS), dtype=torch.float16, device=coords.device)
+        rc = self.fn["pos_aug"](_ptr(coords), n, _ptr(eps), int(tab_lo), eps.numel(), _ptr(out),
+                                _ptr(self.status_word(coords.device)), self.stream(coords.device))
+        self._check(rc, "pos_aug")
+        return out
+
+    def attn_feat_supported(self, qn: int, c: int) -> bool:
+        return qn <= 128 and (c == 64 or (self.device_type == "cpu" and c % 32 == 0)) and self.has("attn_cross_feat")
+
+    def attn_cross_feat(self, q2, x_split, aug, n: int, bits=None, any_=None, exp2=None) -> torch.Tensor:
+        """Attention on the level's feature operand (include/pasco_hip.h attn_cross_feat): q2 [B, H, Qn, c + 16],
+        x_split f16 [B*N, c/32, 2, 32], aug f16 [B*N, 16] -> Y [B, Qn, H * (c + 16)]."""
+        self._chk(q2, torch.float32, "q2")
+        b, h, qn, d = q2.shape
+        c = d - self.POS_AUG_COLS
+        assert x_split.dtype == torch.float16 and x_split.is_contiguous() and x_split.numel() == b * n * c * 2, "x_split"
+        assert aug.dtype == torch.float16 and aug.is_contiguous() and aug.numel() == b * n * self.POS_AUG_COLS, "aug"
+        exp2 = SPLIT_ACT_EXP2 if exp2 is None else int(exp2)
+        out = torch.empty((b, qn, h * d), dtype=torch.float32, device=q2.device)
+        need = int(self.fn["attn_workspace_bytes"](n, b, h, qn, d))
+        key = ("attn",) + self._stream_key(q2.device)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=q2.device)
+            self._ws[key] = ws
+        rc = self.fn["attn_cross_feat"](_ptr(q2), _ptr(x_split), _ptr(aug), c, exp2, _ptr(bits), _ptr(any_), _ptr(out), n, b, h,
+                                        qn, _ptr(ws), ws.numel(), _ptr(self.status_word(q2.device)), self.stream(q2.device))
+        self._check(rc, "attn_cross_feat")
+        return out
 
     # ---- panoptic ensembling rows (include/pasco_hip.h ens_*) ----------------------------------------------------------
     def project_canonical(self, T: torch.Tensor, size, resolution: float, min_bound) -> torch.Tensor:

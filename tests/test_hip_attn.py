@@ -192,3 +192,99 @@ def test_bits_block_or_matches_oracle_and_pooling(hip, oracle, s):
     level[1, 0, 2] = -1
     _, rng = hip.bits_block_or(level.reshape(-1, 4).cuda(), N, s, tk, tv, bits1.cuda(), lo.cuda(), hi.cuda(), want_range=True)
     assert int(rng.item()) == 1
+
+
+# ---- attention on the level's feature operand (ph_attn_cross_feat, ph_pos_aug) ---------------------------------------
+def feat_ref(q2, x_split, aug, B, N, allow):
+    """fp64 restatement: rows r = [x | aug] (x = hi + lo of the operand, unscaled), Y = softmax(q2 r^T + mask) r."""
+    from pasco_amd.me.backend import SPLIT_ACT_EXP2
+    xs = x_split.double()
+    x = (xs[:, :, 0] + xs[:, :, 1]).reshape(B, N, -1) * 2.0 ** -SPLIT_ACT_EXP2
+    r = torch.cat([x, aug.double().reshape(B, N, 16)], dim=-1)             # [B, N, E]
+    s = torch.einsum("bhqe,bne->bhqn", q2.double(), r)
+    if allow is not None:
+        al = allow.permute(0, 2, 1)
+        al = al | ~al.any(dim=-1, keepdim=True)
+        s = s.masked_fill(~al[:, None], float("-inf"))
+    y = torch.einsum("bhqn,bne->bhqe", torch.softmax(s, dim=-1), r)        # [B, H, Q, E]
+    H, Q, E = y.shape[1:]
+    return y.permute(0, 2, 1, 3).reshape(B, Q, H * E).float()
+
+
+def feat_inputs(B, H, Q, N, seed, hip):
+    from pasco_amd.graph.transformer import PositionEmbeddingSineSparse
+    g = torch.Generator().manual_seed(seed)
+    C = 64
+    x = torch.randn(B * N, C, generator=g) * torch.rand(B * N, 1, generator=g) * 3
+    coords = torch.randint(-2, 260, (B * N, 4), generator=g, dtype=torch.int32)
+    coords[: max(1, N // 7), 1:] = torch.randint(0, 3, (max(1, N // 7), 3), generator=g, dtype=torch.int32)
+    q2 = torch.randn(B, H, Q, C + 16, generator=g) * 48 ** -0.5
+    q2[..., C + 6:] = 0                                              # unused position columns
+    q2[..., C + 3:C + 6] *= 2.0 ** -14
+    pe = PositionEmbeddingSineSparse(128, normalize=True)
+    eps = pe.angle_model(torch.device("cuda"))[0]
+    return x.cuda(), coords.cuda(), q2.cuda(), eps, pe.TABLE_LO
+
+
+@pytest.mark.parametrize("B,H,Q,N", [(1, 8, 100, 1), (2, 8, 100, 31), (2, 8, 100, 32), (3, 8, 100, 33), (3, 8, 100, 4097),
+                                      (2, 8, 128, 3000), (1, 2, 5, 70000), (3, 8, 100, 60000)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attn_cross_feat_matches_fp64(hip, B, H, Q, N, masked):
+    x, coords, q2, eps, lo = feat_inputs(B, H, Q, N, N + Q, hip)
+    x_split = hip.split_rows(x)
+    aug = hip.pos_aug(coords, eps, lo)
+    bits = any_ = allow = None
+    if masked:
+        g = torch.Generator().manual_seed(N)
+        allow = torch.rand(B, N, Q, generator=g) > 0.7
+        allow[:, :, 3] = False
+        if N > 20:
+            allow[0, : N // 2, Q - 1] = False
+        allow = allow.cuda()
+        bits, any_ = hip.attn_mask_pack(allow.reshape(B * N, Q).float().contiguous(), B, N)
+    got = hip.attn_cross_feat(q2, x_split, aug, N, bits, any_)
+    exp = feat_ref(q2, x_split, aug, B, N, allow)
+    hip.check_status(x.device)
+    assert torch.isfinite(got).all()
+    assert torch.allclose(got, exp, rtol=1e-4, atol=2e-5), float((got - exp).abs().max())
+
+
+def test_pos_aug_and_feat_attention_match_the_oracle(hip, oracle):
+    B, H, Q, N = 2, 8, 100, 777
+    x, coords, q2, eps, lo = feat_inputs(B, H, Q, N, 5, hip)
+    aug_h = hip.pos_aug(coords, eps, lo)
+    aug_o = oracle.pos_aug(coords.cpu(), eps.cpu(), lo)
+    assert torch.equal(aug_h.cpu().view(torch.int16), aug_o.view(torch.int16))
+    xs_h = hip.split_rows(x)
+    xs_o = oracle.split_rows(x.cpu())
+    assert torch.equal(xs_h.cpu().view(torch.int16), xs_o.view(torch.int16))
+    g = torch.Generator().manual_seed(1)
+    allow = (torch.rand(B * N, Q, generator=g) > 0.5).float()
+    b_o, a_o = oracle.attn_mask_pack(allow, B, N)
+    b_h, a_h = hip.attn_mask_pack(allow.cuda(), B, N)
+    exp = oracle.attn_cross_feat(q2.cpu(), xs_o, aug_o, N, b_o, a_o)
+    got = hip.attn_cross_feat(q2, xs_h, aug_h, N, b_h, a_h).cpu()
+    assert torch.allclose(got, exp, rtol=1e-3, atol=1e-4), float((got - exp).abs().max())
+    # a coordinate outside the table raises the stream's status bit 2
+    bad = coords.clone()
+    bad[3, 2] = 100000
+    hip.pos_aug(bad, eps, lo)
+    from pasco_amd.me.backend import StatusError
+    with pytest.raises(StatusError):
+        hip.check_status(x.device)
+
+
+def test_attn_cross_feat_workspace_canary(hip):
+    from pasco_amd.me.backend import _ptr, SPLIT_ACT_EXP2
+    B, H, Q, N = 2, 8, 100, 5000
+    x, coords, q2, eps, lo = feat_inputs(B, H, Q, N, 9, hip)
+    xs, aug = hip.split_rows(x), hip.pos_aug(coords, eps, lo)
+    need = int(hip.fn["attn_workspace_bytes"](N, B, H, Q, 80))
+    ws = torch.full((need + 4096,), 0x5A, dtype=torch.uint8, device="cuda")
+    out = torch.empty((B, Q, H * 80), device="cuda")
+    rc = hip.fn["attn_cross_feat"](_ptr(q2), _ptr(xs), _ptr(aug), 64, SPLIT_ACT_EXP2, None, None, _ptr(out), N, B, H, Q,
+                                   _ptr(ws), need, None, hip.stream(x.device))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert bool((ws[need:] == 0x5A).all())
+    assert torch.allclose(out, feat_ref(q2, xs, aug, B, N, None), rtol=1e-4, atol=2e-5)

@@ -145,7 +145,7 @@ def test_s10_mimo3_split_path_vs_exact_fp32(hip, s10_net):
           f"(floor 0.25 mean |y|) {worst['elementwise']:.2e}")
 
 
-@pytest.mark.parametrize("switch", ["PASCO_HEAD_ABSORB", "PASCO_ATTN_SPLIT", "PASCO_PE_TABLE", "PASCO_RESIZE_ABSORB", "PASCO_MASK_BLOCK"])
+@pytest.mark.parametrize("switch", ["PASCO_ATTN_FEAT", "PASCO_HEAD_ABSORB", "PASCO_ATTN_SPLIT", "PASCO_PE_TABLE", "PASCO_RESIZE_ABSORB", "PASCO_MASK_BLOCK"])
 def test_s10_transformer_restructurings_vs_plain_forms(hip, s10_net, switch, monkeypatch):
     """The algebraic restructurings of the mask transformer at the benchmark size, each against the form it replaces
     (the switch set to 0): mask heads absorbed into the level's features vs voxel features formed and multiplied
