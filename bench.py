@@ -620,6 +620,7 @@ def main():
         res["allocator"]["device_mallocs_in_timed_loop"] = (alloc_log["after_timed_loop"].get("device_mallocs", 0) -
                                                             alloc_log["after_warmup"].get("device_mallocs", 0))
         res["warmup_detail"] = warm_info
+        res["warmup_detail"]["allocator_rounding"] = server.allocator_rounding
         if vet is not None:
             res["memory_vet"] = vet
         if rounds_ms:

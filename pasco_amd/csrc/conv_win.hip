@@ -570,6 +570,203 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_win(ConvArgsH a) {
   h2_store_tile<TM, TN, EMIT>(a, acc, m0, n0, wm, wn, h, l31);
 }
 
+// ---- the 64-wide convolution, OFFSET-PARALLEL waves (round 4) --------------------------------------------------------------
+// What held k_conv_win<4, 4, 1, 1, 2> (the 64-channel 3^3 layers, the largest class of a step) at 0.23 of the matrix peak
+// (profiles/r3u_pmc_window_kernel.txt): a 32 x 64 wave tile needs 12 fragment reads (4 activation + 8 weight, 16 bytes per
+// lane each) per 12 MFMAs, every wave of the workgroup reads the SAME weight tile from LDS, and the weight ring costs one
+// workgroup barrier per 12 MFMAs (28 % of the wave cycles in counter / barrier waits).  Here the four waves split the 27
+// KERNEL OFFSETS instead of the tile's rows: wave w owns offsets w, w + 4, ... and multiplies ALL 128 rows x 64 columns for
+// them (accumulators 4 x 2 x 16 registers).  Then
+//   * a weight fragment is used by one wave only: it is loaded global -> registers (L2-resident, 16 bytes per lane, half a
+//     stage ahead), no LDS ring, NO BARRIER in the offset loop - waves free-run between the window loads;
+//   * per half-stage (one offset, 16 of the chunk's 32 channels) a wave reads 8 activation fragments from the window for
+//     24 MFMAs: a third of the LDS read traffic per MFMA;
+//   * at the end of the tile the four partial accumulators are summed through LDS in a fixed order (own part, then the
+//     other waves' ascending) and wave i stores row block i with the common epilogue.
+// Same products as k_conv_win, another fp32 summation order (per wave: pass, chunk, own offsets; then across waves).
+template <int WMAX, bool EMIT>
+__global__ void __launch_bounds__(256, 2) k_conv_wop(ConvArgsH a) {
+  constexpr int NT = 256;
+  constexpr int RPP = NT / 8;                       // window rows one DMA pass covers
+  constexpr int BM = WIN_BM;
+  constexpr int W_PASSES = WMAX / RPP;
+  static_assert(WMAX % RPP == 0, "window capacity vs DMA pass");
+  constexpr int WIN_BYTES = (WMAX + 1) * 128;       // + the zero row
+  constexpr int OFF_SLOT = WIN_BYTES;
+  constexpr int OFF_WIDX = OFF_SLOT + WIN_CAP * 2;
+  static_assert(WIN_BYTES >= 4 * 2 * 16 * 64 * 4, "the reduction of the partial accumulators reuses the window");
+  __shared__ __attribute__((aligned(128))) char lds[OFF_WIDX + WMAX * 4];
+
+  const int nwg = gridDim.x;
+  const int cpx = nwg >> 3;
+  const int bid = blockIdx.x;
+  const int row_tile = (bid & 7) * cpx + (bid >> 3);
+  if (row_tile >= a.n_row_tiles) return;
+  if (!ph_win_pred(a.win_stats, a.win_which, a.n_row_tiles)) return;   // the gather kernel serves this map
+  const int64_t m0 = (int64_t)row_tile * BM;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5;
+  const int l31 = lane & 31;
+  const int cout = a.cout;
+  const int nchunks = a.cpad >> 5;
+  const uint32_t rsb = 4u * (uint32_t)a.cpad;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  {   // tile constants: slot map -> LDS, zero row
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.win_slots + (int64_t)row_tile * WIN_CAP);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds + OFF_SLOT);
+    for (int i = tid; i < WIN_CAP * 2 / 16; i += NT) dst[i] = src[i];
+    if (tid < 8) reinterpret_cast<uint4 *>(lds + WMAX * 128)[tid] = make_uint4(0, 0, 0, 0);
+  }
+  const int cnt = a.win_cnt[row_tile];
+  const int npass = cnt > 0 ? (cnt + WMAX - 1) / WMAX : 1;
+  const uint16_t *slot_lds = reinterpret_cast<const uint16_t *>(lds + OFF_SLOT);
+  int *widx = reinterpret_cast<int *>(lds + OFF_WIDX);
+
+  // window DMA geometry (as k_conv_win)
+  const int l_j = tid & 7;
+  const int l_r = tid >> 3;
+  const uint32_t sj16 = (uint32_t)((l_j ^ ((l_r >> 1) & 7)) << 4);
+  const uint64_t in_base = (uint64_t)reinterpret_cast<uintptr_t>(a.in_split) + sj16;
+  const uint64_t zero_src = (uint64_t)reinterpret_cast<uintptr_t>(a.zero) + sj16;
+
+  // weight fragments: lane (column l31 of column block j, k-slots 8 h .. 8 h + 7 of the half-stage) = 16 bytes of row
+  // (k * cout + column) of the weight operand, hi at + 0, lo at + 64 of the chunk's 128-byte group
+  const char *wrow[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int n = j * 32 + l31;
+    n = n < cout ? n : cout - 1;
+    wrow[j] = reinterpret_cast<const char *>(a.w_split) + (uint64_t)n * rsb + h * 16;
+  }
+  const uint64_t wslab = (uint64_t)cout * rsb;
+  struct WF {
+    f16x8 bh[2], bl[2];
+  };
+  auto load_w = [&](int k, int chunk, int ks) {
+    WF f;
+    const uint64_t off = (uint64_t)k * wslab + ((uint32_t)chunk << 7) + (uint32_t)(ks * 32);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f.bh[j] = *reinterpret_cast<const f16x8 *>(wrow[j] + off);
+      f.bl[j] = *reinterpret_cast<const f16x8 *>(wrow[j] + off + 64);
+    }
+    return f;
+  };
+  // this wave's offsets: wave, wave + 4, ...; the flattened sequence of half-stages over (pass, chunk, offset, ks) is walked
+  // with the weights of the NEXT half-stage in flight
+  const int nk = (WIN_KV - wave + 3) >> 2;          // 7, 7, 7, 6
+
+  auto half_stage = [&](const WF &w, int ks, const uint32_t (&abase)[4], const uint32_t (&sw)[4]) {
+    f16x8 ah[4], al[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const f16x8 *>(lds + abase[i] + (((uint32_t)(ks * 2 + h) ^ sw[i]) << 4));
+      al[i] = *reinterpret_cast<const f16x8 *>(lds + abase[i] + (((uint32_t)(4 + ks * 2 + h) ^ sw[i]) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bh[j], al[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bl[j], ah[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bh[j], ah[i], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  WF w0 = load_w(wave, 0, 0);
+  for (int pass = 0; pass < npass; ++pass) {
+    const int base = pass * WMAX;
+    const int wp = cnt - base < WMAX ? cnt - base : WMAX;
+    __syncthreads();                                 // slot map / zero row written; previous pass's window no longer read
+    {
+      const int32_t *wr = a.win_rows + (int64_t)row_tile * WIN_CAP + base;
+      for (int i = tid; i < WMAX; i += NT) widx[i] = i < wp ? wr[i] : -1;
+    }
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const uint32_t coff = (uint32_t)chunk << 7;
+      if (chunk > 0) __syncthreads();                // every wave is done reading the previous chunk's window
+#pragma unroll
+      for (int p = 0; p < W_PASSES; ++p) {
+        if (p * RPP < wp) {                          // uniform
+          const int ix = widx[p * RPP + l_r];
+          uint64_t v = in_base + (uint64_t)(uint32_t)(ix < 0 ? 0 : ix) * rsb + coff;
+          asm volatile("" : "+v"(v));
+          const uint64_t src = ix >= 0 ? v : zero_src;
+          char *dst = lds + (p * RPP + wave * 8) * 128;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)src,
+                                           (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const bool last_chunk = chunk + 1 == nchunks && pass + 1 == npass;
+      for (int t = 0; t < nk; ++t) {
+        const int k = wave + 4 * t;
+        // window rows of this offset's 4 x 32 entries (zero row: no neighbour, or a row of another pass)
+        uint32_t abase[4], sw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t slot = slot_lds[k * BM + i * 32 + l31];
+          const uint32_t local = slot - (uint32_t)base;
+          const uint32_t wr = local < (uint32_t)wp ? local : (uint32_t)WMAX;
+          abase[i] = wr * 128u;
+          sw[i] = (wr >> 1) & 7u;
+        }
+        const WF w1 = load_w(k, chunk, 1);
+        half_stage(w0, 0, abase, sw);
+        // next half-stage's weights: next offset of this chunk, else the first offset of the next chunk / pass (the last one of
+        // the tile re-reads its own: harmless, never used)
+        const bool more = t + 1 < nk;
+        const int kn = more ? k + 4 : wave;
+        const int cn = more ? chunk : (last_chunk ? chunk : (chunk + 1 == nchunks ? 0 : chunk + 1));
+        w0 = load_w(kn, cn, 0);
+        half_stage(w1, 1, abase, sw);
+      }
+    }
+  }
+
+  // ---- sum of the four partial accumulators: wave i ends up with row block i ---------------------------------------------
+  __syncthreads();                                   // the window is free
+  float *red = reinterpret_cast<float *>(lds);       // [wave][j][r][lane]
+  f32x16 fin[1][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (wave != i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wave == i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        fin[0][j] = acc[i][j];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (s == i) continue;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) fin[0][j][r] += red[((s * 2 + j) * 16 + r) * 64 + lane];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  h2_store_tile<1, 2, EMIT>(a, fin, m0, 0, wave, 0, h, l31);
+}
+
 template <int WAVES, int WM, int WN, int TM, int TN, int WMAX>
 static int launch_win(const ConvArgsH &a, hipStream_t st) {
   constexpr int BN = WN * TN * 32;
@@ -600,6 +797,17 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st) {
   }
   if (bn == 64) {
     b.win_which = 0 | ph_win_force_bits();
+    static const bool wop = [] { const char *e = getenv("PASCO_WIN_OFFSET_PARALLEL"); return e == nullptr || atoi(e) != 0; }();
+    if (wop && b.cout <= 64) {       // offset-parallel waves (k_conv_wop); PASCO_WIN_OFFSET_PARALLEL=0: the row-parallel kernel
+      ConvArgsH args = b;
+      args.n_row_tiles = (int)((b.n_out + WIN_BM - 1) / WIN_BM);
+      args.n_col_tiles = 1;
+      const int grid = ((args.n_row_tiles + 7) / 8) * 8;
+      if (args.out_split != nullptr) hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, true>), dim3(grid), dim3(256), 0, st, args);
+      else hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, false>), dim3(grid), dim3(256), 0, st, args);
+      PH_LAUNCH_CHECK();
+      return 0;
+    }
     return launch_win<4, 4, 1, 1, 2, WIN_MAX_64>(b, st);
   }
   b.win_which = 1 | ph_win_force_bits();

@@ -97,8 +97,19 @@ class SceneServer:
     """`in_flight` scenes at a time through `step(item)` on one GPU.  `step` is called under `torch.no_grad()` with the
     worker's stream current; items are whatever `step` takes (the benchmark passes scene indices)."""
 
-    def __init__(self, device, step: Callable, in_flight: int = 3, switch_interval_ms: Optional[float] = 0.5):
+    def __init__(self, device, step: Callable, in_flight: int = 3, switch_interval_ms: Optional[float] = 0.5,
+                 allocator_rounding: Optional[int] = 8):
         self.device = torch.device(device)
+        # Request sizes differ from scene to scene by a few percent (row counts), so a cached block rarely fits the next
+        # scene's request exactly; rounding requests up to 1/8 of a power of two lets scenes reuse each other's blocks and
+        # the pools settle in one pass instead of growing for many (process-wide allocator setting: None leaves it alone)
+        self.allocator_rounding = None
+        if allocator_rounding:
+            try:
+                torch.cuda.memory._set_allocator_settings(f"roundup_power2_divisions:{int(allocator_rounding)}")
+                self.allocator_rounding = int(allocator_rounding)
+            except Exception:      # an optimisation of the warm-up, never a requirement
+                pass
         self.step = step
         self.in_flight = max(int(in_flight), 1)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.in_flight)]
@@ -161,13 +172,21 @@ class SceneServer:
 
     # -- warm-up -------------------------------------------------------------------------------------------------------
     def warm(self, items: Sequence, max_rounds: int = 6) -> dict:
-        """Every item once on the caller's stream (map shapes, operand caches), once on every worker stream (their graphs
-        and workspaces; one stream at a time - graph captures do not overlap other launches), then rounds of the in-flight
-        loop over 2 x in_flight x len(items) steps until a whole round needed no device allocation (the allocator's pools
-        depend on the order the workers draw the items in; they settle within a few rounds)."""
+        """Every item on the caller's stream until a whole pass needed no device allocation (map shapes, operand caches, the
+        stream's allocator pool), once on every worker stream (their graphs and workspaces; one stream at a time - graph
+        captures do not overlap other launches), then rounds of the in-flight loop over 2 x in_flight x len(items) steps
+        until a whole round needed no device allocation either (the pools depend on the order the workers draw the items
+        in; they settle within a few rounds).  Why it matters: a device allocation inside a served loop costs from ~0.1 ms
+        to several ms depending on the box, stalls the launch that waits for it and, on the slow boxes, every stream
+        (profiles/README.md, round 4: the "slow mode" of rounds 2 - 3)."""
         items = list(items)
         t0 = time.perf_counter()
-        self.run_serial(items)
+        serial_rounds, quiet1 = 0, False
+        while not quiet1 and serial_rounds < max_rounds:
+            before = _device_mallocs(self.device)
+            self.run_serial(items)
+            serial_rounds += 1
+            quiet1 = serial_rounds > 1 and _device_mallocs(self.device) == before
         if self.in_flight > 1:
             for s in self.streams:
                 with torch.cuda.stream(s):
@@ -180,4 +199,5 @@ class SceneServer:
             rounds += 1
             quiet = _device_mallocs(self.device) == before
         torch.cuda.synchronize(self.device)
-        return {"in_flight_rounds": rounds, "settled": bool(quiet), "seconds": round(time.perf_counter() - t0, 2)}
+        return {"serial_rounds": serial_rounds, "serial_settled": bool(quiet1), "in_flight_rounds": rounds,
+                "settled": bool(quiet), "seconds": round(time.perf_counter() - t0, 2)}

@@ -67,6 +67,28 @@ def main():
             flag = "  <-- SLOW" if (f < 0.5 * fills[len(fills) // 2] or k < 0.5 * k1s[len(k1s) // 2]) else ""
             print(f"  {ptr:#016x}  fill {f:7.0f} GB/s   k1 {k:7.0f} GB/s ({us:7.0f} us)   read {r:7.0f} GB/s{flag}")
 
+    # what a device allocation costs on this box (host time of a request the cache cannot serve, and of the first launch
+    # into the new block): the cost a served loop pays for every allocation its warm-up did not provoke
+    import time
+    for mb in (64, 256, 1024):
+        ts, tl = [], []
+        for _ in range(5):
+            torch.cuda.empty_cache()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            t = torch.empty(mb << 20, dtype=torch.uint8, device=dev)
+            t1 = time.perf_counter()
+            t[:1 << 20].fill_(0)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            ts.append((t1 - t0) * 1e3)
+            tl.append((t2 - t1) * 1e3)
+            del t
+        t0 = time.perf_counter()
+        torch.cuda.empty_cache()
+        tf = (time.perf_counter() - t0) * 1e3
+        print(f"device allocation of {mb:5d} MB: {min(ts):7.3f} .. {max(ts):7.3f} ms (host), first 1 MB fill + sync "
+              f"{min(tl):6.3f} .. {max(tl):6.3f} ms, free {tf:6.3f} ms")
     held = [torch.empty(GIB, dtype=torch.uint8, device=dev) for _ in range(blocks)]
     probe("caching allocator, 1 GiB requests", held)
     st = torch.cuda.memory_stats(dev)
