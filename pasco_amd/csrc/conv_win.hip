@@ -584,7 +584,50 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_win(ConvArgsH a) {
 //   * at the end of the tile the four partial accumulators are summed through LDS in a fixed order (own part, then the
 //     other waves' ascending) and wave i stores row block i with the common epilogue.
 // Same products as k_conv_win, another fp32 summation order (per wave: pass, chunk, own offsets; then across waves).
-template <int WMAX, bool EMIT>
+// The offset loop is scheduled by hand (inline-asm loads with counted waits; left to the compiler the weight loads were sunk
+// behind the MFMAs that precede them and every fragment read was waited for one by one): per half-stage
+//     issue the 4 weight loads of the NEXT half-stage           (vmcnt: waited at the end of this half-stage)
+//     wait for the fragments of row blocks 0, 1 -> 12 MFMAs -> issue their reads for the next half-stage
+//     wait for the fragments of row blocks 2, 3 -> 12 MFMAs -> issue their reads for the next half-stage
+// so LDS and L2 latencies run under the MFMAs of the same wave, and the second wave of the SIMD fills what is left.
+__device__ __forceinline__ f16x8 wop_gld(const char *p) {
+  f16x8 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ f16x8 wop_lds(uint32_t addr) {
+  f16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint32_t wop_lds16(uint32_t addr) {
+  uint32_t v;
+  asm volatile("ds_read_u16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+struct WopW {
+  f16x8 bh[2], bl[2];
+};
+struct WopA {                 // activation fragments of two row blocks: [block][hi, lo]
+  f16x8 h[2], l[2];
+};
+#define WOP_WAIT_VM0(w) asm volatile("s_waitcnt vmcnt(0)" : "+v"((w).bh[0]), "+v"((w).bh[1]), "+v"((w).bl[0]), "+v"((w).bl[1])::"memory")
+#define WOP_WAIT_LGKM(n, f) \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"((f).h[0]), "+v"((f).h[1]), "+v"((f).l[0]), "+v"((f).l[1])::"memory")
+
+// development hook (tools/wop_trace.py): shader-clock stamps of the phases of the first 64 workgroups (wave 0), TRACE builds only
+__device__ unsigned long long g_wop_trace[64 * 16];
+static int g_wop_trace_on = 0;
+extern "C" void ph_wop_trace_enable(int on) { g_wop_trace_on = on; }
+extern "C" int ph_wop_trace_read(unsigned long long *host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wop_trace), sizeof(g_wop_trace)) == hipSuccess ? 0 : 2;
+}
+#define WOP_STAMP(i)                                                                                   \
+  do {                                                                                                 \
+    if (TRACE && tid == 0 && blockIdx.x < 64) g_wop_trace[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+
+template <int WMAX, bool EMIT, bool TRACE = false>
 __global__ void __launch_bounds__(256, 2) k_conv_wop(ConvArgsH a) {
   constexpr int NT = 256;
   constexpr int RPP = NT / 8;                       // window rows one DMA pass covers
@@ -594,7 +637,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop(ConvArgsH a) {
   constexpr int WIN_BYTES = (WMAX + 1) * 128;       // + the zero row
   constexpr int OFF_SLOT = WIN_BYTES;
   constexpr int OFF_WIDX = OFF_SLOT + WIN_CAP * 2;
-  static_assert(WIN_BYTES >= 4 * 2 * 16 * 64 * 4, "the reduction of the partial accumulators reuses the window");
   __shared__ __attribute__((aligned(128))) char lds[OFF_WIDX + WMAX * 4];
 
   const int nwg = gridDim.x;
@@ -602,10 +644,32 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop(ConvArgsH a) {
   const int bid = blockIdx.x;
   const int row_tile = (bid & 7) * cpx + (bid >> 3);
   if (row_tile >= a.n_row_tiles) return;
-  if (!ph_win_pred(a.win_stats, a.win_which, a.n_row_tiles)) return;   // the gather kernel serves this map
   const int64_t m0 = (int64_t)row_tile * BM;
+  // Everything the tile needs from global memory before its first window is requested AT ONCE (the statistics of the
+  // predicate, the slot map, the window's row list, the row count; the dependent chain predicate -> slot map -> row list ->
+  // window cost four round trips = 11 % of a workgroup's life, tools/wop_trace.py): one round trip, then the window DMA.
+  const int32_t st_w = a.win_stats[a.win_which & 1];
+  uint4 slot_raw[2];
+  int32_t widx_raw[2];
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.win_slots + (int64_t)row_tile * WIN_CAP);
+    const int32_t *wrp = a.win_rows + (int64_t)row_tile * WIN_CAP;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = (int)threadIdx.x + q * NT;
+      slot_raw[q] = i < WIN_CAP * 2 / 16 ? src[i] : make_uint4(0, 0, 0, 0);
+      widx_raw[q] = i < WMAX ? wrp[i] : -1;
+    }
+  }
+  const int cnt = a.win_cnt[row_tile];
+  {
+    const int which = a.win_which;       // ph_win_pred on the value loaded above
+    const bool windows = (which & 0x100) ? true : ((which & 0x200) ? false : (int64_t)st_w * 4 <= (int64_t)a.n_row_tiles * 5);
+    if (!windows) return;                // the gather kernel serves this map
+  }
 
   const int tid = threadIdx.x;
+  WOP_STAMP(0);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5;
@@ -613,6 +677,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop(ConvArgsH a) {
   const int cout = a.cout;
   const int nchunks = a.cpad >> 5;
   const uint32_t rsb = 4u * (uint32_t)a.cpad;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -622,16 +687,20 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop(ConvArgsH a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  {   // tile constants: slot map -> LDS, zero row
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.win_slots + (int64_t)row_tile * WIN_CAP);
+  static_assert(WIN_CAP * 2 / 16 <= 2 * NT && WMAX <= 2 * NT, "two loads per thread cover the slot map and the row list");
+  int *widx = reinterpret_cast<int *>(lds + OFF_WIDX);
+  {   // tile constants: slot map, first pass's row list, zero row -> LDS
     uint4 *dst = reinterpret_cast<uint4 *>(lds + OFF_SLOT);
-    for (int i = tid; i < WIN_CAP * 2 / 16; i += NT) dst[i] = src[i];
+    const int wp0 = cnt < WMAX ? cnt : WMAX;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = tid + q * NT;
+      if (i < WIN_CAP * 2 / 16) dst[i] = slot_raw[q];
+      if (i < WMAX) widx[i] = i < wp0 ? widx_raw[q] : -1;
+    }
     if (tid < 8) reinterpret_cast<uint4 *>(lds + WMAX * 128)[tid] = make_uint4(0, 0, 0, 0);
   }
-  const int cnt = a.win_cnt[row_tile];
   const int npass = cnt > 0 ? (cnt + WMAX - 1) / WMAX : 1;
-  const uint16_t *slot_lds = reinterpret_cast<const uint16_t *>(lds + OFF_SLOT);
-  int *widx = reinterpret_cast<int *>(lds + OFF_WIDX);
 
   // window DMA geometry (as k_conv_win)
   const int l_j = tid & 7;
@@ -650,48 +719,49 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop(ConvArgsH a) {
     wrow[j] = reinterpret_cast<const char *>(a.w_split) + (uint64_t)n * rsb + h * 16;
   }
   const uint64_t wslab = (uint64_t)cout * rsb;
-  struct WF {
-    f16x8 bh[2], bl[2];
-  };
-  auto load_w = [&](int k, int chunk, int ks) {
-    WF f;
+  auto load_w = [&](int k, int chunk, int ks, WopW &f) {
     const uint64_t off = (uint64_t)k * wslab + ((uint32_t)chunk << 7) + (uint32_t)(ks * 32);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      f.bh[j] = *reinterpret_cast<const f16x8 *>(wrow[j] + off);
-      f.bl[j] = *reinterpret_cast<const f16x8 *>(wrow[j] + off + 64);
-    }
-    return f;
+    f.bh[0] = wop_gld(wrow[0] + off);
+    f.bl[0] = wop_gld(wrow[0] + off + 64);
+    f.bh[1] = wop_gld(wrow[1] + off);
+    f.bl[1] = wop_gld(wrow[1] + off + 64);
   };
-  // this wave's offsets: wave, wave + 4, ...; the flattened sequence of half-stages over (pass, chunk, offset, ks) is walked
-  // with the weights of the NEXT half-stage in flight
-  const int nk = (WIN_KV - wave + 3) >> 2;          // 7, 7, 7, 6
+  // this wave's offsets: wave, wave + 4, ... (7, 7, 7, 6 of them)
+  const int nk = (WIN_KV - wave + 3) >> 2;
+  const uint32_t slot_rd = lds0 + (uint32_t)OFF_SLOT + (uint32_t)(l31 * 2);      // + (k * 128 + 32 i) * 2
 
-  auto half_stage = [&](const WF &w, int ks, const uint32_t (&abase)[4], const uint32_t (&sw)[4]) {
-    f16x8 ah[4], al[4];
+  // fragment reads of two row blocks (i0, i0 + 1) of a half-stage: window rows wr (128-byte rows, 16-byte granules swizzled by
+  // (row >> 1) & 7; hi granules 0..3, lo granules 4..7 of the chunk)
+  auto issue_a = [&](const uint32_t (&wr)[4], int ks, int i0, WopA &f) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ah[i] = *reinterpret_cast<const f16x8 *>(lds + abase[i] + (((uint32_t)(ks * 2 + h) ^ sw[i]) << 4));
-      al[i] = *reinterpret_cast<const f16x8 *>(lds + abase[i] + (((uint32_t)(4 + ks * 2 + h) ^ sw[i]) << 4));
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t r = wr[i0 + u];
+      const uint32_t sw = (r >> 1) & 7u;
+      const uint32_t ab = lds0 + r * 128u;
+      f.h[u] = wop_lds(ab + (((uint32_t)(ks * 2 + h) ^ sw) << 4));
+      f.l[u] = wop_lds(ab + (((uint32_t)(4 + ks * 2 + h) ^ sw) << 4));
     }
+  };
+  auto mfma12 = [&](const WopW &w, const WopA &f, int i0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bh[j], al[i], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bl[j], ah[i], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bh[j], ah[i], acc[i][j], 0, 0, 0);
+        acc[i0 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bh[j], f.l[u], acc[i0 + u][j], 0, 0, 0);
+        acc[i0 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bl[j], f.h[u], acc[i0 + u][j], 0, 0, 0);
+        acc[i0 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bh[j], f.h[u], acc[i0 + u][j], 0, 0, 0);
       }
   };
 
-  WF w0 = load_w(wave, 0, 0);
+  WopW w0, w1;
+  load_w(wave, 0, 0, w0);
   for (int pass = 0; pass < npass; ++pass) {
     const int base = pass * WMAX;
     const int wp = cnt - base < WMAX ? cnt - base : WMAX;
-    __syncthreads();                                 // slot map / zero row written; previous pass's window no longer read
-    {
-      const int32_t *wr = a.win_rows + (int64_t)row_tile * WIN_CAP + base;
-      for (int i = tid; i < WMAX; i += NT) widx[i] = i < wp ? wr[i] : -1;
+    if (pass > 0) {                                  // further passes (windows beyond the LDS capacity): their row list
+      __syncthreads();                               // the previous pass's window and row list are no longer read
+      const int32_t *wrp = a.win_rows + (int64_t)row_tile * WIN_CAP + base;
+      for (int i = tid; i < WMAX; i += NT) widx[i] = i < wp ? wrp[i] : -1;
     }
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -709,62 +779,115 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop(ConvArgsH a) {
                                            (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      WOP_STAMP(1 + 3 * (chunk & 1));
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the window and the prefetched weights w0
+      __builtin_amdgcn_s_barrier();
+      WOP_STAMP(2 + 3 * (chunk & 1));
       const bool last_chunk = chunk + 1 == nchunks && pass + 1 == npass;
+      const int cnext = last_chunk ? chunk : (chunk + 1 == nchunks ? 0 : chunk + 1);
+      // window rows of the first offset's entries (zero row: no neighbour / a row of another pass)
+      uint32_t wr[4], sl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sl[i] = wop_lds16(slot_rd + (uint32_t)((wave * BM + i * 32) * 2));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3])::"memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t local = sl[i] - (uint32_t)base;
+        wr[i] = local < (uint32_t)wp ? local : (uint32_t)WMAX;
+      }
       for (int t = 0; t < nk; ++t) {
         const int k = wave + 4 * t;
-        // window rows of this offset's 4 x 32 entries (zero row: no neighbour, or a row of another pass)
-        uint32_t abase[4], sw[4];
+        const bool more = t + 1 < nk;                // uniform
+        WopA fa, fb;
+        // ---- half-stage (k, first 16 channels of the chunk): weights w0 (landed)
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a(wr, 0, 0, fa);
+        issue_a(wr, 0, 2, fb);
+        load_w(k, chunk, 1, w1);
+        if (more) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sl[i] = wop_lds16(slot_rd + (uint32_t)(((k + 4) * BM + i * 32) * 2));
+          WOP_WAIT_LGKM(8, fa);
+        } else {
+          WOP_WAIT_LGKM(4, fa);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(w0, fa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a(wr, 1, 0, fa);
+        if (more) WOP_WAIT_LGKM(8, fb);
+        else WOP_WAIT_LGKM(4, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(w0, fb, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_a(wr, 1, 2, fb);
+        WOP_WAIT_VM0(w1);
+        // ---- half-stage (k, second 16 channels): weights w1; w0 <- the next offset's (or the next chunk's first)
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(more ? k + 4 : wave, more ? chunk : cnext, 0, w0);
+        WOP_WAIT_LGKM(4, fa);                        // the next offset's slots landed before these fragments
+        asm volatile("" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3]));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(w1, fa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        WOP_WAIT_LGKM(0, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(w1, fb, 2);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const uint32_t slot = slot_lds[k * BM + i * 32 + l31];
-          const uint32_t local = slot - (uint32_t)base;
-          const uint32_t wr = local < (uint32_t)wp ? local : (uint32_t)WMAX;
-          abase[i] = wr * 128u;
-          sw[i] = (wr >> 1) & 7u;
+          const uint32_t local = sl[i] - (uint32_t)base;
+          wr[i] = local < (uint32_t)wp ? local : (uint32_t)WMAX;
         }
-        const WF w1 = load_w(k, chunk, 1);
-        half_stage(w0, 0, abase, sw);
-        // next half-stage's weights: next offset of this chunk, else the first offset of the next chunk / pass (the last one of
-        // the tile re-reads its own: harmless, never used)
-        const bool more = t + 1 < nk;
-        const int kn = more ? k + 4 : wave;
-        const int cn = more ? chunk : (last_chunk ? chunk : (chunk + 1 == nchunks ? 0 : chunk + 1));
-        w0 = load_w(kn, cn, 0);
-        half_stage(w1, 1, abase, sw);
+        WOP_WAIT_VM0(w0);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      WOP_STAMP(3 + 3 * (chunk & 1));
     }
   }
 
   // ---- sum of the four partial accumulators: wave i ends up with row block i ---------------------------------------------
   __syncthreads();                                   // the window is free
-  float *red = reinterpret_cast<float *>(lds);       // [wave][j][r][lane]
+  WOP_STAMP(7);
+  // two rounds of two row blocks: in round b the waves write their partial sums of blocks 2 b and 2 b + 1 (the owner keeps its
+  // own), waves 2 b and 2 b + 1 sum them up: own part first, then the other waves' ascending - a fixed order
+  float *red = reinterpret_cast<float *>(lds);       // [block in round][writer: the 3 other waves][j][r][lane]: 2 x 3 x 8 KB
+  static_assert(WIN_BYTES >= 2 * 3 * 2 * 16 * 64 * 4, "the reduction reuses the window");
   f32x16 fin[1][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (wave != i) {
+  for (int b = 0; b < 2; ++b) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+    for (int u = 0; u < 2; ++u) {
+      const int i = 2 * b + u;
+      if (wave != i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[((wave * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (wave == i) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        fin[0][j] = acc[i][j];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          if (s == i) continue;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) fin[0][j][r] += red[((s * 2 + j) * 16 + r) * 64 + lane];
-        }
+          for (int r = 0; r < 16; ++r) red[(((u * 3 + (wave < i ? wave : wave - 1)) * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
       }
     }
     __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = 2 * b + u;
+      if (wave == i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          fin[0][j] = acc[i][j];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            if (s == i) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fin[0][j][r] += red[(((u * 3 + (s < i ? s : s - 1)) * 2 + j) * 16 + r) * 64 + lane];
+          }
+        }
+      }
+    }
+    if (b == 0) __syncthreads();
   }
+  WOP_STAMP(8);
   h2_store_tile<1, 2, EMIT>(a, fin, m0, 0, wave, 0, h, l31);
+  WOP_STAMP(9);
 }
 
 template <int WAVES, int WM, int WN, int TM, int TN, int WMAX>
@@ -803,7 +926,8 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st) {
       args.n_row_tiles = (int)((b.n_out + WIN_BM - 1) / WIN_BM);
       args.n_col_tiles = 1;
       const int grid = ((args.n_row_tiles + 7) / 8) * 8;
-      if (args.out_split != nullptr) hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, true>), dim3(grid), dim3(256), 0, st, args);
+      if (g_wop_trace_on) hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, false, true>), dim3(grid), dim3(256), 0, st, args);
+      else if (args.out_split != nullptr) hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, true>), dim3(grid), dim3(256), 0, st, args);
       else hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, false>), dim3(grid), dim3(256), 0, st, args);
       PH_LAUNCH_CHECK();
       return 0;

@@ -1,0 +1,69 @@
+"""Where does a workgroup of k_conv_wop (64-channel 3^3 window convolution) spend its life?  Shader-clock stamps of the
+first 64 workgroups (wave 0) of the largest 64 -> 64 launch of an S10 step, TRACE instantiation (development hook
+ph_wop_trace_enable / ph_wop_trace_read in conv_win.hip).
+    python tools/wop_trace.py > gpurun_out/wop_trace.txt"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from pasco_amd.graph.synth import TeacherKeep, make_scene
+from pasco_amd.me.backend import hip_backend
+
+dev = torch.device("cuda", 0)
+be = hip_backend()
+net = bench.build_net(3, 283, dev)
+scene = make_scene(0, n_infers=3).to(dev)
+tk = TeacherKeep(scene, dev)
+best = [None]
+inner = be.conv_fwd
+
+
+def spy(x, weight, nbr, n_out, **kw):
+    out = inner(x, weight, nbr, n_out, **kw)
+    cfg = be.conv_last_config()
+    if cfg["kernel"] == 5 and cfg["bn"] == 64 and (best[0] is None or n_out > best[0][3]):
+        best[0] = (x, weight, nbr, n_out, dict(kw))
+    return out
+
+
+with torch.no_grad():
+    bench.run_scene(net, scene, tk)
+    be.conv_fwd = spy
+    bench.run_scene(net, scene, tk)
+    be.conv_fwd = inner
+x, weight, nbr, n_out, kw = best[0]
+kw.pop("emit_split", None)
+kw["want_out"] = True
+lib = be.lib
+lib.ph_wop_trace_enable.argtypes = [C.c_int]
+lib.ph_wop_trace_read.argtypes = [C.c_void_p]
+ts = []
+for it in range(3):
+    if it == 2:
+        lib.ph_wop_trace_enable(1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    inner(x, weight, nbr, n_out, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) * 1e3)
+lib.ph_wop_trace_enable(0)
+buf = np.zeros(64 * 16, dtype=np.uint64)
+assert lib.ph_wop_trace_read(buf.ctypes.data) == 0
+st = buf.reshape(64, 16).astype(np.int64)
+names = ["setup (slot map, widx, first weights)", "window 0 issue -> landed + barrier", "offset loop, chunk 0",
+         "barrier + window 1 issue", "window 1 landed + barrier", "offset loop, chunk 1", "final barrier", "reduction of the partial sums",
+         "epilogue stores"]
+idx = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9)]
+print(f"launch n_out = {n_out}: {ts[1]:.1f} us plain, {ts[2]:.1f} us traced; {((n_out + 127) // 128)} tiles")
+tot = (st[:, 9] - st[:, 0]).astype(float)
+print(f"workgroup life (first 64 workgroups = first round): median {np.median(tot):.0f} clk, min {tot.min():.0f}, max {tot.max():.0f}")
+for nm, (a, b) in zip(names, idx):
+    d = (st[:, b] - st[:, a]).astype(float)
+    print(f"  {nm:45s} median {np.median(d):9.0f} clk  ({100 * np.median(d) / np.median(tot):5.1f} %)   min {d.min():9.0f}  max {d.max():9.0f}")
+print("matrix work of a wave: 7 offsets x 2 chunks x 48 MFMAs x 32 clk =", 7 * 2 * 48 * 32, "clk (two waves per SIMD share the pipe)")
