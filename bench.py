@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (matrix) = vector rate
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA peak
 HBM_PEAK_GBS = 8000.0
-SPLIT_KERNELS = ("k_conv_dma", "k_conv_h2", "k_conv_f16x3", "k_conv_rl", "k_conv_win", "k_conv_wide")   # 3 f16 MFMAs per product
+SPLIT_KERNELS = ("k_conv_dma", "k_conv_h2", "k_conv_f16x3", "k_conv_rl", "k_conv_win", "k_conv_wop", "k_conv_wide")   # 3 f16 MFMAs per product
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -114,8 +114,8 @@ def _roofs(name, flops, bytes_alg, time_s, bytes_min=None):
 
 
 def roofline_object(per_kernel, steps, classes=None):
-    """`roofline` for the dominant convolution kernel (most time in the timed region), the other convolution
-    kernels beside it, the operand-split passes, and the per-layer-class table."""
+    """`roofline`: the dominant LAYER CLASS (most time per step in the profiled pass) as the headline entry, every class
+    (`by_layer_class`) and every kernel name (`by_kernel`) beside it, and the operand-split passes."""
     def entry(name, s):
         avg = s["time_s"] / s["launches"]
         e = {"kernel": name, "launches_per_step": s["launches"] / steps, "avg_launch_us": round(avg * 1e6, 2),
@@ -134,28 +134,42 @@ def roofline_object(per_kernel, steps, classes=None):
         return e
 
     names = sorted((n for n in per_kernel if n.startswith("k_conv")), key=lambda n: -per_kernel[n]["time_s"])
-    out = entry(names[0], per_kernel[names[0]])
+    by_kernel = [entry(n, per_kernel[n]) for n in names]
+    rows = []
+    if classes:
+        for (cls, kern), s in sorted(classes.items(), key=lambda kv: -kv[1]["time_s"]):
+            r = {"class": cls, "kernel": kern, "launches_per_step": s["launches"] / steps,
+                 "ms_per_step": round(s["time_s"] / steps * 1e3, 3),
+                 "avg_launch_us": round(s["time_s"] / s["launches"] * 1e6, 1),
+                 "flops_per_launch": s["flops"] / s["launches"], "alg_bytes_per_launch": s["bytes_alg"] / s["launches"],
+                 "min_bytes_per_launch": s.get("bytes_min", 0.0) / s["launches"]}
+            r.update(_roofs(kern, s["flops"], s["bytes_alg"], s["time_s"], s.get("bytes_min")))
+            rows.append(r)
+    if rows:
+        # the headline entry = the LAYER CLASS with the most time (a kernel NAME like k_conv_dma serves k = 1 streams, small
+        # 3^3 maps and the 245-offset bottleneck at once: its average means nothing and its mix changes from round to round)
+        out = dict(rows[0])
+        out["dominant_by"] = "layer class (most time per step)"
+        same_name = [r for r in rows if r["kernel"] == out["kernel"]]
+        rec = pmc_record(out["kernel"])
+        out["traffic"] = None if rec is None else rec["hbm_bytes_per_launch"]
+        if rec is not None:
+            out["traffic_source"] = {"file": rec["file"], "commit": rec["commit"],
+                                     "note": "PMC FETCH_SIZE + WRITE_SIZE per launch, mean over the launches of this kernel name"
+                                             + ("" if len(same_name) == 1 else f" ({len(same_name)} layer classes run on it)")}
+    else:
+        out = dict(by_kernel[0])
     if HBM_COPY_GBS:
         out["hbm_box_copy_GBps"] = round(HBM_COPY_GBS, 1)       # float4 copy of 1 GiB on this box, read + write
     out["conv_ms_per_step"] = round(sum(per_kernel[n]["time_s"] for n in names) / steps * 1e3, 3)
-    if len(names) > 1:
-        out["other_conv_kernel"] = entry(names[1], per_kernel[names[1]])
-    if len(names) > 2:
-        out["more_conv_kernels"] = [entry(n, per_kernel[n]) for n in names[2:]]
+    out["by_kernel"] = by_kernel
     sp = per_kernel.get("k_split_rows")
     if sp:     # operand preparation of the split kernels (one pass per conv input, not per gather)
         out["operand_split"] = {"kernel": "k_split_rows", "launches_per_step": sp["launches"] / steps,
                                 "ms_per_step": round(sp["time_s"] / steps * 1e3, 3),
                                 "alg_GBps": round(sp["bytes_alg"] / sp["time_s"] / 1e9, 1),
                                 "traffic": pmc_traffic("k_split_rows")}
-    if classes:
-        rows = []
-        for (cls, kern), s in sorted(classes.items(), key=lambda kv: -kv[1]["time_s"]):
-            r = {"class": cls, "kernel": kern, "launches_per_step": s["launches"] / steps,
-                 "ms_per_step": round(s["time_s"] / steps * 1e3, 3),
-                 "avg_launch_us": round(s["time_s"] / s["launches"] * 1e6, 1)}
-            r.update(_roofs(kern, s["flops"], s["bytes_alg"], s["time_s"], s.get("bytes_min")))
-            rows.append(r)
+    if rows:
         out["by_layer_class"] = rows
     return out
 
@@ -501,8 +515,9 @@ def main():
     n1 = int(out["sem_logits_at_scales"][1][0].F.shape[0])
     window = []
     # per-launch HIP events only mean something when one scene runs at a time (kernels of two streams share the GPU):
-    # with several scenes in flight the roofline comes from the one-at-a-time pass below
+    # with several scenes in flight the roofline comes from a one-at-a-time pass of its own below
     prof.enabled = (not args.no_profile) and args.in_flight <= 1
+    prof_steps = args.steps
     # the cyclic garbage collector is paused over the timed steps (as a serving loop would): a generation-2
     # pass over the step's many small Python objects costs ~27 ms whenever it lands inside a step; the same
     # loop with the collector running is reported beside it (`gc_enabled`)
@@ -534,20 +549,32 @@ def main():
         per = [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])]
         print(f"[bench] per-step host ms: {per}", file=sys.stderr, flush=True)
     one_in_flight = None
-    if args.in_flight > 1 and world == 1:          # the same K steps, one scene at a time on one stream
+    if args.in_flight > 1 and world == 1:          # the same K steps, one scene at a time on one stream (no per-launch events)
         window = []
-        prof.enabled = not args.no_profile
+        mallocs0 = allocator_state(device).get("device_mallocs", 0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run_steps(0, args.steps, 1, window)
         torch.cuda.synchronize()
         dt1 = (time.perf_counter() - t0) / args.steps
-        prof.enabled = False
         one_in_flight = {"value": round(1.0 / dt1, 4), "unit": "scenes/s", "ms_per_step": round(dt1 * 1e3, 3),
                          "steps": args.steps}
         alloc_log["after_in_flight_1"] = allocator_state(device)
+        one_in_flight["device_mallocs"] = alloc_log["after_in_flight_1"].get("device_mallocs", 0) - mallocs0
         if window:      # the reference's own timing window (`self.unet3d`, README.md:448-449), one scene at a time
             one_in_flight["unet_window_ms"] = round(sum(a.elapsed_time(b) for a, b in window) / len(window), 3)
+        # the roofline's per-launch HIP events: a separate one-at-a-time pass, so that neither the events nor the pair
+        # counts the profiler launches perturb a reported step time
+        if not args.no_profile:
+            prof.enabled = True
+            mallocs0 = allocator_state(device).get("device_mallocs", 0)
+            kprof = max(8, args.steps // 2)
+            run_steps(0, kprof, 1)
+            torch.cuda.synchronize()
+            prof.enabled = False
+            prof_steps = kprof
+            alloc_log["after_profile_pass"] = allocator_state(device)
+            alloc_log["device_mallocs_in_profile_pass"] = alloc_log["after_profile_pass"].get("device_mallocs", 0) - mallocs0
     if gc_was_on:
         gc.enable()
 
@@ -641,7 +668,7 @@ def main():
         if not args.no_profile:
             per_kernel, classes = prof.summary(by_class=True)
             if per_kernel:
-                res["roofline"] = roofline_object(per_kernel, args.steps, classes)
+                res["roofline"] = roofline_object(per_kernel, prof_steps, classes)
         res["config"]["in_flight"] = args.in_flight
         res["host_threads"] = {"scene_threads_per_rank": max(args.in_flight, 1), "ranks": world,
                                "cpus_per_rank": len(pinned) if pinned else len(os.sched_getaffinity(0)),

@@ -58,30 +58,39 @@ def packed_allgather(parts: Sequence[torch.Tensor], group=None) -> Tuple[List[Li
     dist.all_gather(all_rows, rows, group=group)
     counts = torch.stack(all_rows).tolist()                       # the one host read of the step
     row_bytes = [p.element_size() * math.prod(p.shape[1:]) for p in parts]
-    sizes = [sum(c * b for c, b in zip(cnt, row_bytes)) for cnt in counts]
-    cap = max(max(sizes), 1)
-    cap = (cap + 15) // 16 * 16
-    mine = torch.empty(cap, dtype=torch.uint8, device=dev)
-    off = 0
-    for p, b in zip(parts, row_bytes):
+    ALIGN = 16                                                    # every part starts on a 16-byte boundary of the buffer: the
+                                                                  # typed views below need offset % element_size == 0 whatever
+                                                                  # the row counts and dtypes of the parts before it are
+
+    def layout(cnt):                                              # byte offset of every part for one rank's row counts
+        offs, off = [], 0
+        for c, b in zip(cnt, row_bytes):
+            offs.append(off)
+            off = (off + c * b + ALIGN - 1) // ALIGN * ALIGN
+        return offs, off
+
+    sizes = [layout(cnt)[1] for cnt in counts]
+    cap = max(max(sizes), ALIGN)
+    mine = torch.zeros(cap, dtype=torch.uint8, device=dev)        # padding between and behind the parts is zero
+    offs, _ = layout([int(p.shape[0]) for p in parts])
+    payload = 0
+    for p, b, off in zip(parts, row_bytes, offs):
         nb = int(p.shape[0]) * b
+        payload += nb
         if nb:
             mine[off:off + nb] = p.contiguous().view(-1).view(torch.uint8)
-        off += nb
-    if off < cap:
-        mine[off:].zero_()
     box = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(box, mine, group=group)
     out = []
     for r in range(world):
-        off, got = 0, []
-        for p, b, c in zip(parts, row_bytes, counts[r]):
+        offs, _ = layout(counts[r])
+        got = []
+        for p, b, c, off in zip(parts, row_bytes, counts[r], offs):
             nb = c * b
             t = box[r][off:off + nb].view(p.dtype).view((c,) + tuple(p.shape[1:])) if nb else p.new_zeros((0,) + tuple(p.shape[1:]))
             got.append(t)
-            off += nb
         out.append(got)
-    return out, {"bytes_sent": int(sizes[dist.get_rank(group)]), "bytes_padded": int(cap), "collectives": 2}
+    return out, {"bytes_sent": int(payload), "bytes_padded": int(cap), "collectives": 2}
 
 
 def cpu_list(text: str) -> List[int]:

@@ -6,12 +6,15 @@ ONE net (shared weights and operand caches; per-stream workspaces, status words 
 backend / the modules, keyed by stream).  Reference counterpart: the Lightning predict loop around
 `Net.step_inference` (pasco/models/net_panoptic_sparse.py:539-576), which serves one scene at a time.
 
-Memory: every buffer of a step comes from torch's caching allocator, per stream.  `warm` runs every scene shape on every
-stream (graph captures one at a time), then the in-flight loop itself until the allocator has stopped asking the driver
-for memory - so that a timed or served loop performs no device malloc - and `vet_cached_blocks` write-tests every large
-block the allocator then holds: a block that streams at less than half the rate of its peers is quarantined (kept
-allocated, never handed out) and replaced by a fresh one (rounds 2 - 3 saw whole runs in which ONLY the launches writing
-the step's largest buffers were 7 x slow; which physical pages back a block is the driver's choice, this makes it ours).
+Memory: every buffer of a step comes from torch's caching allocator, per stream.  A device allocation inside a served loop
+is what rounds 2 - 3 called the "slow mode": a request the cache cannot serve goes to the driver, which costs ~0.02 ms on
+some boxes of the pool and several ms on others, stalls the launch that waits for it and - several scenes in flight - every
+stream; it hit whichever launches allocated the step's largest outputs (the 970 MB K / V operands then; profiles/README.md,
+round 4).  `warm` therefore runs every scene shape on every stream (graph captures one at a time) and then the in-flight
+loop itself until a whole round needed no device allocation, with requests rounded to 1/8 of a power of two so that scenes
+of slightly different size reuse each other's blocks.  `vet_cached_blocks` is the diagnostic that ruled the other suspect
+out (slow physical memory behind some blocks): it write-tests every large block the allocator holds after the warm-up,
+quarantines and replaces a block that streams at less than half the rate of its peers, and reports the rates.
 """
 from __future__ import annotations
 

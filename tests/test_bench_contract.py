@@ -20,21 +20,23 @@ def test_roofline_object_fields():
     classes = {("k3 C=64", "k_conv_h2"): dict(launches=60, time_s=0.05, flops=1.0e13, bytes_alg=2.0e11),
                ("k3 C=256", "k_conv_dma"): dict(launches=60, time_s=0.04, flops=2.0e13, bytes_alg=0.6e11)}
     r = bench.roofline_object(per_kernel, steps=10, classes=classes)
-    # both roofs are reported; `bound` is the one the kernel sits closer to
-    hbm_frac = 8.1e11 / 0.27 / 1e9 / 8000.0
-    mfma_frac = 3 * 4.7e13 / 0.27 / 1e12 / 2500.0
-    assert r["kernel"] == "k_conv_h2" and abs(r["alg_frac_of_hbm_peak"] - hbm_frac) < 1e-3
-    assert abs(r["mfma_frac_of_peak"] - mfma_frac) < 1e-3
+    # the headline entry is the LAYER CLASS with the most time; both roofs are reported, `bound` is the one it sits closer to
+    assert r["class"] == "k3 C=64" and r["kernel"] == "k_conv_h2" and r["dominant_by"].startswith("layer class")
+    hbm_frac = 2.0e11 / 0.05 / 1e9 / 8000.0
+    mfma_frac = 3 * 1.0e13 / 0.05 / 1e12 / 2500.0
+    assert abs(r["alg_frac_of_hbm_peak"] - hbm_frac) < 1e-3 and abs(r["mfma_frac_of_peak"] - mfma_frac) < 1e-3
     assert r["bound"] == ("hbm" if hbm_frac >= mfma_frac else "mfma") and abs(r["frac"] - max(hbm_frac, mfma_frac)) < 1e-3
     assert r["unit"] == ("GB/s" if r["bound"] == "hbm" else "TFLOP/s")
+    assert r["launches_per_step"] == 6.0 and abs(r["avg_launch_us"] - 0.05 / 60 * 1e6) < 0.1
+    assert r["alg_bytes_per_launch"] == 2.0e11 / 60 and "traffic" in r
     rows = {x["class"]: x for x in r["by_layer_class"]}
     assert rows["k3 C=256"]["bound"] == "mfma" and rows["k3 C=256"]["kernel"] == "k_conv_dma"
     assert rows["k3 C=64"]["bound"] == "hbm"
-    # compulsory bytes (SURVEY.md 8(d) B_min) ride next to the algorithmic ones
-    assert abs(r["min_frac_of_hbm_peak"] - 2.7e11 / 0.27 / 1e9 / 8000.0) < 1e-3 and r["min_bytes_per_launch"] == 2.7e11 / 1120
-    assert r["launches_per_step"] == 112.0 and abs(r["avg_launch_us"] - 0.27 / 1120 * 1e6) < 0.01
-    assert r["other_conv_kernel"]["kernel"] == "k_conv_mfma" and r["other_conv_kernel"]["bound"] == "mfma"
-    assert r["other_conv_kernel"]["peak"] == 157.3
+    # per kernel name beside it (compulsory bytes B_min of SURVEY.md 8(d) next to the algorithmic ones)
+    k = {x["kernel"]: x for x in r["by_kernel"]}
+    assert abs(k["k_conv_h2"]["min_frac_of_hbm_peak"] - 2.7e11 / 0.27 / 1e9 / 8000.0) < 1e-3
+    assert k["k_conv_h2"]["min_bytes_per_launch"] == 2.7e11 / 1120 and k["k_conv_h2"]["launches_per_step"] == 112.0
+    assert k["k_conv_mfma"]["bound"] == "mfma" and k["k_conv_mfma"]["peak"] == 157.3
     assert r["operand_split"]["kernel"] == "k_split_rows" and r["operand_split"]["launches_per_step"] == 41.0
     assert abs(r["conv_ms_per_step"] - (0.27 + 0.0066) / 10 * 1e3) < 1e-3     # the split passes are not a conv kernel
     json.dumps(r)
