@@ -279,6 +279,17 @@ int PH_FN(gather_rows)(const void *src, int32_t c, const int32_t *rows, int64_t 
 int PH_FN(scatter_add_rows)(const float *src, int32_t c, const int32_t *rows, int64_t n_src,
                             float *dst, ph_stream_t stream);
 
+/* Keep masks of the decoder in one pass (decoder_v3.py:148-158 completion keep = OR over the subnets' occupied masks;
+ * :411-420 panoptic keep = occupied, or the first 1000 rows when nothing is occupied, AND inside the subnet's box):
+ *   out[r] = K[r] && lo <= coords[r].xyz <= hi,   K[r] = OR_i kept_i[r]
+ * srcs: HOST array of n_src <= 8 device pointers, all of one kind: 0 = bytes (non-zero = kept), 1 = int32 (>= 0 = kept: the
+ * rows ph_map_find returns).  lo / hi: device int32[3] or both NULL (no box test; coords may then be NULL).
+ * fallback_rows > 0: when K is false everywhere, K[r] = (r < fallback_rows) instead - decided on the device through the
+ * scratch word any_word (int32, clobbered).  out: bytes 0 / 1. */
+int PH_FN(keep_mask)(const void *const *srcs, int32_t n_src, int32_t kind, const int32_t *coords, int64_t n,
+                     const int32_t *lo, const int32_t *hi, int64_t fallback_rows, uint8_t *out, int32_t *any_word,
+                     ph_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Semantic ensembling on the canonical grid in one pass (Ensembler.ensemble_sem_compl + the confidence map of
  * Net.forward: pasco/models/ensembler.py:159-187, net_panoptic_sparse.py:252-310).  For every canonical site s and every

@@ -898,6 +898,32 @@ int pho_pos_aug(const int32_t *coords, int64_t n, const float *eps, int32_t tab_
   return 0;
 }
 
+/* keep masks of the decoder (decoder_v3.py:148-158, 411-420; include/pasco_hip.h keep_mask) */
+int pho_keep_mask(const void *const *srcs, int32_t n_src, int32_t kind, const int32_t *coords, int64_t n, const int32_t *lo,
+                  const int32_t *hi, int64_t fallback_rows, uint8_t *out, int32_t *any_word, ph_stream_t stream) {
+  (void)stream; (void)any_word;
+  if (n_src < 1 || n_src > 8 || (kind != 0 && kind != 1) || n < 0 || fallback_rows < 0) return fail("keep_mask: bad arguments");
+  if ((lo == NULL) != (hi == NULL) || (lo != NULL && coords == NULL)) return fail("keep_mask: bounds need lo, hi and coords");
+  int any = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    int k = 0;
+    for (int i = 0; i < n_src; ++i)
+      k = k || (kind == 1 ? ((const int32_t *)srcs[i])[r] >= 0 : ((const uint8_t *)srcs[i])[r] != 0);
+    out[r] = (uint8_t)k;
+    any |= k;
+  }
+  for (int64_t r = 0; r < n; ++r) {
+    int k = out[r];
+    if (!any && fallback_rows > 0) k = r < fallback_rows;
+    if (k && lo != NULL) {
+      const int32_t *c = coords + r * 4 + 1;
+      k = c[0] >= lo[0] && c[1] >= lo[1] && c[2] >= lo[2] && c[0] <= hi[0] && c[1] <= hi[1] && c[2] <= hi[2];
+    }
+    out[r] = (uint8_t)k;
+  }
+  return 0;
+}
+
 int pho_bits_orpool(const uint32_t *bits_in, const int32_t *nbr, int32_t kvol, int64_t n_out, uint32_t *bits_out,
                     ph_stream_t stream) {
   (void)stream;

@@ -59,6 +59,71 @@ extern "C" int ph_scatter_add_rows(const float *src, int32_t c, const int32_t *r
   return 0;
 }
 
+// ---- keep masks of the decoder in one pass (ph_keep_mask) ---------------------------------------------------------------
+// out[r] = K[r] && (lo <= coords[r].xyz <= hi), K[r] = OR over the sources of "kept" (kind 0: byte != 0; kind 1: int32 >= 0, the
+// output of ph_map_find).  k_keep_mask also raises *any when some K[r] holds; k_keep_fallback (a few workgroups, always
+// launched) rewrites the first `fallback` rows to the bounds test alone when nothing was kept - the reference's "nothing kept
+// -> keep the first 1000 rows" (decoder_v3.py:415-418), decided on the device.
+struct KeepSrcs {
+  const void *p[8];
+};
+__global__ void __launch_bounds__(256)
+    k_keep_mask(KeepSrcs srcs, int n_src, int kind, const int4 *__restrict__ coords, int64_t n, const int32_t *__restrict__ lo,
+                const int32_t *__restrict__ hi, uint8_t *__restrict__ out, int32_t *__restrict__ any) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool k = false;
+  if (r < n) {
+    for (int i = 0; i < n_src; ++i)
+      k = k || (kind == 1 ? reinterpret_cast<const int32_t *>(srcs.p[i])[r] >= 0 : reinterpret_cast<const uint8_t *>(srcs.p[i])[r] != 0);
+  }
+  if (any != nullptr && __ballot(k) != 0ull && (threadIdx.x & 63) == 0) {
+    if (__hip_atomic_load(any, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(any, 1);
+  }
+  if (r >= n) return;
+  bool inside = true;
+  if (lo != nullptr) {
+    const int4 c = coords[r];
+    inside = c.y >= lo[0] && c.z >= lo[1] && c.w >= lo[2] && c.y <= hi[0] && c.z <= hi[1] && c.w <= hi[2];
+  }
+  out[r] = (k && inside) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256)
+    k_keep_fallback(const int4 *__restrict__ coords, int64_t n, int64_t fallback, const int32_t *__restrict__ lo,
+                    const int32_t *__restrict__ hi, uint8_t *__restrict__ out, const int32_t *__restrict__ any) {
+  if (*any != 0) return;
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n || r >= fallback) return;
+  bool inside = true;
+  if (lo != nullptr) {
+    const int4 c = coords[r];
+    inside = c.y >= lo[0] && c.z >= lo[1] && c.w >= lo[2] && c.y <= hi[0] && c.z <= hi[1] && c.w <= hi[2];
+  }
+  out[r] = inside ? 1 : 0;
+}
+
+extern "C" int ph_keep_mask(const void *const *srcs, int32_t n_src, int32_t kind, const int32_t *coords, int64_t n,
+                            const int32_t *lo, const int32_t *hi, int64_t fallback_rows, uint8_t *out, int32_t *any_word,
+                            ph_stream_t stream) {
+  PH_REQUIRE(n_src >= 1 && n_src <= 8 && (kind == 0 || kind == 1) && n >= 0 && fallback_rows >= 0, "keep_mask: bad arguments");
+  PH_REQUIRE((lo == nullptr) == (hi == nullptr) && (lo == nullptr || coords != nullptr), "keep_mask: bounds need lo, hi and coords");
+  PH_REQUIRE(fallback_rows == 0 || any_word != nullptr, "keep_mask: the fallback needs the scratch word");
+  if (n == 0) return 0;
+  KeepSrcs ks;
+  for (int i = 0; i < 8; ++i) ks.p[i] = i < n_src ? srcs[i] : nullptr;
+  hipStream_t st = ph_stream(stream);
+  int32_t *any = fallback_rows > 0 ? any_word : nullptr;
+  if (any) PH_CHECK_HIP(hipMemsetAsync(any, 0, sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_keep_mask, dim3(nblk(n, 256)), dim3(256), 0, st, ks, n_src, kind, (const int4 *)coords, n, lo, hi, out, any);
+  PH_LAUNCH_CHECK();
+  if (any) {
+    const int64_t m = n < fallback_rows ? n : fallback_rows;
+    hipLaunchKernelGGL(k_keep_fallback, dim3(nblk(m, 256)), dim3(256), 0, st, (const int4 *)coords, n, fallback_rows, lo, hi, out,
+                       any);
+    PH_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 // ---- local max pooling ----------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
     k_maxpool(const float *__restrict__ in, int c, const int32_t *__restrict__ nbr, int kvol,

@@ -218,11 +218,33 @@ class DecoderGenerativeSepConvV2(nn.Module):
         # argmax(softmax(l)) != 0  <=>  argmax(l) != 0   (decoder_v3.py:337-339, :411-414)
         return logits.F.argmax(dim=-1) != 0
 
-    def _keep_completion(self, x, scale, sem_logits, keep_override):
+    @staticmethod
+    def _keep_sources(keep_override, scale, i, x, logits):
+        """What says "kept" for subnet i at this level: the override's lookup rows (int32, >= 0 = kept) or a bool mask."""
         if keep_override is not None:
-            keeps = [keep_override.member(scale, i, x.C) for i in range(self.n_infers)]
-        else:
-            keeps = [self._occupied(l) for l in sem_logits]
+            if hasattr(keep_override, "member_rows"):
+                return keep_override.member_rows(scale, i, x.C)
+            return keep_override.member(scale, i, x.C)
+        return DecoderGenerativeSepConvV2._occupied(logits)
+
+    @staticmethod
+    def _fused_keep(x):
+        """The backend whose `keep_mask` (one pass per mask instead of ~10 element-wise torch kernels) serves x, or None."""
+        if not fused.fusion() or x.C.dtype != torch.int32 or len(x.C.shape) != 2 or x.C.shape[1] != 4:
+            return None
+        try:
+            be = x.coordinate_manager.backend()
+        except Exception:
+            return None
+        return be if be.has("keep_mask") and os.environ.get("PASCO_KEEP_FUSED", "1") != "0" else None
+
+    def _keep_completion(self, x, scale, sem_logits, keep_override):
+        srcs = [self._keep_sources(keep_override, scale, i, x, sem_logits[i] if sem_logits is not None else None)
+                for i in range(self.n_infers)]
+        be = self._fused_keep(x)
+        if be is not None and len(srcs) <= 8 and len({s.dtype for s in srcs}) == 1:
+            return be.keep_mask([s.contiguous() for s in srcs])          # OR over the subnets, one pass
+        keeps = [s >= 0 if s.dtype == torch.int32 else s for s in srcs]
         keep = keeps[0]
         for k in keeps[1:]:
             keep = keep | k
@@ -235,7 +257,14 @@ class DecoderGenerativeSepConvV2(nn.Module):
 
         def keep_mask(i, scale, x):
             logits = sem_logits_at_scales[scale][i]
-            keep = keep_override.member(scale, i, x.C) if keep_override is not None else self._occupied(logits)
+            src = self._keep_sources(keep_override, scale, i, x, logits)
+            be = self._fused_keep(x)
+            if be is not None:
+                # occupied (or, when nothing is: the first 1000 rows, decoder_v3.py:415-418) AND inside the subnet's box
+                # (:151-158), decided on the device in one pass
+                lo, hi = _corner(min_Cs[i], x.C).reshape(3), _corner(max_Cs[i], x.C).reshape(3)
+                return be.keep_mask([src.contiguous()], x.C.contiguous(), lo.contiguous(), hi.contiguous(), fallback_rows=1000)
+            keep = src >= 0 if src.dtype == torch.int32 else src
             # reference fallback (decoder_v3.py:415-418): nothing kept -> keep the first 1000 rows.  Selected on the
             # device (no host read of the count)
             first = _first_rows(keep.shape[0], keep.device)

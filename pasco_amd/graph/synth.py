@@ -146,9 +146,13 @@ class TeacherKeep:
                 tk, tv, _, _, _ = self.be.map_insert(c4, dedup=False)
                 self.tables[(s, i)] = (tk, tv)
 
-    def member(self, scale: int, i: int, coords: torch.Tensor) -> torch.Tensor:
+    def member_rows(self, scale: int, i: int, coords: torch.Tensor) -> torch.Tensor:
+        """int32 [N]: row of the coordinate in the keep set (>= 0 = member) - what `CBackend.keep_mask` takes as a source."""
         tk, tv = self.tables[(scale, i)]
         q = coords.to(torch.int32).contiguous()
         # the graph's tensors carry batch index 0 (MIMO merge); the tables are keyed with batch 0 as well.
         # No host read here: this sits inside the timed region of the benchmark.
-        return self.be.map_find(q, tk, tv) >= 0
+        return self.be.map_find(q, tk, tv)
+
+    def member(self, scale: int, i: int, coords: torch.Tensor) -> torch.Tensor:
+        return self.member_rows(scale, i, coords) >= 0

@@ -118,6 +118,7 @@ _SIGNATURES = {
     "attn_cross_split": [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "attn_cross_feat": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "pos_aug": [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp],
+    "keep_mask": [_vp, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp],
     "points_bounds": [_vp, _i64, _vp, _vp],
     "points_mark": [_vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "mask_compact_rank": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
@@ -836,6 +837,42 @@ class CBackend:
         self._check(rc, "dense_gather")
         return feats
 
+
+    def keep_mask(self, srcs, coords: Optional[torch.Tensor] = None, lo: Optional[torch.Tensor] = None,
+                  hi: Optional[torch.Tensor] = None, fallback_rows: int = 0) -> torch.Tensor:
+        """bool [n]: OR over `srcs` (all bool / uint8 "kept" masks, or all int32 row tensors where >= 0 means kept - what
+        `map_find` returns) AND the inclusive box test lo <= coords[:, 1:4] <= hi (device int32 [3] each, or both None);
+        fallback_rows > 0: when nothing is kept at all, the first `fallback_rows` rows count as kept instead (decided on the
+        device).  One pass (include/pasco_hip.h keep_mask) instead of a dozen element-wise torch kernels per mask."""
+        srcs = list(srcs)
+        kind = 1 if srcs[0].dtype == torch.int32 else 0
+        n = srcs[0].shape[0]
+        dev = srcs[0].device
+        for t in srcs:
+            if t.shape != (n,) or not t.is_contiguous() or (t.dtype == torch.int32) != (kind == 1) or \
+                    (kind == 0 and t.dtype not in (torch.bool, torch.uint8)):
+                raise ValueError("keep_mask: sources must be contiguous [n] tensors, all int32 or all bool / uint8")
+        if (lo is None) != (hi is None):
+            raise ValueError("keep_mask: give both corners or neither")
+        if lo is not None:
+            self._chk(coords, torch.int32, "coords")
+            self._chk(lo, torch.int32, "lo")
+            self._chk(hi, torch.int32, "hi")
+            if coords.shape != (n, 4) or lo.numel() != 3 or hi.numel() != 3:
+                raise ValueError("keep_mask: coords [n, 4], corners [3]")
+        out = torch.empty((n,), dtype=torch.bool, device=dev)
+        ptrs = (_vp * len(srcs))(*[_ptr(t) for t in srcs])
+        word = None
+        if fallback_rows > 0:
+            key = ("keep_any",) + self._stream_key(dev)
+            word = self._ws.get(key)
+            if word is None:
+                word = torch.zeros(1, dtype=torch.int32, device=dev)
+                self._ws[key] = word
+        rc = self.fn["keep_mask"](C.cast(ptrs, _vp), len(srcs), kind, _ptr(coords) if lo is not None else None, n, _ptr(lo),
+                                  _ptr(hi), int(fallback_rows), _ptr(out), _ptr(word), self.stream(dev))
+        self._check(rc, "keep_mask")
+        return out
 
     # -- attention -----------------------------------------------------------------------------------
     def attn_mask_pack(self, vals: torch.Tensor, b: int, n: int, positive_only: bool = False, want_any: bool = True):

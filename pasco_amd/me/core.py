@@ -460,8 +460,13 @@ class SparseTensor:
         be = self._manager.backend()
         key, a2o, b2o = self._manager.union(self.coordinate_map_key, other.coordinate_map_key)
         n_out = self._manager.size(key)
-        out = torch.zeros((n_out, self._F.shape[1]), dtype=self._F.dtype, device=self._F.device)
-        be.scatter_add_rows(self._F.contiguous(), a2o.contiguous(), out)
+        # the union lists the lhs rows first, in their order (a map's coordinates are unique, so every lhs row is its own first
+        # occurrence): the lhs features are a plain copy into the leading rows, only the rhs rows are scattered
+        na = self._F.shape[0]
+        out = torch.empty((n_out, self._F.shape[1]), dtype=self._F.dtype, device=self._F.device)
+        out[:na].copy_(self._F)
+        if n_out > na:
+            out[na:].zero_()
         be.scatter_add_rows(other._F.contiguous(), b2o.contiguous(), out)
         return SparseTensor(out, coordinate_map_key=key, coordinate_manager=self._manager)
 

@@ -186,16 +186,18 @@ def test_subnet_parallel_forward_nccl_world1(hip):
         dist.destroy_process_group()
 
 
-def test_two_scenes_in_flight_match_one_at_a_time(hip):
-    """bench.py's default serving shape: worker threads, each bound to its own HIP stream, run different scenes at
-    the same time through ONE net (shared weights / operand caches; per-stream workspaces and query-side graphs).
-    Every scene's outputs must equal what the same scene gives alone on the default stream."""
-    import threading
+@pytest.mark.parametrize("n_flight", [2, 3])
+def test_scenes_in_flight_match_one_at_a_time(hip, n_flight):
+    """bench.py's serving shape (`pasco_amd.graph.serve.SceneServer`, default 3 in flight): worker threads, each bound to its
+    own HIP stream, run different scenes at the same time through ONE net (shared weights / operand caches; per-stream
+    workspaces, status words and query-side graphs).  Every scene's outputs must equal, bit for bit, what the same scene
+    gives alone on the default stream - also after the server's own warm-up (allocator settling, block write test)."""
     from pasco_amd.graph import PascoNet
+    from pasco_amd.graph.serve import SceneServer, vet_cached_blocks
     dev = torch.device("cuda", 0)
     torch.manual_seed(21)
     net = PascoNet(n_classes=20, n_infers=2, in_channels=16, f=32, num_queries=20, heavy_decoder=False).eval().to(dev)
-    scenes = [make_scene(40 + i, n_infers=2, in_channels=16, grid=(96, 96, 16), occupancy=0.12).to(dev) for i in range(2)]
+    scenes = [make_scene(40 + i, n_infers=2, in_channels=16, grid=(96, 96, 16), occupancy=0.12).to(dev) for i in range(n_flight)]
     teachers = [TeacherKeep(sc, dev) for sc in scenes]
 
     def step(j):
@@ -207,33 +209,16 @@ def test_two_scenes_in_flight_match_one_at_a_time(hip):
                [p["query_logits"].clone() for p in ret["panop_predictions"]] + [t.clone() for t in sem] + [t.clone() for t in conf]
 
     with torch.no_grad():
-        ref = [step(j) for j in range(2)]
-        torch.cuda.synchronize()
-        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-        for j, s in enumerate(streams):          # graph captures happen here, one stream at a time
-            s.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(s):
-                step(j)
-            s.synchronize()
-    got, errors = {}, []
-
-    def worker(j):
-        try:
-            torch.cuda.set_device(dev)
-            with torch.cuda.stream(streams[j]), torch.no_grad():
-                for _ in range(4):
-                    got[j] = step(j)
-            streams[j].synchronize()
-        except BaseException as e:
-            errors.append(e)
-
-    threads = [threading.Thread(target=worker, args=(j,)) for j in range(2)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    assert not errors, errors
-    for j in range(2):
+        ref = [step(j) for j in range(n_flight)]
+    torch.cuda.synchronize()
+    server = SceneServer(dev, step, in_flight=n_flight)
+    info = server.warm(range(n_flight), max_rounds=3)
+    vet = vet_cached_blocks(dev, [torch.cuda.current_stream(dev)] + server.streams, min_bytes=8 << 20)
+    assert vet["quarantined"] == 0 or vet["replaced"] == vet["quarantined"]
+    got = {}
+    server.run([j for _ in range(4) for j in range(n_flight)], on_done=lambda j, out: got.__setitem__(j, out))
+    assert info["in_flight_rounds"] >= 1 and sorted(got) == list(range(n_flight))
+    for j in range(n_flight):
         assert len(got[j]) == len(ref[j])
         for a, b in zip(got[j], ref[j]):
             assert a.shape == b.shape and torch.equal(a, b)

@@ -388,3 +388,23 @@ def test_project_canonical_matches_oracle_bit_for_bit(hip, oracle):
         exp = oracle.project_canonical(T, CANONICAL_SIZE, RESOLUTION, MIN_BOUND)
         got = hip.project_canonical(T.cuda(), CANONICAL_SIZE, RESOLUTION, MIN_BOUND).cpu()
         assert torch.equal(got, exp)
+
+
+def test_keep_mask_matches_oracle(hip, oracle):
+    """ph_keep_mask (decoder keep masks in one pass) bit for bit against the oracle: both source kinds, OR over several
+    sources, box test, the "nothing kept -> first rows" fallback decided on the device, ragged sizes."""
+    g = torch.Generator().manual_seed(11)
+    for n in (1, 63, 64, 1000, 1001, 70001):
+        coords = torch.randint(-5, 60, (n, 4), generator=g, dtype=torch.int32)
+        lo, hi = torch.tensor([0, 3, -2], dtype=torch.int32), torch.tensor([40, 50, 30], dtype=torch.int32)
+        rows = [torch.randint(-3, 2, (n,), generator=g, dtype=torch.int32) for _ in range(3)]
+        masks = [(r >= 0).contiguous() for r in rows]
+        none = torch.full((n,), -1, dtype=torch.int32)
+        cases = [dict(srcs=rows), dict(srcs=masks), dict(srcs=[rows[0]], coords=coords, lo=lo, hi=hi, fallback_rows=1000),
+                 dict(srcs=[none], coords=coords, lo=lo, hi=hi, fallback_rows=1000), dict(srcs=[none], coords=coords, lo=lo, hi=hi),
+                 dict(srcs=[masks[1]], coords=coords, lo=lo, hi=hi, fallback_rows=5)]
+        for kw in cases:
+            exp = oracle.keep_mask(**kw)
+            dkw = {k: ([t.cuda() for t in v] if k == "srcs" else (v.cuda() if torch.is_tensor(v) else v)) for k, v in kw.items()}
+            got = hip.keep_mask(**dkw)
+            assert got.dtype == torch.bool and torch.equal(got.cpu(), exp), (n, sorted(kw))

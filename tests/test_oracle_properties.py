@@ -207,3 +207,24 @@ def test_rowlist_promise_is_checked_on_the_device(oracle):
     ident = torch.arange(cu.shape[0], dtype=torch.int32).reshape(1, -1).contiguous()      # a one-pair map: silent
     oracle.rowlist_build(ident)
     oracle.check_status(dev)
+
+
+def test_keep_mask_matches_the_torch_formulation(oracle):
+    """`keep_mask` (one pass) against the element-wise torch formulation of decoder_v3.py:148-158, 411-420: OR over the
+    sources, the "nothing kept -> first rows" fallback, the inclusive box test; both source kinds."""
+    g = torch.Generator().manual_seed(3)
+    n = 5000
+    coords = torch.randint(-5, 60, (n, 4), generator=g, dtype=torch.int32)
+    lo, hi = torch.tensor([0, 3, -2], dtype=torch.int32), torch.tensor([40, 50, 30], dtype=torch.int32)
+    inside = ((coords[:, 1:] >= lo) & (coords[:, 1:] <= hi)).all(dim=1)
+    rows = [torch.randint(-3, 2, (n,), generator=g, dtype=torch.int32) for _ in range(3)]
+    masks = [r >= 0 for r in rows]
+    want_or = masks[0] | masks[1] | masks[2]
+    assert torch.equal(oracle.keep_mask(rows), want_or)
+    assert torch.equal(oracle.keep_mask([m.contiguous() for m in masks]), want_or)
+    assert torch.equal(oracle.keep_mask([rows[0]], coords, lo, hi, fallback_rows=1000), masks[0] & inside)
+    none = torch.full((n,), -1, dtype=torch.int32)
+    first = torch.arange(n) < 1000
+    assert torch.equal(oracle.keep_mask([none], coords, lo, hi, fallback_rows=1000), first & inside)
+    assert torch.equal(oracle.keep_mask([none], coords, lo, hi), torch.zeros(n, dtype=torch.bool))
+    assert oracle.keep_mask([torch.zeros(0, dtype=torch.int32)]).shape == (0,)

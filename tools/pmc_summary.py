@@ -24,6 +24,24 @@ def per_kernel(path, counter):
     return out
 
 
+def per_shape(path, counter):
+    """(kernel instantiation, grid, workgroup) -> (mean KiB per dispatch, dispatches): one row per distinct launch shape, i.e.
+    per layer (the maps of a step have distinct row counts), so that a layer CLASS can be read off the committed summary."""
+    per = defaultdict(float)
+    meta = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") != counter:
+                continue
+            key = (r.get("Dispatch_Id"), r.get("Agent_Id"))
+            per[key] += float(r["Counter_Value"])
+            meta[key] = (r.get("Kernel_Name", "").replace("void ", "").split("(")[0], int(r.get("Grid_Size", 0)), int(r.get("Workgroup_Size", 0)))
+    acc = defaultdict(list)
+    for k, v in per.items():
+        acc[meta[k]].append(v)
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 res = {"commit": sys.argv[4] if len(sys.argv) > 4 else None, "kernels": {}, "note": "FETCH_SIZE doubled (gfx950 128-B requests tallied at 64 B); Infinity-Cache hits are counted, "
@@ -34,5 +52,15 @@ for kern in fetch:
         w, n2 = write[kern]
         res["kernels"][kern] = {"dispatches": [n1, n2], "FETCH_SIZE_KiB_mean": f, "WRITE_SIZE_KiB_mean": w,
                                 "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+fs, ws = per_shape(sys.argv[1], "FETCH_SIZE"), per_shape(sys.argv[2], "WRITE_SIZE")
+shapes = []
+for key in sorted(fs, key=lambda k: -(2.0 * fs[k][0] + ws.get(k, (0.0, 0))[0]) * fs[k][1]):
+    if key not in ws:
+        continue
+    name, grid, wg = key
+    shapes.append({"kernel": name, "workgroups": grid // max(wg, 1), "workgroup_size": wg, "dispatches": [fs[key][1], ws[key][1]],
+                   "hbm_MB_per_launch": round((2.0 * fs[key][0] + ws[key][0]) * 1024.0 / 1e6, 2),
+                   "fetch_MB": round(2.0 * fs[key][0] * 1024.0 / 1e6, 2), "write_MB": round(ws[key][0] * 1024.0 / 1e6, 2)})
+res["by_launch_shape"] = shapes
 json.dump(res, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(res))
+print(json.dumps({k: v for k, v in res.items() if k != "by_launch_shape"}))
