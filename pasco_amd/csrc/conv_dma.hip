@@ -25,6 +25,10 @@
 
 #include "conv_h2_common.h"
 
+// kernel volumes above this are the bottleneck's (7, 7, 5) implicit GEMMs: their empty (tile, offset) stages are dropped and their
+// slices interleaved (measured: 544 -> 478 us on the 245-offset products; the 75-offset ones, whose light and heavy tiles cannot
+// balance over 4 slices, lose 4 % to the bookkeeping and stay as they were: profiles/r4p_layer_ab_dense_stage_skip.txt)
+constexpr int DMA_DENSE_KVOL = 100;
 constexpr int DMA_KMAX = 32;   // kernel offsets one workgroup walks (its slice of the split over the offsets)
 
 // Development hook: bit 8 of the mask selects the 256-row / 8-wave tiles (measured no faster: one workgroup per CU convoys).
@@ -80,12 +84,21 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
   int k_begin = (int)blockIdx.y * kper;
   const int k_end = (k_begin + kper < a.kvol) ? k_begin + kper : a.kvol;
   int kcount = k_end > k_begin ? k_end - k_begin : 0;
+  // dense implicit GEMMs (kvol > DMA_DENSE_KVOL) slice the offsets INTERLEAVED (slice s walks s, s + ksplit, ...): which offsets of a tile
+  // are empty depends on the tile's z plane and on the offset's dz, the slowest-running index of the enumeration - contiguous
+  // slices would be all-empty or all-full, and a launch is as long as its fullest workgroups
+  int kstride = 1;
+  if (a.kvol > DMA_DENSE_KVOL && a.tile_k == nullptr && a.ksplit > 1 && !(a.ablate & 4)) {
+    kstride = a.ksplit;
+    k_begin = (int)blockIdx.y;
+    kcount = k_begin < a.kvol ? (a.kvol - k_begin + kstride - 1) / kstride : 0;
+  }
   if (a.tile_k != nullptr) {          // row lists: this row tile is ONE kernel offset's k = 1 product (-1: unused tile)
     k_begin = a.tile_k[row_tile];
     if (k_begin < 0) return;
     kcount = 1;
   }
-  const int nstages = kcount * nchunks;
+  int nstages = kcount * nchunks;
   const uint32_t rsb = 4u * (uint32_t)a.cpad;   // bytes per operand row
 
   f32x16 acc[TM][TN];
@@ -104,11 +117,42 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
       const int k = i / BM, r = i - k * BM;
       const int64_t row = m0 + r;
       int idx = -1;
-      if (row < a.n_out) idx = a.tile_k ? a.nbr[row] : (a.nbr ? a.nbr[(int64_t)(k_begin + k) * a.nbr_stride + row] : (int)row);
+      if (row < a.n_out) idx = a.tile_k ? a.nbr[row] : (a.nbr ? a.nbr[(int64_t)(k_begin + k * kstride) * a.nbr_stride + row] : (int)row);
       idx_lds[k * BM + (r % RPP) * 4 + (r / RPP)] = idx;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+
+    // ---- dense implicit GEMMs (the bottleneck's 245-offset products): offsets none of the tile's rows has a neighbour at
+    // (beyond the grid's faces: the bottleneck orders its sites z-major so that a 128-row tile lies in ONE z plane, and
+    // 30 % of the (tile, offset) stages of the (7, 7, 5) kernels are then empty) are dropped from the stage
+    // list: the walk goes over kmap[0 .. nvalid).  Empty stages add exact zeros, so the sums do not change -----------------
+    // the list lives in the LAST offset slot of the index table (such launches walk at most DMA_KMAX - 1 offsets, ph_conv_dma_try:
+    // the tile's 80 KB of LDS are what lets two workgroups share a CU - not one byte more)
+    static_assert(BM >= 2 * DMA_KMAX + 4, "the stage list fits one offset slot of the index table");
+    int *kmap = idx_lds + (DMA_KMAX - 1) * BM;         // [DMA_KMAX] valid offset slots, then [DMA_KMAX] flags, then the count
+    const bool compact = a.kvol > DMA_DENSE_KVOL && a.tile_k == nullptr && !(a.ablate & 4);
+    if (compact) {
+      int *kflag = kmap + DMA_KMAX;
+      for (int k = wave; k < kcount; k += WAVES) {
+        bool any = false;
+        for (int r = lane; r < BM; r += 64) any |= idx_lds[k * BM + r] >= 0;
+        const unsigned long long bal = __ballot(any);
+        if (lane == 0) kflag[k] = bal != 0ull ? 1 : 0;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tid == 0) {
+        int nv = 0;
+        for (int k = 0; k < kcount; ++k)
+          if (kflag[k]) kmap[nv++] = k;
+        kflag[DMA_KMAX] = nv;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      nstages = kflag[DMA_KMAX] * nchunks;
+    }
+    if (nstages > 0) {
 
     // ---- DMA geometry of this thread: tile row l_r + RPP p, 16-byte slot l_j; source chunk swizzled ---------
     const int l_j = tid & 7;
@@ -131,8 +175,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
     // stage s -> (offset slot, channel chunk); the tail re-loads the last stage instead of branching
     auto stage_kc = [&](int s, int &k, uint32_t &coff) {
       const int sc = s < nstages - 1 ? s : nstages - 1;
-      k = sc / nchunks;
-      coff = (uint32_t)(sc - k * nchunks) << 7;
+      const int kk = sc / nchunks;
+      coff = (uint32_t)(sc - kk * nchunks) << 7;
+      k = compact ? kmap[kk] : kk;
     };
     auto load_idx = [&](int s) {
       int k;
@@ -155,7 +200,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
         asm volatile("" : "+v"(v));            // materialise before the select: a select, not a branch per row
         src.a[p] = ix >= 0 ? v : zero_src;
       }
-      src.w = w_base + (uint64_t)((int64_t)(k_begin + k) * wslab) + coff;
+      src.w = w_base + (uint64_t)((int64_t)(k_begin + k * kstride) * wslab) + coff;
     };
     auto fire = [&](const Src &src, int buf) {
       char *abuf = lds + buf * STAGE;
@@ -349,6 +394,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
     }
 #undef DMA_WAIT_STAGE
 #undef DMA_READS_DONE
+    }
   }
 
   // every load of the epilogue ahead of its first store (conv_h2_common.h, ParGlobal): 600 -> 510 us on the 64 -> 384 projections
@@ -408,12 +454,13 @@ static inline int64_t g_tail_ws_bytes(const ConvArgsH &a) { return a.tail_ws_byt
 // `a` arrives fully prepared (tile-independent fields, ksplit / partial chosen by the caller for 128-row tiles).
 int ph_conv_dma_try(const ConvArgsH &a_in, int bn, hipStream_t st) {
   const int kper = (a_in.kvol + a_in.ksplit - 1) / a_in.ksplit;
-  if (kper > DMA_KMAX) return -1;
+  if (kper > DMA_KMAX - (a_in.kvol > DMA_DENSE_KVOL ? 1 : 0)) return -1;     // dense GEMMs: the last index slot holds the stage list
   const char *zero = ph_dma_zero_line();
   if (zero == nullptr) return -1;
   ConvArgsH a = a_in;
   a.zero = zero;
-  a.ablate = g_dma_ablate & 1;      // bit 0 (experiment switch, tools/layer_ab.py): 1 = the long pipeline for short launches too
+  a.ablate = g_dma_ablate & 5;      // experiment switches (tools/layer_ab.py): bit 0 = the long pipeline for short launches too,
+                                    // bit 2 = no dropping of empty (tile, offset) stages in the dense implicit GEMMs
   // timing experiments (wrong results by design): 0x10 drops the per-axis table residual, 0x40 the dense residual
   if (g_dma_ablate & 0x10) a.axis_table = nullptr;
   if (g_dma_ablate & 0x40) a.residual = nullptr;

@@ -758,7 +758,8 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
       double best_us = 1e30;
       for (int ks = 1; ks <= 12 && ks <= d->kvol / 3; ++ks) {
         const int kper = (d->kvol + ks - 1) / ks;
-        if (kper > 32 || (d->kvol + kper - 1) / kper != ks) continue;      // beyond the index table / same as fewer slices
+        if (kper > (d->kvol > 100 ? 31 : 32) || (d->kvol + kper - 1) / kper != ks) continue;   // beyond the index table (the dense
+                                                       // GEMMs keep its last slot for their stage list, conv_dma.hip) / same as fewer slices
         if (ks > 1 && d->splitk_ws_bytes < (int64_t)ks * d->n_out * d->cout * 4) continue;
         const double rounds = (double)((t128 * ks + 511) / 512);
         double us = rounds * (kper * nchunks * stage_us + fixed_us);

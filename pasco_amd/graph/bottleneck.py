@@ -83,22 +83,32 @@ class SPCDense3Dv2(nn.Module):
         return hit[1]
 
     def _grid_tables(self, dims, device):
-        """site coordinates [B*X*Y*Z, 4] (lexicographic) + neighbour tables per kernel shape, cached."""
+        """Site coordinates + neighbour tables per kernel shape, cached per grid shape.  The sites are enumerated Z-MAJOR -
+        (b, z, x, y) - not lexicographically: a run of 128 rows (one tile of the convolution kernel) then lies in one z plane
+        of the 4-deep grid, and for such a tile every kernel offset that points above / below the grid (2 of the 5 dz of a
+        (7, 7, 5) kernel at z = 0 or 3) has no neighbour at all - the kernel drops those stages (k_conv_dma, kvol > 27).
+        -> (coords [n, 4] z-major, tables, perm [n] int64: row of the lexicographic order each z-major row is, inv: the
+        inverse, the lexicographic coordinates)."""
         cache = self.__dict__.setdefault("_grid_cache", {})
         key = (tuple(int(d) for d in dims), str(device))
         if key in cache:
             return cache[key]
         b, x, y, z = key[0]
         be = backend_for(device)
+        lex = torch.arange(b * x * y * z, dtype=torch.int64, device=device).view(b, x, y, z)
+        perm = lex.permute(0, 3, 1, 2).reshape(-1).contiguous()            # z-major position -> lexicographic row
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel(), dtype=torch.int64, device=device)
         ax = [torch.arange(n, dtype=torch.int32, device=device) for n in (b, x, y, z)]
-        coords = torch.stack(torch.meshgrid(*ax, indexing="ij"), dim=-1).reshape(-1, 4).contiguous()
+        lex_coords = torch.stack(torch.meshgrid(*ax, indexing="ij"), dim=-1).reshape(-1, 4).contiguous()
+        coords = lex_coords.index_select(0, perm).contiguous()
         tk, tv, _, _, _ = be.map_insert(coords, dedup=False)
         tables = {}
         for ks in {(3, 3, 1), (5, 5, 3), (7, 7, 5)}:
             offs = kernel_offsets(ks, 1)
             parts = [be.nbr_build(coords, tk, tv, offs[i:i + MAX_KVOL]) for i in range(0, len(offs), MAX_KVOL)]
             tables[ks] = torch.cat(parts, dim=0).contiguous()
-        cache[key] = (coords, tables)
+        cache[key] = (coords, tables, perm, inv, lex_coords)
         return cache[key]
 
     def forward_rows(self, rows: torch.Tensor, dims) -> torch.Tensor:
@@ -106,7 +116,7 @@ class SPCDense3Dv2(nn.Module):
         lexicographic (b,x,y,z) order -> same layout after the block.  dims = (B, X, Y, Z)."""
         assert not self.training, "inference only"
         be = backend_for(rows.device)
-        _, tables = self._grid_tables(dims, rows.device)
+        _, tables, perm, inv, _ = self._grid_tables(dims, rows.device)
         n = rows.shape[0]
 
         from . import fused
@@ -131,7 +141,7 @@ class SPCDense3Dv2(nn.Module):
             return be.conv_fwd(x, w, tables.get(ks), n, epi_scale=scale, epi_shift=shift, epi_act=ACT_RELU,
                                split=split, in_split=in_split)
 
-        x = rows.contiguous()
+        x = rows.index_select(0, perm)                     # z-major inside the block (see _grid_tables), lexicographic outside
         x1 = cbr("a_conv1", x)
         x2, x3, x4 = cbr("a_conv2", x1), cbr("a_conv3", x1), cbr("a_conv4", x1)
         t1 = x2 + x3 + x4
@@ -139,4 +149,4 @@ class SPCDense3Dv2(nn.Module):
         s = x1 + t1 + x5 + x6 + x7
         y0 = cbr("ch_conv1", s)
         y1, y2, y3 = cbr("res_1", x), cbr("res_2", x), cbr("res_3", x)
-        return x1 + y0 + y1 + y2 + y3
+        return (x1 + y0 + y1 + y2 + y3).index_select(0, inv)

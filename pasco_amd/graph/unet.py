@@ -208,7 +208,7 @@ class UNet3DV2(nn.Module):
         dense3d, dropout = self.dense3d[0], self.dense3d[1]
         assert not dropout.training
         out = dense3d.forward_rows(rows, dims)
-        site_coords, _ = dense3d._grid_tables(dims, out.device)
+        site_coords = dense3d._grid_tables(dims, out.device)[4]       # lexicographic (b, x, y, z): what forward_rows returns
         nz = (out != 0).any(dim=1)                     # ME.to_sparse drops all-zero sites
         opt = fused.optimistic_word(dev)
         if opt is not None:
