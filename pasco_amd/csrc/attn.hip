@@ -1182,6 +1182,8 @@ extern "C" int ph_attn_cross_split(const float *q, const void *k_split, const vo
   PH_REQUIRE(qn >= 1 && qn <= 128, "attn_cross_split: %d queries not served (1..128)", qn);
   PH_REQUIRE(b >= 1 && h >= 1 && n >= 1, "attn_cross_split: bad shape");
   PH_REQUIRE(exp2 >= -14 && exp2 <= 14, "attn_cross_split: operand exponent %d", exp2);
+  // (kv_unscale = 2^-exp2 is therefore finite and positive: the running maximum is taken on the raw accumulator, which is
+  // only order-preserving for a positive scale)
   PH_REQUIRE(ws_bytes >= ph_attn_workspace_bytes(n, b, h, qn, dh), "attn_cross_split: workspace too small");
   AttnSplitArgs s;
   AttnArgs &a = s.a;

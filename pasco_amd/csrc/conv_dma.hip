@@ -484,6 +484,9 @@ int ph_conv_dma_try(const ConvArgsH &a_in, int bn, hipStream_t st) {
     int ks = (int)(slots / rest);
     if (ks > a.kvol / 3) ks = a.kvol / 3;
     if (ks > 16) ks = 16;
+    // no empty slices: the kernel gives every slice ceil(kvol / ks) offsets, so e.g. 27 offsets in 8 slices of 4 leaves the
+    // eighth with nothing - its workgroups would only write (and the reduction read) zeros
+    while (ks > 1 && (a.kvol + (a.kvol + ks - 1) / ks - 1) / ((a.kvol + ks - 1) / ks) != ks) --ks;
     const int64_t r0 = (trow - rest) * 128, tail_rows = a.n_out - r0;
     if (ks >= 2 && (int64_t)ks * tail_rows * a.cout * 4 <= g_tail_ws_bytes(a_in)) {
       ConvArgsH head = a;

@@ -123,6 +123,19 @@ class SceneServer:
         for s in self.streams:                      # whatever was uploaded on the current stream is visible to the workers
             s.wait_stream(torch.cuda.current_stream(self.device))
 
+    def close(self) -> None:
+        """Retire the worker streams: their per-stream buffers in the backend (workspaces, status pairs) are dropped, so a
+        long-lived process that builds servers repeatedly neither leaks them nor hands a recycled stream handle stale flags."""
+        from ..me.backend import backend_for
+        try:
+            be = backend_for(self.device)
+        except Exception:
+            return
+        for s in self.streams:
+            s.synchronize()
+            be.release_stream(s)
+        self.streams = []
+
     # -- one at a time, on the caller's stream -------------------------------------------------------------------------
     def run_serial(self, items: Sequence, on_done: Optional[Callable] = None):
         last = None

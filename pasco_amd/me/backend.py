@@ -27,7 +27,8 @@ class StatusError(RuntimeError):
     """A device-side status flag was raised since the last check (`CBackend.check_status`).  `bits` holds every flag:
     1 = f16 range of a split-precision operand, 2 = unpackable coordinate, 4 = coordinate outside a per-axis table,
     8 = the fused input stage must be redone on its general path (all-zero merged row), 16 = an optimistic shortcut of the
-    graph did not hold (redo with the checked paths)."""
+    graph did not hold (redo with the checked paths), 32 = a kernel map handed over as one-pair-per-row (row lists) has
+    another number of pairs than rows."""
 
     def __init__(self, bits: int, message: str):
         super().__init__(message)
@@ -202,6 +203,19 @@ class CBackend:
         if device.type == "cuda" and device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         return (device, self.stream(device) or 0)
+
+    def release_stream(self, stream) -> int:
+        """Drop every per-stream buffer (workspaces, split-K scratch, attention partials, the status pair) this backend keeps
+        for `stream` (a torch.cuda.Stream or a raw handle): call it when a serving loop retires a stream - the buffers are
+        keyed by the raw handle, so they would otherwise outlive it, and a later stream that is handed the same handle would
+        inherit them together with any status bit nobody read.  Returns the number of buffers dropped."""
+        handle = int(getattr(stream, "cuda_stream", stream) or 0)
+        dev = getattr(stream, "device", None)
+        drop = [k for k in self._ws
+                if isinstance(k, tuple) and len(k) >= 3 and k[-1] == handle and (dev is None or k[-2] == dev)]
+        for k in drop:
+            del self._ws[k]
+        return len(drop)
 
     def workspace(self, n: int, device: torch.device) -> torch.Tensor:
         need = int(self.fn["workspace_bytes"](int(n)))

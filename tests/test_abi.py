@@ -75,3 +75,16 @@ def test_no_cpu_path_in_product():
     import pasco_amd.me as ME
     with pytest.raises(RuntimeError):
         ME.SparseTensor(torch.zeros(2, 3), torch.zeros(2, 4, dtype=torch.int32))
+
+
+def test_release_stream_drops_the_per_stream_buffers(oracle):
+    """`CBackend.release_stream`: workspaces and the status pair are keyed by (device, raw stream handle); retiring a
+    stream drops them, so a recycled handle starts with a clean status word."""
+    import torch
+    dev = torch.device("cpu")
+    oracle.workspace(1000, dev)
+    oracle.status_word(dev).fill_(1)
+    assert any(k[0] == "status" for k in oracle._ws)
+    assert oracle.release_stream(0) >= 2
+    assert not any(isinstance(k, tuple) and k[0] in ("status", "ws") for k in oracle._ws)
+    assert int(oracle.status_word(dev)) == 0          # a fresh pair
