@@ -1194,8 +1194,11 @@ extern "C" int ph_attn_cross_split(const float *q, const void *k_split, const vo
   s.status = status;
   const int64_t ntile = (n + AS_KT - 1) / AS_KT;
   const int bh = b * h;
-  // ~1536 workgroups (256 CUs x 3 resident x 2) in total, at most the 2048 + 4 b h partial records the workspace holds
-  int64_t splits = 1536 / bh;
+  // 512 workgroups = one round of the two resident per CU (round 4; 1536 before: every key range leaves a partial record that
+  // k_attn_merge reads again - 229 -> 181 us and 104 -> 66 us at the two coarser levels' sizes, merge included); at most the
+  // 2048 + 4 b h partial records the workspace holds
+  static const int target = [] { const char *e = getenv("PASCO_ATTN_SPLIT_WGS"); return e ? atoi(e) : 512; }();
+  int64_t splits = (target > 0 && target <= 2048 ? target : 512) / bh;
   if (splits < 1) splits = 1;
   if (splits > ntile) splits = ntile;
   int64_t tpw = (ntile + splits - 1) / splits;
@@ -1238,7 +1241,11 @@ extern "C" int ph_attn_cross_feat(const float *q2, const void *x_split, const vo
   s.status = status;
   const int64_t ntile = (n + AS_KT - 1) / AS_KT;
   const int bh = b * h;
-  int64_t splits = 2048 / bh;      // at most the 2048 + 4 b h partial records the workspace holds
+  // key ranges per (subnet, head): two workgroups are resident per CU (256 registers per wave), so 512 workgroups are one
+  // round; every partial record is 43 KB that k_attn_merge reads again (2048 workgroups: 88 MB of partials, 157 us of merge;
+  // 846 -> 756 us at the finest level's size, merge included)
+  static const int target = [] { const char *e = getenv("PASCO_ATTN_FEAT_WGS"); return e ? atoi(e) : 512; }();
+  int64_t splits = (target > 0 && target <= 2048 ? target : 512) / bh;      // at most the 2048 + 4 b h records the workspace holds
   if (splits < 1) splits = 1;
   if (splits > ntile) splits = ntile;
   int64_t tpw = (ntile + splits - 1) / splits;

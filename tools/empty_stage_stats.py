@@ -33,7 +33,7 @@ def spy(x, weight, nbr, n_out, **kw):
         if rec is None:
             valid = nbr >= 0
             stats = {}
-            for bm in (128, 256):
+            for bm in (32, 64, 128, 256):
                 t = (n_out + bm - 1) // bm
                 pad = t * bm - n_out
                 v = torch.nn.functional.pad(valid, (0, pad)).view(nbr.shape[0], t, bm).any(dim=2)      # [K, tiles]
@@ -49,6 +49,6 @@ with torch.no_grad():
     be.conv_fwd = spy
     bench.run_scene(net, scene, tk)
     be.conv_fwd = inner
-print("kvol  cin->cout   rows     kernel   x/step  pairs/row  empty (tile, offset) stages: 128-row tiles, 256-row tiles")
+print("kvol  cin->cout   rows     kernel   x/step  pairs/row  empty (row block, offset) stages at 32 / 64 / 128 / 256 rows per block")
 for (kvol, cin, cout, n_out, kid), (cnt, ppr, st) in sorted(seen.items(), key=lambda kv: -kv[0][0] * kv[0][3] * kv[1][0]):
-    print(f"k{kvol:<4d} {cin:3d}->{cout:<3d} n={n_out:7d}  {KN.get(kid, kid):8s} x{cnt:2d}   {ppr:6.1f}     {100 * st[128]:5.1f} %   {100 * st[256]:5.1f} %")
+    print(f"k{kvol:<4d} {cin:3d}->{cout:<3d} n={n_out:7d}  {KN.get(kid, kid):8s} x{cnt:2d}   {ppr:6.1f}     {100 * st[32]:5.1f} %  {100 * st[64]:5.1f} %  {100 * st[128]:5.1f} %  {100 * st[256]:5.1f} %")
