@@ -550,6 +550,7 @@ def main():
         print(f"[bench] per-step host ms: {per}", file=sys.stderr, flush=True)
     one_in_flight = None
     if args.in_flight > 1 and world == 1:          # the same K steps, one scene at a time on one stream (no per-launch events)
+        run_steps(0, len(scenes), 1)               # untimed: the main stream's pool as the collector-less loop leaves it
         window = []
         mallocs0 = allocator_state(device).get("device_mallocs", 0)
         torch.cuda.synchronize()
