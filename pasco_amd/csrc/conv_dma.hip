@@ -23,11 +23,23 @@
 #include <mutex>
 #include <stdlib.h>
 
+#include <hip/hip_runtime.h>
+// development hook (tools/dma_trace.py): shader-clock stamps of the first 64 workgroups' phases when bit 7 of the ablate mask is set
+__device__ unsigned long long g_dma_trace[64 * 8];
+#define DMA_STAMP(i)                                                                                              \
+  do {                                                                                                            \
+    if ((a.ablate & 0x80) && threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y == 0)                              \
+      g_dma_trace[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter();                                           \
+  } while (0)
+#define H2_STAMP(i) DMA_STAMP(i)
 #include "conv_h2_common.h"
 
 // kernel volumes above this are the bottleneck's (7, 7, 5) implicit GEMMs: their empty (tile, offset) stages are dropped and their
 // slices interleaved (measured: 544 -> 478 us on the 245-offset products; the 75-offset ones, whose light and heavy tiles cannot
 // balance over 4 slices, lose 4 % to the bookkeeping and stay as they were: profiles/r4p_layer_ab_dense_stage_skip.txt)
+extern "C" int ph_dma_trace_read(unsigned long long *host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dma_trace), sizeof(g_dma_trace)) == hipSuccess ? 0 : 2;
+}
 constexpr int DMA_DENSE_KVOL = 100;
 constexpr int DMA_KMAX = 32;   // kernel offsets one workgroup walks (its slice of the split over the offsets)
 
@@ -72,6 +84,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
   const int n0 = col_tile * BN;
 
   const int tid = threadIdx.x;
+  DMA_STAMP(0);
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -328,9 +341,11 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
         prep(1, load_idx(1), src);
         fire(src, 1);
       }
+      DMA_STAMP(1);
       for (int s = 0; s < nstages; ++s) {
         const int buf = s & 1;
         wait_landed(s + 1 < nstages);                  // stage s landed (stage s + 1 may still fly)
+        if (s == 0) DMA_STAMP(2);
         readfrag(buf, f0);
         if (s + 2 < nstages) {                         // buffer `buf` is free once every wave holds its fragments
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -397,9 +412,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
     }
   }
 
+  DMA_STAMP(3);
   // every load of the epilogue ahead of its first store (conv_h2_common.h, ParGlobal): 600 -> 510 us on the 64 -> 384 projections
   // together with the epilogue's VALU diet, 547 without the staging (profiles/r3s_layer_ab_epilogue_diet_vs_base.txt)
   h2_store_tile_staged<TM, TN, EMIT, NT, BN, 2 * STAGE + DMA_KMAX * BM * 4>(a, acc, m0, n0, wm, wn, h, l31, tid, lds);
+  if (a.ablate & 0x80) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DMA_STAMP(4);
 }
 
 template <int WAVES, int WM, int WN, int TM, int TN>
@@ -459,7 +477,7 @@ int ph_conv_dma_try(const ConvArgsH &a_in, int bn, hipStream_t st) {
   if (zero == nullptr) return -1;
   ConvArgsH a = a_in;
   a.zero = zero;
-  a.ablate = g_dma_ablate & 5;      // experiment switches (tools/layer_ab.py): bit 0 = the long pipeline for short launches too,
+  a.ablate = g_dma_ablate & 0x85;      // experiment switches (tools/layer_ab.py): bit 0 = the long pipeline for short launches too,
                                     // bit 2 = no dropping of empty (tile, offset) stages in the dense implicit GEMMs
   // timing experiments (wrong results by design): 0x10 drops the per-axis table residual, 0x40 the dense residual
   if (g_dma_ablate & 0x10) a.axis_table = nullptr;

@@ -480,6 +480,10 @@ __device__ __forceinline__ void h2_store_tile(const ConvArgsH &a, f32x16 (&acc)[
   if (EMIT && a.status != nullptr && obad != 0) atomicOr(a.status, 1);
 }
 
+#ifndef H2_STAMP
+#define H2_STAMP(i) do {} while (0)        // conv_dma.hip's development trace defines it (tools/dma_trace.py)
+#endif
+
 // Staged epilogue of a one-tile workgroup (see ParGlobal): `scratch` = SCRATCH bytes of LDS that nothing reads or writes any
 // more once every wave has arrived here (the stage buffers and index table of the main loop).  NT threads, BN-wide tile.
 template <int TM, int TN, bool EMIT, int NT, int BN, int SCRATCH, int J0 = 0>
@@ -494,6 +498,7 @@ __device__ __forceinline__ void h2_staged_passes(const ConvArgsH &a, f32x16 (&ac
   if (J0 == 0) {   // the per-channel vectors every thread staged: visible after the barrier
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    H2_STAMP(6);
   }
   h2_store_tile<TM, TN, EMIT, ParLds, TailLds, J0, JB>(a, acc, m0, n0, wm, wn, h, l31, pl, TailLds{slots, NT});
   if constexpr (J0 + JB < TN) h2_staged_passes<TM, TN, EMIT, NT, BN, SCRATCH, J0 + JB>(a, acc, m0, n0, wm, wn, h, l31, pl, slots);
@@ -507,12 +512,14 @@ __device__ __forceinline__ void h2_store_tile_staged(const ConvArgsH &a, f32x16 
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                      // every wave is done with the main loop's LDS
+  H2_STAMP(5);
   lds_float *par = (lds_float *)scratch;
   h2_stage_params(a, n0, BN, tid, par);
   const ParLds pl{par, n0, BN};
   if (a.residual == nullptr && a.axis_table == nullptr) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    H2_STAMP(6);
     h2_store_tile<TM, TN, EMIT, ParLds>(a, acc, m0, n0, wm, wn, h, l31, pl);
     return;
   }
