@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    DMA_STAMP(7);
 
     // ---- dense implicit GEMMs (the bottleneck's 245-offset products): offsets none of the tile's rows has a neighbour at
     // (beyond the grid's faces: the bottleneck orders its sites z-major so that a 128-row tile lies in ONE z plane, and

@@ -42,7 +42,7 @@ with torch.no_grad():
 lib = be.lib
 lib.ph_conv_dma_set_ablate.argtypes = [C.c_int]
 lib.ph_dma_trace_read.argtypes = [C.c_void_p]
-names = ["start -> first DMA issued (index table, address arithmetic)", "first stage landed (DMA latency)",
+names = ["start -> index table in LDS (kernel arguments, 128 entries, barrier)", "index table -> first DMA issued (address arithmetic)", "first stage landed (DMA latency)",
          "stages multiplied (-> epilogue entry)", "epilogue: every wave out of the main loop (barrier)",
          "epilogue: per-channel vectors + table / residual addends staged in LDS", "epilogue: arithmetic + stores, drained"]
 for key, rec in sorted(picked.items(), key=lambda kv: -kv[0][2] * kv[0][1]):
@@ -65,6 +65,6 @@ for key, rec in sorted(picked.items(), key=lambda kv: -kv[0][2] * kv[0][1]):
     tot = (st[:, 4] - st[:, 0]).astype(float)
     print(f"k1 {cin} -> {cout}, n = {n}, table residual {axis}, operand emitted {emit}: {ts[1]:.1f} us plain, {ts[2]:.1f} us traced; "
           f"{tiles} tiles on 512 slots; workgroup life median {np.median(tot):.0f} clk (min {tot.min():.0f}, max {tot.max():.0f})")
-    for nm, (a, b) in zip(names, [(0, 1), (1, 2), (2, 3), (3, 5), (5, 6), (6, 4)]):
+    for nm, (a, b) in zip(names, [(0, 7), (7, 1), (1, 2), (2, 3), (3, 5), (5, 6), (6, 4)]):
         d = (st[:, b] - st[:, a]).astype(float)
         print(f"    {nm:62s} median {np.median(d):8.0f} clk ({100 * np.median(d) / np.median(tot):5.1f} %)  min {d.min():8.0f}  max {d.max():8.0f}")
