@@ -825,6 +825,11 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
       const int rc = ph_conv_wide_try(a, st);
       if (rc >= 0) return rc;
     }
+    // k = 1 streams (linear layers, 1x1x1 convolutions) of 64 / 128 input channels onto 128-wide tiles: the row-stream kernel
+    if (pre && knobs.dma_on && !env && bn == 128 && d->kvol == 1 && a.ksplit == 1) {
+      const int rc = ph_conv_lin_try(a, st);
+      if (rc >= 0) return rc;
+    }
     if (pre && knobs.dma_on && !env && (bn == 128 || knobs.dma_all)) {
       ConvArgsH b = a;
       if (bm != 128) {        // the choice above was made for a shorter tile: redo the split decision for 128 rows

@@ -125,6 +125,8 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st);
 int ph_launch_splitk_epilogue(const ConvArgsH &args, hipStream_t st);
 // conv_dma.hip: the LDS-DMA pipelined kernel; -1 = shape not served (caller falls back to k_conv_h2)
 int ph_conv_dma_try(const ConvArgsH &a, int bn, hipStream_t st);
+// conv_lin.hip: k = 1 products of 64 / 128 input channels as a row stream (weights in LDS, no barriers); -1 = shape not served
+int ph_conv_lin_try(const ConvArgsH &a, hipStream_t st);
 // conv_wide.hip: 256 x 256 tiles, 8 waves, one workgroup per CU (256 output channels); -1 = shape not served
 int ph_conv_wide_try(const ConvArgsH &a, hipStream_t st);
 

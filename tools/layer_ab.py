@@ -62,7 +62,7 @@ base = None
 if os.environ.get("LAYER_AB_BASE"):
     base = CBackend(os.path.abspath(os.environ["LAYER_AB_BASE"]), "ph_", "cuda")
     masks = ["base"] + masks
-KN = {0: "mfma", 1: "f16x3", 2: "h2", 3: "rl", 4: "dma", 5: "win|dma", 6: "wide"}
+KN = {0: "mfma", 1: "f16x3", 2: "h2", 3: "rl", 4: "dma", 5: "win|dma", 6: "wide", 7: "lin"}
 
 
 def timed(rec, mask):
