@@ -528,11 +528,13 @@ def main():
         gc.disable()
     alloc_log = {"after_warmup": allocator_state(device)}
     barrier()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     marks = [t0]
     last = run_steps(0, args.steps, args.in_flight, window, marks)
     barrier()
     elapsed = time.perf_counter() - t0
+    host_cpu_s = time.process_time() - cpu0      # CPU seconds of every thread of this process over the timed loop
     alloc_log["after_timed_loop"] = allocator_state(device)
     out, panop = last["out"], last["panop"]
     prof.enabled = False
@@ -671,6 +673,7 @@ def main():
             if per_kernel:
                 res["roofline"] = roofline_object(per_kernel, prof_steps, classes)
         res["config"]["in_flight"] = args.in_flight
+        res["host_cpu_ms_per_step"] = round(host_cpu_s / args.steps * 1e3, 3)      # CPU time of ALL threads (the workers spin inside HIP's waits: ~one core each)
         res["host_threads"] = {"scene_threads_per_rank": max(args.in_flight, 1), "ranks": world,
                                "cpus_per_rank": len(pinned) if pinned else len(os.sched_getaffinity(0)),
                                "pinned_to_gpu_local_cores": bool(pinned), "omp_num_threads": os.environ.get("OMP_NUM_THREADS"),

@@ -463,9 +463,12 @@ class TransformerPredictorV2(nn.Module):
             return "eager"
         return "graph"
 
+    def param_versions(self):
+        return tuple((p._version, p.data_ptr()) for p in self.parameters())
+
     _QGRAPH_MAX = 48     # captured graphs kept per module (4 per shape and stream; a few shapes, a few streams); oldest evicted
 
-    def query_step(self, layer: int, output, query_embed, want_operand: bool):
+    def query_step(self, layer: int, output, query_embed, want_operand: bool, vers=None):
         if not output.is_cuda or self.training or torch.is_grad_enabled() or \
                 os.environ.get("PASCO_QUERY_GRAPH", "1") == "0" or self.__dict__.get("_qgraph_broken", False):
             return self._query_step(layer, output, query_embed, want_operand)
@@ -473,7 +476,9 @@ class TransformerPredictorV2(nn.Module):
         # a captured graph bakes in the ADDRESSES of every parameter it reads: the key carries version and storage
         # address of each (load_state_dict(assign=True), .cpu().cuda() round trips, param.data = ... change the
         # address without bumping the version)
-        vers = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        # (`vers` from the caller: forward() takes it once for its four calls - walking the module tree costs ~0.2 ms)
+        if vers is None:
+            vers = self.param_versions()
         # one graph per launch stream: a serving loop with several scenes in flight replays them concurrently, and a
         # graph's static input / output buffers must not be shared between streams
         key = (layer, tuple(output.shape), tuple(query_embed.shape), output.device, want_operand,
@@ -683,7 +688,8 @@ class TransformerPredictorV2(nn.Module):
         if "lens" in xs.get("_meta", {}):       # rows of every subnet at every scale (host ints from the caller)
             mask_cache["lens"] = xs["_meta"]["lens"]
         head_mode = 2 if absorbed is not None else (vf_split is not None)
-        output, *qs = self.query_step(-1, output.contiguous(), query_embed, head_mode)
+        qvers = self.param_versions() if output.is_cuda else None
+        output, *qs = self.query_step(-1, output.contiguous(), query_embed, head_mode, qvers)
         oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape, query_side=qs, absorbed=absorbed)
         predictions_class.append(oc)
         predictions_mask.append(om)
@@ -746,7 +752,7 @@ class TransformerPredictorV2(nn.Module):
                 attn_mask = ~(allow != 0).permute(0, 2, 1)
                 attn_mask = attn_mask & ~attn_mask.all(dim=-1, keepdim=True)   # all-masked -> unmasked
                 output = ca(output, src_F, attn_mask=attn_mask, pos=None, query_pos=query_embed)
-            output, *qs = self.query_step(i, output.contiguous(), query_embed, head_mode)
+            output, *qs = self.query_step(i, output.contiguous(), query_embed, head_mode, qvers)
             oc, om = self.pred_heads(output, voxel_feat, vf_split, vf_shape, query_side=qs, absorbed=absorbed)
             predictions_class.append(oc)
             predictions_mask.append(om)
