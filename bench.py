@@ -526,6 +526,11 @@ def main():
     gc_was_on = gc.isenabled()
     if os.environ.get("PASCO_BENCH_GC", "0") != "1":
         gc.disable()
+    # the write test above walked every cached block and the collector has just run: a last untimed stretch of the loop itself, so that
+    # the timed steps start from the state a serving loop is in (one box's first process ran its first 20 timed steps 25 - 45 % slow
+    # right after them: profiles/r4x_bench_full.json)
+    if args.in_flight > 1:
+        run_steps(0, max(2 * args.in_flight * len(scenes), args.steps), args.in_flight)
     alloc_log = {"after_warmup": allocator_state(device)}
     barrier()
     cpu0 = time.process_time()

@@ -187,12 +187,13 @@ class SceneServer:
         return state["last"]
 
     # -- warm-up -------------------------------------------------------------------------------------------------------
-    def warm(self, items: Sequence, max_rounds: int = 6) -> dict:
+    def warm(self, items: Sequence, max_rounds: int = 8, quiet_rounds: int = 2) -> dict:
         """Every item on the caller's stream until a whole pass needed no device allocation (map shapes, operand caches, the
         stream's allocator pool), once on every worker stream (their graphs and workspaces; one stream at a time - graph
         captures do not overlap other launches), then rounds of the in-flight loop over 2 x in_flight x len(items) steps
-        until a whole round needed no device allocation either (the pools depend on the order the workers draw the items
-        in; they settle within a few rounds).  Why it matters: a device allocation inside a served loop costs from ~0.1 ms
+        until `quiet_rounds` rounds in a row needed no device allocation either (the pools depend on the order the workers draw
+        the items in; they settle within a few rounds - one quiet round still left 0 - 5 allocations to a following loop of 24
+        steps, `profiles/r4x_*`).  Why it matters: a device allocation inside a served loop costs from ~0.1 ms
         to several ms depending on the box, stalls the launch that waits for it and, on the slow boxes, every stream
         (profiles/README.md, round 4: the "slow mode" of rounds 2 - 3)."""
         items = list(items)
@@ -208,12 +209,14 @@ class SceneServer:
                 with torch.cuda.stream(s):
                     self.run_serial(items)
                 s.synchronize()
-        rounds, quiet = 0, self.in_flight <= 1
+        rounds, streak = 0, 0
+        quiet = self.in_flight <= 1
         while not quiet and rounds < max_rounds:
             before = _device_mallocs(self.device)
             self.run([items[i % len(items)] for i in range(2 * self.in_flight * len(items))])
             rounds += 1
-            quiet = _device_mallocs(self.device) == before
+            streak = streak + 1 if _device_mallocs(self.device) == before else 0
+            quiet = streak >= max(int(quiet_rounds), 1)
         torch.cuda.synchronize(self.device)
         return {"serial_rounds": serial_rounds, "serial_settled": bool(quiet1), "in_flight_rounds": rounds,
                 "settled": bool(quiet), "seconds": round(time.perf_counter() - t0, 2)}
