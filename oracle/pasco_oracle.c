@@ -692,6 +692,13 @@ int pho_to_dense(const float *feats, const int32_t *coords, int64_t n, int32_t c
   for (int64_t i = 0; i < n; ++i) {
     const int32_t *p = coords + 4 * i;
     int x = floor_div(p[1] - h_min3[0], ts), y = floor_div(p[2] - h_min3[1], ts), z = floor_div(p[3] - h_min3[2], ts);
+    /* upstream writes `dense_F[b, :, x, y, z] = F` by advanced indexing [ME-upstream: MinkowskiSparseTensor.dense]: an index
+     * in [-dim, 0) wraps around python-style (the padded rows of the attention mask rely on it,
+     * transformer_predictor_v2.py:263-279 with SURVEY.md section 9 item 5); beyond that upstream raises - skipped here.
+     * Rows are written in order, so the last of several rows of one site wins (torch's CPU index_put order). */
+    if (x < 0) x += X;
+    if (y < 0) y += Y;
+    if (z < 0) z += Z;
     if (p[0] < 0 || p[0] >= B || x < 0 || x >= X || y < 0 || y >= Y || z < 0 || z >= Z) continue;
     int64_t site = ((int64_t)x * Y + y) * Z + z;
     for (int ch = 0; ch < c; ++ch) dense[((int64_t)p[0] * c + ch) * per_b + site] = feats[i * c + ch];

@@ -175,6 +175,12 @@ __global__ void __launch_bounds__(256)
   int ch = (int)(t - i * c);
   int4 p = coords[i];
   int x = floor_div(p.y - mx, ts), y = floor_div(p.z - my, ts), z = floor_div(p.w - mz, ts);
+  // upstream's dense() assigns by advanced indexing: an index in [-dim, 0) wraps around python-style (the padded rows of the
+  // attention mask rely on it, transformer_predictor_v2.py:263-279); anything further out is skipped (upstream raises).
+  // Several rows on one site: unordered here, as in upstream's GPU index_put.
+  if (x < 0) x += d.x;
+  if (y < 0) y += d.y;
+  if (z < 0) z += d.z;
   if (p.x < 0 || p.x >= d.b || x < 0 || x >= d.x || y < 0 || y >= d.y || z < 0 || z >= d.z) return;
   int64_t site = ((int64_t)x * d.y + y) * d.z + z;
   dense[((int64_t)p.x * c + ch) * ((int64_t)d.x * d.y * d.z) + site] = feats[t];

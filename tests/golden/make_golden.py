@@ -19,6 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference")
+sys.path.insert(0, HERE)
 
 from tests.conftest import load_oracle  # noqa: E402
 import pasco_amd.me as ME  # noqa: E402
@@ -232,6 +233,116 @@ def _golden_unet(n_infers, heavy, tag, seed):
     return True
 
 
+@torch.no_grad()
+def golden_unet_wide(tag="m2_f64", n_infers=2, f=64, nq=100, hid=384, ff=1024, grid=(48, 48, 16)):
+    """The reference's graph at the BENCHMARK'S widths (f = 64 -> 64 / 128 / 256 / 256 channels, hidden 384, 8 heads of 48,
+    100 queries): the widths at which the HIP path runs its MFMA kernels (k_conv_wop / k_conv_wide / k_conv_dma /
+    k_conv_lin / k_attn_feat / k_attn_split).  ~120 M parameters: the weights are procedural (proc_weights.py: a function
+    of key, shape and seed), only inputs and outputs are stored; logits of the big tensors on a row sample.
+
+    A random net decides `argmax != 0` for ~10^5 voxels; the smallest margin among that many decisions is ~1e-5 of the
+    logits' magnitude, i.e. inside the fp32-vs-split-precision difference, and one flipped voxel changes its neighbours at
+    every later level.  The fixture therefore also stores the reference's OWN decision and margin for every candidate voxel
+    (`dec_{scale}_*`): the test forces these decisions (keep_override) and asserts that the free-running decisions of the
+    HIP path agree wherever the reference's margin is above the noise."""
+    from pasco.models.unet3d_sparse_v2 import UNet3DV2
+    from pasco.models.transformer.transformer_predictor_v2 import TransformerPredictorV2
+    from pasco.models.augmenter import Augmenter
+    from pasco_amd.graph.synth import make_scene
+    from proc_weights import fill_state_dict
+    for seed in range(40):
+        torch.manual_seed(seed)
+        g = torch.Generator().manual_seed(7000 + seed)
+        tp = TransformerPredictorV2(dropout=0.0, nheads=8, hidden_dim=hid, enc_layers=0, num_queries=nq,
+                                    dim_feedforward=ff, dec_layers=1, aux_loss=False, mask_dim=f, n_infers=n_infers,
+                                    query_sample_ratio=1.0, in_channels=[f * 4, f * 2, f])
+        net = UNet3DV2(heavy_decoder=False, drop_path_rate=0.0, n_classes=20, in_channels=f * n_infers,
+                       transformer_predictor=tp, f_maps=[f, f * 2, f * 4, f * 4], dense3d_dropout=0.0,
+                       n_infers=n_infers, decoder_dropouts=[0.0, 0.0, 0.0], num_queries=nq, query_sample_ratio=1.0,
+                       encoder_dropouts=[0.0, 0.0, 0.0], use_se_layer=False).eval()
+        fill_state_dict(net, seed)
+        captured = []            # (C, keep, relative margin) per completion-head call: scales 4, 2, 1 x subnets
+
+        def hook(_m, _inp, out):
+            F = out.F
+            captured.append((out.C.clone(), F.argmax(dim=1) != 0,
+                             (F[:, 0] - F[:, 1:].max(dim=1)[0]).abs() / F.abs().mean()))
+        hs = [head.register_forward_hook(hook) for blk in net.decoder_generative.dec_blocks
+              for head in blk.completion_heads.values()]
+        mask_logits = []         # the mask logits each attention mask was thresholded from (transformer_predictor_v2.py:224)
+        inner_cam = tp.compute_attn_mask
+
+        def cam(outputs_mask, voxel_coord, *a, **k):
+            mask_logits.append((outputs_mask.clone(), voxel_coord.clone()))
+            return inner_cam(outputs_mask, voxel_coord, *a, **k)
+        tp.compute_attn_mask = cam
+        sc = make_scene(40 + seed, n_infers=n_infers, in_channels=f, grid=grid, occupancy=0.12)
+        coords, feats = [], []
+        for i in range(n_infers):
+            u = torch.unique(sc.in_coords[i], dim=0)
+            coords.append(torch.cat([torch.full((u.shape[0], 1), i), u], dim=1))
+            feats.append(torch.randn(u.shape[0], f, generator=g))
+        coords, feats = torch.cat(coords).int(), torch.cat(feats)
+        merged = Augmenter().merge(ME.SparseTensor(feats, coords))
+        sem_labels = {f"1_{s}": [None] * n_infers for s in (1, 2, 4)}
+        out = net(merged, 1, sc.Ts, sc.global_min_Cs, sc.global_max_Cs, sc.min_Cs, sc.max_Cs, class_frequencies=None,
+                  is_predict_panop=True, sem_labels=sem_labels, test=True)
+        for h in hs:
+            h.remove()
+        sizes = {s: [l.F.shape[0] for l in v] for s, v in out["sem_logits_at_scales"].items()}
+        psizes = [p["voxel_logits"].F.shape[0] for p in out["panop_predictions"]]
+        mmin = min(float(c[2].min()) for c in captured)
+        print(tag, "seed", seed, sizes, psizes, "min relative argmax margin %.2e" % mmin)
+        n1 = sizes[1][0]
+        if min(min(v) for v in sizes.values()) < 200 or min(psizes) < 4000 or not 12000 <= n1 <= 45000:
+            continue
+        assert len(captured) == 3 * n_infers
+        arrays = dict(seed=np.array(seed), in_coords=coords, in_feats=feats, merged_C=merged.C,
+                      global_min=sc.global_min_Cs, global_max=sc.global_max_Cs,
+                      min_Cs=torch.stack(sc.min_Cs), max_Cs=torch.stack(sc.max_Cs),
+                      cfg=np.array([n_infers, 0, f, nq, hid, ff]), margin=np.array(mmin))
+        for li, scale in enumerate((4, 2, 1)):
+            cs = captured[li * n_infers: (li + 1) * n_infers]
+            assert all(torch.equal(c[0], cs[0][0]) for c in cs)
+            arrays[f"dec_{scale}_C"] = cs[0][0].to(torch.int16)
+            arrays[f"dec_{scale}_keep"] = torch.stack([c[1] for c in cs])
+            arrays[f"dec_{scale}_margin"] = torch.stack([c[2] for c in cs]).clamp(max=60000.0).to(torch.float16)
+        gs = torch.Generator().manual_seed(1)
+
+        def sample(n, k=1536):
+            return torch.sort(torch.randperm(n, generator=gs)[:min(n, k)])[0]
+        for s, logits in out["sem_logits_at_scales"].items():
+            for i, l in enumerate(logits):
+                r = sample(l.F.shape[0])
+                arrays[f"sem_{s}_{i}_rows"], arrays[f"sem_{s}_{i}_F"] = r, l.F[r]
+                arrays[f"sem_{s}_{i}_absmean"] = l.F.abs().mean()
+            arrays[f"sem_{s}_C"] = logits[0].C.to(torch.int16)
+            assert all(torch.equal(l.C, logits[0].C) for l in logits)
+        for i, p in enumerate(out["panop_predictions"]):
+            v = p["voxel_logits"]
+            r = sample(v.F.shape[0])
+            arrays[f"panop_{i}_query_logits"] = p["query_logits"]
+            arrays[f"panop_{i}_voxel_C"], arrays[f"panop_{i}_voxel_rows"], arrays[f"panop_{i}_voxel_F"] = v.C.to(torch.int16), r, v.F[r]
+            arrays[f"panop_{i}_voxel_absmean"] = v.F.abs().mean()
+            for j, aux in enumerate(p["aux_outputs"]):
+                arrays[f"panop_{i}_aux{j}_query_logits"] = aux["query_logits"]
+        for i, t in enumerate(out["sem_logits_pruneds"]):
+            arrays[f"sem_pruned_{i}_C"] = t.C.to(torch.int16)
+        # the reference's attention-mask decisions `mask logit > 0` per (layer, subnet): rows = the subnet's voxels in the
+        # order of panop_{i}_voxel_C, one more row = its padded rows' decision (all padded rows are identical)
+        assert len(mask_logits) == 3
+        for j, (om, vc) in enumerate(mask_logits):
+            for i in range(n_infers):
+                n_i = out["panop_predictions"][i]["voxel_logits"].F.shape[0]
+                assert torch.equal(vc[i, :n_i].int(), out["panop_predictions"][i]["voxel_logits"].C.int())
+                bits = om[i, :n_i] > 0
+                pad = (om[i, n_i] > 0) if om.shape[1] > n_i else torch.zeros(om.shape[2], dtype=torch.bool)
+                arrays[f"mask_{j}_{i}_bits"] = np.packbits(torch.cat([bits, pad[None]]).numpy(), axis=1)
+        save(f"unet_{tag}.npz", **arrays)
+        return
+    raise RuntimeError("no seed gave a scene of the wanted size")
+
+
 def ensemble_inputs(seed=0, n_sub=3, Q=6):
     """Synthetic per-subnet outputs with matching structure: Q-2 blob instances + background, query ids
     permuted per subnet, query classes mixing things and (duplicated) stuff."""
@@ -395,6 +506,9 @@ if __name__ == "__main__":
     if "--ensemble-only" in sys.argv:
         golden_ensemble()
         sys.exit(0)
+    if "--wide-only" in sys.argv:
+        golden_unet_wide()
+        sys.exit(0)
     if "--leaf-only" in sys.argv:
         golden_transform_and_matching()
         sys.exit(0)
@@ -404,6 +518,7 @@ if __name__ == "__main__":
     golden_unet(1, False, "m1_light")
     golden_unet(2, False, "m2_light")
     golden_unet(1, True, "m1_heavy")
+    golden_unet_wide()
     golden_ensemble()
     golden_transform_and_matching()
     golden_input_stage()

@@ -130,7 +130,7 @@ def golden_checkpoint():
     from pasco.models.unet3d_sparse_v2 import UNet3DV2, CylinderFeat
     from pasco.models.transformer.transformer_predictor_v2 import TransformerPredictorV2
     torch.manual_seed(21)
-    f, n_infers, nq, in_ch = 8, 2, 6, 24
+    f, n_infers, nq, in_ch = 8, 2, 6, 283      # the frame files carry 283-channel point features
     tp = TransformerPredictorV2(dropout=0.0, nheads=8, hidden_dim=48, enc_layers=0, num_queries=nq, dim_feedforward=96,
                                 dec_layers=1, aux_loss=False, mask_dim=f, n_infers=n_infers, query_sample_ratio=1.0,
                                 in_channels=[f * 4, f * 2, f])

@@ -126,17 +126,54 @@ def test_lightning_checkpoint_loads_into_pasconet(tmp_path):
         D.net_from_checkpoint(p2)
 
 
-def test_loaded_frame_runs_through_the_graph(oracle_registered):
-    """Files -> a0 contract -> `PascoNet.step_inference` on the checker backend: the formats feed the path."""
+def _frame_through_checkpoint(device):
+    """The reference's real entry (scripts/eval.py:69-76: `Net.load_from_checkpoint` -> `trainer.test`): a frame read from
+    files in the reference's on-disk formats (kitti_dataset.py:290-303, 423-430) + a Lightning checkpoint ->
+    `PascoNet.step_inference`."""
     g = gold("io_items.npz")
     reader = D.FrameReader(MINI, os.path.join(MINI, "preprocess"))
-    batch = reader.batch(SEQ, FRAME, [torch.from_numpy(g["eye_T"]), torch.from_numpy(g["rigid_T"])], embedding_index=0)
-    from pasco_amd.graph import PascoNet
-    torch.manual_seed(2)
-    net = PascoNet(n_classes=20, n_infers=2, in_channels=283, f=8, num_queries=6, heavy_decoder=False).eval()
+    Ts = [torch.from_numpy(g["eye_T"]), torch.from_numpy(g["rigid_T"])]
+    batch = reader.batch(SEQ, FRAME, Ts, embedding_index=0)
+    # the loaded frame IS what the reference's own dataset built from the same files
+    assert torch.equal(batch["in_coords"][1], torch.from_numpy(g["rigid_in_coord"]))
+    assert torch.equal(batch["global_min_Cs"], torch.from_numpy(g["global_min_Cs"]))
+    net = D.net_from_checkpoint(os.path.join(GOLD, "net_mini.ckpt"), device=device)
+    assert net.feat.PPmodel[1].in_features == batch["in_feats"][0].shape[1] == 283
     ext = (batch["global_max_Cs"] - batch["global_min_Cs"] + 1).tolist()
     net.ensembler.scene_size = tuple(int(v) for v in ext)
+    dev = torch.device(device)
     with torch.no_grad():
-        x = net.prepare_input(batch["in_feats"], batch["in_coords"])
+        x = net.prepare_input([t.to(dev) for t in batch["in_feats"]], [t.to(dev) for t in batch["in_coords"]])
         ret = net(x, batch["global_min_Cs"], batch["global_max_Cs"], batch["min_Cs"], batch["max_Cs"])
+    return batch, ret
+
+
+def test_loaded_frame_runs_through_the_graph(oracle_registered):
+    """Files -> a0 contract -> checkpoint -> `PascoNet` forward on the checker backend: the formats feed the path."""
+    batch, ret = _frame_through_checkpoint("cpu")
     assert len(ret["panop_predictions"]) == 2 and ret["sem_logits_at_scales"][1][0].F.shape[1] == 20
+
+
+@pytest.mark.gpu
+def test_loaded_frame_and_checkpoint_on_the_hip_path(hip, oracle_registered):
+    """SURVEY.md 8(f) item 4 on the GPU: the same files and checkpoint through libpascohip.so, against the oracle run of the
+    same frame: coordinates of every sparse output identical and in the same order, logits within the path's contract
+    |got - exp| <= 1e-3 (|exp| + 0.25 mean |exp|)."""
+    _, exp = _frame_through_checkpoint("cpu")
+    _, got = _frame_through_checkpoint("cuda")
+
+    def close(a, b, what):
+        scale = float(b.abs().mean())
+        rel = float(((a.cpu() - b).abs() / (b.abs() + 0.25 * scale)).max())
+        assert rel <= 1e-3, f"{what}: element-wise relative error {rel:.3e}"
+        return rel
+    worst = 0.0
+    for s in exp["sem_logits_at_scales"]:
+        for i, (a, b) in enumerate(zip(got["sem_logits_at_scales"][s], exp["sem_logits_at_scales"][s])):
+            assert torch.equal(a.C.cpu(), b.C), f"scale {s} subnet {i}: coordinates / row order"
+            worst = max(worst, close(a.F, b.F, f"sem logits scale {s} subnet {i}"))
+    for i, (a, b) in enumerate(zip(got["panop_predictions"], exp["panop_predictions"])):
+        assert torch.equal(a["voxel_logits"].C.cpu(), b["voxel_logits"].C)
+        worst = max(worst, close(a["voxel_logits"].F, b["voxel_logits"].F, f"voxel logits subnet {i}"))
+        worst = max(worst, close(a["query_logits"], b["query_logits"], f"query logits subnet {i}"))
+    print(f"[f4 on the GPU] files + checkpoint through libpascohip.so vs the oracle: worst relative error {worst:.2e}")

@@ -55,7 +55,8 @@ def test_split_conv_matches_oracle_and_fp64(hip, oracle, cin, cout, n):
     e32 = float((f32 - ref).abs().max() / scale)
     esp = float((spl - ref).abs().max() / scale)
     print(f"cin={cin} cout={cout}: max err / mean|y|  fp32 MFMA {e32:.2e}   f16x3 {esp:.2e}")
-    assert esp < 8 * e32 + 2e-6, (e32, esp)
+    # the split path is at (or below) the exact fp32 MFMA path's error against fp64
+    assert esp <= 1.5 * e32 + 2e-6, (e32, esp)
 
 
 def test_split_conv_identity_map_and_strided(hip, oracle):

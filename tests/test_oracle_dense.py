@@ -191,6 +191,40 @@ def test_prune_union_dense_roundtrip(oracle_registered):
     assert torch.equal(t.F, sample(d, t.C, (0, 0, 0), 1))
 
 
+def _dense_wrap_case(device):
+    """`SparseTensor.dense(shape, min_coordinate)` assigns by advanced indexing upstream [ME-upstream:
+    MinkowskiSparseTensor.dense: `dense_F[b, :, x, y, z] = F`]: a coordinate below `min_coordinate` lands on a NEGATIVE
+    index, which wraps around python-style.  PaSCo relies on it for the zero-padded rows of the attention mask
+    (transformer_predictor_v2.py:263-279).  Compared with torch's own advanced indexing."""
+    g = torch.Generator().manual_seed(3)
+    ts, mn = 2, torch.tensor([8, -4, 0], dtype=torch.int32)
+    X, Y, Z = 6, 5, 4
+    xyz = torch.stack([torch.randint(-2, X, (40,), generator=g), torch.randint(-3, Y, (40,), generator=g),
+                       torch.randint(0, Z, (40,), generator=g)], 1)
+    xyz = torch.unique(xyz, dim=0)
+    # distinct sites after the wrap (several rows on one site are unordered upstream)
+    site = (xyz % torch.tensor([X, Y, Z])).tolist()
+    keep = [i for i, s in enumerate(site) if site.index(s) == i]
+    xyz = xyz[keep]
+    coords = torch.cat([torch.zeros(xyz.shape[0], 1, dtype=torch.int64), xyz * ts + mn], 1).int()
+    feats = torch.randn(xyz.shape[0], 3, generator=g)
+    x = ME.SparseTensor(feats.to(device), coords.to(device), tensor_stride=ts)
+    d, _, _ = x.dense(shape=torch.Size([1, 3, X, Y, Z]), min_coordinate=mn)
+    exp = torch.zeros(1, 3, X, Y, Z)
+    exp[0, :, xyz[:, 0], xyz[:, 1], xyz[:, 2]] = feats.t()          # torch's negative-index wrap
+    assert bool((xyz < 0).any())
+    assert torch.equal(d.cpu(), exp)
+
+
+def test_dense_wraps_negative_indices_like_upstream(oracle_registered):
+    _dense_wrap_case("cpu")
+
+
+@pytest.mark.gpu
+def test_dense_wraps_negative_indices_like_upstream_gpu(hip):
+    _dense_wrap_case("cuda")
+
+
 def test_fused_prologue_epilogue(oracle):
     """conv_fwd's fused BN/ReLU prologue + bias/BN/act/residual epilogue == unfused composition."""
     torch.manual_seed(13)

@@ -29,13 +29,15 @@ pytestmark = pytest.mark.gpu
 
 
 FLOOR = 1.0          # |got - exp| <= 1e-3 (|exp| + FLOOR * mean |exp|): torch.allclose(rtol = 1e-3, atol = 1e-3 mean |exp|)
+FLOOR_FROZEN = 0.25  # the same contract with the attention-mask decisions of the oracle run forced into the HIP run: what is
+                     # left is arithmetic alone, held to the floor two HIP paths are held to against each other
 PROB_ATOL = 2e-3     # probabilities ([0, 1]): sigmoid / softmax of logits that agree to ~7e-4 of their mean magnitude
 
 
-def _rel(a, b):
+def _rel(a, b, floor=FLOOR):
     scale = float(b.abs().mean())
     err = float((a - b).abs().max())
-    rel = float(((a - b).abs() / (b.abs() + FLOOR * scale)).max())
+    rel = float(((a - b).abs() / (b.abs() + floor * scale)).max())
     return err / max(scale, 1e-30), rel
 
 
@@ -46,13 +48,15 @@ def test_s10_step_hip_vs_oracle_end_to_end(hip, oracle):
 
     scene_cpu = make_scene(seed=0, n_infers=3, in_channels=283)
 
-    def run(device):
+    def run(device, unet_only=False):
         net = bench.build_net(3, 283, device)
         sc = scene_cpu.to(device)
         tk = TeacherKeep(sc, device)
         with torch.no_grad():
             x = net.prepare_input(sc.in_feats, sc.in_coords)
             ret = net(x, sc.global_min_Cs, sc.global_max_Cs, sc.min_Cs, sc.max_Cs, keep_override=tk)
+            if unet_only:
+                return ret
             conf, sem_probs, panop = net.ensemble(ret, sc.Ts)
             from pasco_amd.graph.panoptic import panoptic_inference
             pis = [panoptic_inference(p["voxel_probs"], p["query_probs"], overlap_threshold=net.overlap_threshold,
@@ -73,10 +77,13 @@ def test_s10_step_hip_vs_oracle_end_to_end(hip, oracle):
         recorded.append(tuple(t.clone() for t in out))
         return out
 
+    from tests import mask_freeze
+    mask_decisions = []                # the oracle run's attention-mask decisions (mask logit > 0), per decoder layer
     backend.register_checker_backend(oracle)
     Ensembler.match_queries = staticmethod(recording)
     try:
-        exp = run(torch.device("cpu"))
+        with mask_freeze.recording(mask_decisions):
+            exp = run(torch.device("cpu"))
     finally:
         Ensembler.match_queries = staticmethod(match_orig)
         backend.register_checker_backend(None)
@@ -119,6 +126,31 @@ def test_s10_step_hip_vs_oracle_end_to_end(hip, oracle):
           f"{worst['elementwise']:.2e} over {n_rows} semantic rows + the voxel / query logits")
     for f in failures:
         print("[s10 e2e] BEYOND 1e-3:", f)
+    # ---- the same step with the oracle run's attention-mask decisions forced into the HIP run -----------------------------
+    # The masks of decoder layer l are thresholds (mask logit > 0, transformer_predictor_v2.py:224) of layer l - 1's
+    # prediction: a near-zero logit that the two arithmetics round to different sides changes one key of one query's
+    # attention.  With the decisions frozen, what remains is arithmetic alone and must meet the tighter floor.
+    stats = {}
+    with mask_freeze.forcing(mask_decisions, stats):
+        frozen = run(torch.device("cuda", 0), unet_only=True)
+    torch.cuda.synchronize()
+    fw = {"max/mean": 0.0, "elementwise": 0.0}
+    pairs = [(a.F, b.F, f"sem logits scale {s} subnet {i}") for s in e_ret["sem_logits_at_scales"]
+             for i, (a, b) in enumerate(zip(frozen["sem_logits_at_scales"][s], e_ret["sem_logits_at_scales"][s]))]
+    for i, (a, b) in enumerate(zip(frozen["panop_predictions"], e_ret["panop_predictions"])):
+        pairs += [(a["voxel_logits"].F, b["voxel_logits"].F, f"voxel logits subnet {i}"),
+                  (a["query_logits"], b["query_logits"], f"query logits subnet {i}")]
+    for a, b, what in pairs:
+        m, r = _rel(a.cpu(), b, FLOOR_FROZEN)
+        fw["max/mean"], fw["elementwise"] = max(fw["max/mean"], m), max(fw["elementwise"], r)
+        if r > 1e-3:
+            failures.append(f"frozen masks: {what}: element-wise relative {r:.3e} (floor {FLOOR_FROZEN} mean |y|)")
+    print(f"[s10 e2e] attention-mask decisions: {stats['decisions']} in {stats['calls']} layers, {stats['differ']} decided "
+          f"differently by the HIP run on its own, {stats['differ_above_noise']} of them with a logit above 1e-3 of the mean")
+    print(f"[s10 e2e] logits with the oracle's mask decisions forced: worst max-error / mean |y| {fw['max/mean']:.2e}, "
+          f"element-wise relative (floor {FLOOR_FROZEN}) {fw['elementwise']:.2e}  [free-running: {worst['max/mean']:.2e}]")
+    if stats["differ_above_noise"]:
+        failures.append(f"{stats['differ_above_noise']} attention-mask decisions differ with a logit above the noise")
 
     # ensembled semantic probabilities + confidences (dense [C, X, Y, Z] / [X, Y, Z] per subnet and for the ensemble)
     d_sem = max(float((a.cpu() - b).abs().max()) for a, b in zip(got[2], exp[2]))
