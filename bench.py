@@ -192,10 +192,12 @@ def build_net(n_infers, in_channels, device, heavy=False, n_classes=20):
     return net.eval().to(device)
 
 
-def run_scene(net, scene, teacher, window=None):
+def run_scene(net, scene, teacher, window=None, panoptic=False):
     """One step = the reference's `Net.forward(return_ensemble=True)` preceded by its input stage:
     point MLP + merge, U-Net + mask transformer, semantic + panoptic ensembling.  `window` (optional
-    list) receives HIP-event pairs around the reference's own "inference time" window (`self.unet3d`)."""
+    list) receives HIP-event pairs around the reference's own "inference time" window (`self.unet3d`).
+    `panoptic`: also `panoptic_inference` of the M subnets' outputs and the ensemble's = the whole of the reference's
+    `Net.step_inference` (net_panoptic_sparse.py:539-608) without its metric bookkeeping."""
     x = net.prepare_input(scene.in_feats, scene.in_coords)
     if window is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -205,6 +207,8 @@ def run_scene(net, scene, teacher, window=None):
         e1.record()
         window.append((e0, e1))
     ssc_conf, sem_probs, panop = net.ensemble(ret, scene.Ts)
+    if panoptic:
+        net.panoptic(panop, ssc_conf)
     return ret, panop
 
 
@@ -476,14 +480,14 @@ def main():
     from pasco_amd.graph.serve import SceneServer, vet_cached_blocks
     if heads and world > 1:
         args.in_flight = 1                  # one communicator: collectives are issued from one thread
-    ctx = {"window": None}
+    ctx = {"window": None, "panoptic": False}
 
     def one_step(i):
         """Step i of the loop: scene i mod #scenes through the whole hot path."""
         j = i % len(scenes)
         if heads and world > 1:
             return step_fn(net, scenes[j], teachers[j])
-        return run_scene(net, scenes[j], teachers[j], ctx["window"])
+        return run_scene(net, scenes[j], teachers[j], ctx["window"], ctx["panoptic"])
 
     # worker threads, each bound to its own HIP stream, draw step numbers from a shared counter (pasco_amd/graph/serve.py)
     server = SceneServer(device, one_step, in_flight=args.in_flight,
@@ -555,7 +559,7 @@ def main():
     if rank == 0:
         per = [round((b - a) * 1e3, 1) for a, b in zip(marks[:-1], marks[1:])]
         print(f"[bench] per-step host ms: {per}", file=sys.stderr, flush=True)
-    one_in_flight = None
+    one_in_flight = step_inference = None
     if args.in_flight > 1 and world == 1:          # the same K steps, one scene at a time on one stream (no per-launch events)
         run_steps(0, len(scenes), 1)               # untimed: the main stream's pool as the collector-less loop leaves it
         window = []
@@ -571,6 +575,30 @@ def main():
         one_in_flight["device_mallocs"] = alloc_log["after_in_flight_1"].get("device_mallocs", 0) - mallocs0
         if window:      # the reference's own timing window (`self.unet3d`, README.md:448-449), one scene at a time
             one_in_flight["unet_window_ms"] = round(sum(a.elapsed_time(b) for a, b in window) / len(window), 3)
+        # the same loop with `panoptic_inference` of the M + 1 outputs behind every step: Net.step_inference as a whole
+        ctx["panoptic"] = True
+        try:
+            run_steps(0, len(scenes), 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(0, args.steps, 1)
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t0) / args.steps
+            step_inference = {"ms_per_step": round(dts * 1e3, 3), "scenes_per_s": round(1.0 / dts, 4), "steps": args.steps,
+                              "in_flight": 1, "panoptic_added_ms": round((dts - dt1) * 1e3, 3),
+                              "what": "in_flight_1's step + panoptic_inference of the M subnets' outputs and the ensemble's "
+                                      "(3 launches each on the sparse rows, one device->host copy of the segment tables)"}
+            if args.in_flight > 1:
+                run_steps(0, args.in_flight * len(scenes), args.in_flight)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run_steps(0, args.steps, args.in_flight)
+                torch.cuda.synchronize()
+                dtf = (time.perf_counter() - t0) / args.steps
+                step_inference["in_flight_%d" % args.in_flight] = {"ms_per_step": round(dtf * 1e3, 3),
+                                                                   "scenes_per_s": round(1.0 / dtf, 4)}
+        finally:
+            ctx["panoptic"] = False
         # the roofline's per-launch HIP events: a separate one-at-a-time pass, so that neither the events nor the pair
         # counts the profiler launches perturb a reported step time
         if not args.no_profile:
@@ -695,6 +723,8 @@ def main():
             res["exchange"] = ex
         if one_in_flight is not None:
             res["in_flight_1"] = one_in_flight
+        if step_inference is not None:
+            res["step_inference"] = step_inference
         if gc_row is not None:
             res["gc_enabled"] = gc_row
         if exact is not None:
@@ -707,6 +737,9 @@ def main():
             also["in_flight_1_ms_per_step"] = one_in_flight["ms_per_step"]
             if "unet_window_ms" in one_in_flight:
                 also["in_flight_1_unet_window_ms"] = one_in_flight["unet_window_ms"]
+        if step_inference is not None:
+            also["step_inference_ms"] = step_inference["ms_per_step"]
+            also["step_inference_panoptic_added_ms"] = step_inference["panoptic_added_ms"]
         if exact is not None:
             also["exact_fp32_mfma_scenes_per_s"] = exact["value"]
         if "unet_window_ms" in res:

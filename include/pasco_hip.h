@@ -38,7 +38,7 @@ extern "C" {
 /* 2: ph_conv_desc grew (split_exp2, out_split, window / axis-table / row-list blocks), ph_map_insert and ph_split_rows gained
  * their `status` argument.  A caller built against another version must be rebuilt: the binding checks the version AND the size
  * of ph_conv_desc before the first call. */
-#define PH_ABI_VERSION 2
+#define PH_ABI_VERSION 3
 #define PH_MAX_KVOL 64 /* largest kernel volume of one nbr_build / pooling call (4x4x4 window); conv_fwd takes tables of up to 4096 offsets (dense bottleneck: 7x7x5 = 245) */
 
 /* activation codes for fused prologue / epilogue */
@@ -463,6 +463,31 @@ int PH_FN(points_link)(const int64_t *xyz, int64_t n, const int64_t *h_starts, i
 int PH_FN(cells_max)(const float *h, int32_t c, const int32_t *head, const int32_t *next, int64_t v, int32_t m,
                      const int32_t *sites, const int32_t *h_lo3, const int32_t *h_dims3, float *out, int32_t *coords,
                      int32_t *status, ph_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Panoptic post-processing (reference: pasco/models/helper.py:91-303 `panoptic_inference`, called for each of the M + 1
+ * outputs by Net.step_inference, net_panoptic_sparse.py:578-608).  All tables are int32 [*, 128] rows (q <= 128 queries).
+ *   panop_queries  qp fp32 [q, c1] class probabilities (c1 = classes + dustbin, c1 <= 64) -> qtab int32 [4, 128]:
+ *                  row 0 kidx[q'] = rank of query q' among the KEPT queries (arg-max class != 0, != dustbin, probability >
+ *                  thr: helper.py:135-140; ascending query order) or -1, row 1 kq[k] = query of kept k, row 2 the arg-max
+ *                  class of every query (first maximum), row 3 its probability (float bits); nk[0] = number kept
+ *   panop_argmax   masks fp32 [n, q] mask probabilities -> per voxel: winner = kept index with the largest prob x mask
+ *                  (smallest index on ties; -1 when nothing is kept), own = mask of the winner >= occ_thr, conf = m_w /
+ *                  (sum_k m_k + 1e-8), vunc = max_k (p_k m_k) / sum_k (p_k m_k) (helper.py:150-153, 186, 199-206, 235-241);
+ *                  areas int32 [2, 128] += (voxels won and owned by kept k, voxels with m_k >= occ_thr); caller zeroes
+ *   panop_write    replays the reference's sequential walk over the kept queries (helper.py:188-250: mask_area /
+ *                  original_area < overlap_thr skips, `thing_mask` bit c = class c is a thing, stuff segments of one class
+ *                  merge and then write the panoptic id only) and writes per voxel panoptic id / semantic class /
+ *                  ins_unc (query probability) / vox_conf / vox_unc; seg int32 [5, 128] (may be NULL): rows id, isthing,
+ *                  category, query id of every segment, seg[4][0] = number of segments.  No host read anywhere.
+ * ------------------------------------------------------------------------------------------- */
+int PH_FN(panop_queries)(const float *qp, int32_t q, int32_t c1, float thr, int32_t *qtab, int32_t *nk, ph_stream_t stream);
+int PH_FN(panop_argmax)(const float *masks, int64_t n, int32_t q, const int32_t *qtab, float occ_thr, int32_t *winner,
+                        uint8_t *own, float *conf, float *vunc, int32_t *areas, ph_stream_t stream);
+int PH_FN(panop_write)(int64_t n, const int32_t *winner, const uint8_t *own, const float *conf, const float *vunc,
+                       const int32_t *areas, const int32_t *qtab, const int32_t *nk, double overlap_thr, uint64_t thing_mask,
+                       int32_t *panoptic, int32_t *semantic, float *ins_unc, float *vox_conf, float *vox_unc, int32_t *seg,
+                       ph_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1133,3 +1133,108 @@ int pho_rowlist_pack(const int32_t *pairs_in, const int32_t *pairs_out, const in
   }
   return 0;
 }
+
+
+/* ---- panoptic post-processing (pasco/models/helper.py:91-303), see include/pasco_hip.h panop_* ---------------------- */
+#define PANOP_QMAX 128
+
+int pho_panop_queries(const float *qp, int32_t q, int32_t c1, float thr, int32_t *qtab, int32_t *nk, ph_stream_t stream) {
+  (void)stream;
+  if (q < 1 || q > PANOP_QMAX || c1 < 2 || c1 > 64) return fail("panop_queries: 1 <= q <= 128 queries, 2 <= c1 <= 64");
+  int k = 0;
+  for (int t = 0; t < PANOP_QMAX; ++t) {
+    int label = 0;
+    float prob = 0.f;
+    int keep = 0;
+    if (t < q) {                                            /* helper.py:132-140: probs, labels = query_probs.max(-1) */
+      prob = qp[(int64_t)t * c1];
+      for (int c = 1; c < c1; ++c)
+        if (qp[(int64_t)t * c1 + c] > prob) prob = qp[(int64_t)t * c1 + c], label = c;
+      keep = label != 0 && label != c1 - 1 && prob > thr;
+    }
+    qtab[0 * PANOP_QMAX + t] = keep ? k : -1;
+    qtab[2 * PANOP_QMAX + t] = label;
+    memcpy(&qtab[3 * PANOP_QMAX + t], &prob, 4);
+    if (keep) qtab[1 * PANOP_QMAX + k++] = t;
+  }
+  nk[0] = k;
+  return 0;
+}
+
+int pho_panop_argmax(const float *masks, int64_t n, int32_t q, const int32_t *qtab, float occ_thr, int32_t *winner,
+                     uint8_t *own, float *conf, float *vunc, int32_t *areas, ph_stream_t stream) {
+  (void)stream;
+  if (q < 1 || q > PANOP_QMAX) return fail("panop_argmax: 1 <= q <= 128 queries");
+  for (int64_t r = 0; r < n; ++r) {
+    const float *row = masks + r * q;
+    float bv = -1.f, bm = 0.f, sm = 0.f, sc = 0.f;
+    int bk = -1;
+    for (int c = 0; c < q; ++c) {
+      const int k = qtab[c];
+      if (k < 0) continue;
+      float p;
+      memcpy(&p, &qtab[3 * PANOP_QMAX + c], 4);
+      const float m = row[c], v = p * m;                    /* helper.py:158-160 combined = prob * mask */
+      if (m >= occ_thr) areas[PANOP_QMAX + k] += 1;         /* :203-205 original_area */
+      if (v > bv) bv = v, bk = k, bm = m;                   /* :186 first maximum */
+      sm += m;
+      sc += v;
+    }
+    const int mine = bk >= 0 && bm >= occ_thr;              /* :199-201 */
+    if (mine) areas[bk] += 1;
+    winner[r] = bk;
+    own[r] = (uint8_t)mine;
+    conf[r] = bk >= 0 ? bm / (sm + 1e-8f) : 0.f;            /* :150-153 */
+    vunc[r] = bk >= 0 ? bv / sc : 0.f;                      /* :236-239 */
+  }
+  return 0;
+}
+
+int pho_panop_write(int64_t n, const int32_t *winner, const uint8_t *own, const float *conf, const float *vunc,
+                    const int32_t *areas, const int32_t *qtab, const int32_t *nk, double overlap_thr, uint64_t thing_mask,
+                    int32_t *panoptic, int32_t *semantic, float *ins_unc, float *vox_conf, float *vox_unc, int32_t *seg,
+                    ph_stream_t stream) {
+  (void)stream;
+  int s_seg[PANOP_QMAX], s_full[PANOP_QMAX], s_cls[PANOP_QMAX], stuff_seg[64];
+  float s_prob[PANOP_QMAX];
+  memset(stuff_seg, 0, sizeof(stuff_seg));
+  const int K = nk[0];
+  int current = 0;
+  for (int k = 0; k < K; ++k) {                             /* helper.py:188-250 */
+    const int qid = qtab[1 * PANOP_QMAX + k];
+    const int cls = qtab[2 * PANOP_QMAX + qid];
+    float prob;
+    memcpy(&prob, &qtab[3 * PANOP_QMAX + qid], 4);
+    const int ma = areas[k], oa = areas[PANOP_QMAX + k];
+    s_seg[k] = 0, s_full[k] = 0, s_cls[k] = cls, s_prob[k] = prob;
+    if (!(ma > 0 && oa > 0) || (double)ma / (double)oa < overlap_thr) continue;
+    const int isthing = cls < 64 && ((thing_mask >> cls) & 1ull);
+    if (!isthing) {
+      if (cls < 64 && stuff_seg[cls] != 0) {
+        s_seg[k] = stuff_seg[cls];
+        continue;
+      }
+      if (cls < 64) stuff_seg[cls] = current + 1;
+    }
+    ++current;
+    s_seg[k] = current, s_full[k] = 1;
+    if (seg) {
+      seg[0 * PANOP_QMAX + current - 1] = current;
+      seg[1 * PANOP_QMAX + current - 1] = isthing;
+      seg[2 * PANOP_QMAX + current - 1] = cls;
+      seg[3 * PANOP_QMAX + current - 1] = qid;
+    }
+  }
+  if (seg) seg[4 * PANOP_QMAX] = current;
+  for (int64_t i = 0; i < n; ++i) {
+    const int w = winner[i];
+    const int mine = own[i] != 0 && w >= 0;
+    const int hit = mine && s_seg[w] != 0, full = mine && s_full[w] != 0;
+    panoptic[i] = hit ? s_seg[w] : 0;
+    semantic[i] = full ? s_cls[w] : 0;
+    ins_unc[i] = full ? s_prob[w] : 0.f;
+    vox_conf[i] = full ? conf[i] : 0.f;
+    vox_unc[i] = full ? vunc[i] : 0.f;
+  }
+  return 0;
+}

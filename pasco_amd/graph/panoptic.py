@@ -4,11 +4,20 @@ Queries with a non-empty, non-dustbin class and probability > object_mask_thresh
 (argmax of query prob x mask prob); a query keeps its voxels if enough of its own mask
 (mask prob >= vox_occ_threshold) survived the competition; stuff segments of one class merge.
 
-The reference walks the kept queries in a Python loop with ~6 `.item()` host syncs per query.  Here
-the per-query areas come from one pass over the voxels (bincount), the segment-id bookkeeping - a
-sequential walk over <= 100 queries - runs on the host on those counts (one device->host copy), and
-the per-voxel outputs are one gather through per-query tables.  Results are identical, including the
-reference's quirk that voxels of a *merged* stuff segment keep semantic class 0.
+The reference walks the kept queries in a Python loop with ~6 `.item()` host syncs per query and returns dense
+[X, Y, Z] maps plus a [K, X, Y, Z] tensor of all kept masks (838 MB at K = 100) for every output.
+
+Device path (`panoptic_inference_many`, round 5; include/pasco_hip.h `panop_*`, csrc/panop.hip): per output three launches
+on the SPARSE rows - classify the queries, one pass over the [N, Q] mask probabilities (winner per voxel + per-query areas),
+one element-wise pass that replays the reference's sequential walk over the kept queries on the device and writes the
+per-voxel results - no host read in between; the segment tables of ALL outputs of a step (the M subnets + the ensemble,
+net_panoptic_sparse.py:578-608) come back in ONE device->host copy.  The dense maps are built when somebody asks for them
+(`PanopticResult.__missing__`), not per step.
+
+Torch path (`_panoptic_inference_torch`: tensors no backend serves, batches of more than one scene): per-query areas from
+one pass over the voxels (bincount), the segment-id bookkeeping on the host on those counts, per-voxel outputs as one gather
+through per-query tables.  Both give the reference's results, including its quirk that voxels of a *merged* stuff segment
+keep semantic class 0.
 """
 from __future__ import annotations
 
@@ -31,10 +40,94 @@ def to_dense(values: torch.Tensor, coords: torch.Tensor, scene_size, min_coords=
     return out
 
 
+DENSE_KEYS = ("panoptic_seg_denses", "semantic_seg_denses", "ins_uncertainty_denses", "vox_confidence_denses",
+              "vox_uncertainty_denses")
+
+
+class PanopticResult(dict):
+    """What `panoptic_inference` returns (helper.py:291-303), with the sparse rows computed and the dense maps made on first
+    access: `res["semantic_seg_denses"]` etc. [bs, X, Y, Z], `res["vox_all_mask_probs_denses"]` list of [K, X, Y, Z].  Extra
+    keys of the device path: "semantic_seg_sparses", "ins_uncertainty_sparses", "vox_confidence_sparses",
+    "vox_uncertainty_sparses" (lists of [N] rows, like the reference's "panoptic_seg_sparses")."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._lazy = None      # (coords, scene_size, min_C, rows dict, masks, K)
+
+    def __missing__(self, key):
+        if self._lazy is None or key not in DENSE_KEYS + ("vox_all_mask_probs_denses",):
+            raise KeyError(key)
+        coords, scene_size, min_C, rows, masks, kept = self._lazy
+        dense = lambda v: to_dense(v.unsqueeze(-1) if v.dim() == 1 else v, coords, scene_size, min_C).squeeze()
+        if key == "vox_all_mask_probs_denses":
+            kept_t = torch.as_tensor(kept, dtype=torch.long, device=masks.device)
+            full = (rows["semantic"] != 0)[:, None]          # a written class is never 0 (class 0 queries are not kept)
+            val = [dense(torch.where(full, masks[:, kept_t], torch.zeros((), dtype=masks.dtype, device=masks.device)))]
+        else:
+            src = {"panoptic_seg_denses": "panoptic", "semantic_seg_denses": "semantic", "ins_uncertainty_denses": "ins_unc",
+                   "vox_confidence_denses": "vox_conf", "vox_uncertainty_denses": "vox_unc"}[key]
+            val = torch.stack([dense(rows[src])])
+        self[key] = val
+        return val
+
+
+def _device_backend(t: torch.Tensor):
+    import os
+    if os.environ.get("PASCO_PANOPTIC_KERNEL", "1") == "0":
+        return None
+    from ..me.backend import backend_for
+    try:
+        be = backend_for(t.device)
+    except RuntimeError:
+        return None
+    return be if be.has("panop_write") else None
+
+
+def panoptic_inference_many(outputs, overlap_threshold: float, object_mask_threshold: float, thing_ids: Sequence[int], min_C,
+                            scene_size, input_query_logit: bool = True, input_voxel_logit: bool = False,
+                            vox_occ_threshold: float = 0.3) -> List[dict]:
+    """`panoptic_inference` for several (voxel_output, query_output) pairs - the M subnets' outputs and the ensemble's of one
+    step (net_panoptic_sparse.py:578-608) - with ONE device->host copy for all their segment tables."""
+    outputs = list(outputs)
+    be = _device_backend(outputs[0][0].F) if outputs else None
+    if be is None or any(q.shape[0] != 1 or q.shape[1] > be.PANOP_QMAX or q.shape[2] > 64 for _, q in outputs):
+        return [_panoptic_inference_torch(v, q, overlap_threshold, object_mask_threshold, thing_ids, min_C, scene_size,
+                                          input_query_logit, input_voxel_logit, vox_occ_threshold) for v, q in outputs]
+    work = []
+    for v, q in outputs:
+        masks = (torch.sigmoid(v.F) if input_voxel_logit else v.F).contiguous()
+        qp = (F.softmax(q[0], dim=-1) if input_query_logit else q[0]).contiguous().float()
+        rows = be.panoptic_rows(masks, qp, object_mask_threshold, overlap_threshold, vox_occ_threshold, thing_ids)
+        work.append((v, masks, qp, rows))
+    # one copy for every output's tables: qtab (rows 0-3) | nk (4) | seg (5-9) | areas (10-11), 128 int32 each
+    tabs = torch.stack([w[3]["tabs"] for w in work]).cpu()
+    results = []
+    for (v, masks, qp, rows), t in zip(work, tabs):
+        probs = t[3].view(torch.float32)
+        K, n_seg = int(t[4, 0]), int(t[9, 0])
+        infos = [{"id": int(t[5, s]), "isthing": bool(t[6, s]), "category_id": int(t[7, s]), "query_id": int(t[8, s]),
+                  "confidence": float(probs[int(t[8, s])]), "all_class_probs": qp[int(t[8, s])]} for s in range(n_seg)]
+        res = PanopticResult(panoptic_seg_sparses=[rows["panoptic"]], segments_infos=[infos],
+                             semantic_seg_sparses=[rows["semantic"]], ins_uncertainty_sparses=[rows["ins_unc"]],
+                             vox_confidence_sparses=[rows["vox_conf"]], vox_uncertainty_sparses=[rows["vox_unc"]])
+        res._lazy = (v.C, scene_size, min_C, rows, masks, [int(k) for k in t[1, :K]])
+        results.append(res)
+    return results
+
+
 def panoptic_inference(voxel_output: ME.SparseTensor, query_output: torch.Tensor, overlap_threshold: float,
                        object_mask_threshold: float, thing_ids: Sequence[int], min_C, scene_size,
                        input_query_logit: bool = True, input_voxel_logit: bool = False,
                        vox_occ_threshold: float = 0.3):
+    """The reference's signature (helper.py:91-103); one output = `panoptic_inference_many` of one pair."""
+    return panoptic_inference_many([(voxel_output, query_output)], overlap_threshold, object_mask_threshold, thing_ids, min_C,
+                                   scene_size, input_query_logit, input_voxel_logit, vox_occ_threshold)[0]
+
+
+def _panoptic_inference_torch(voxel_output: ME.SparseTensor, query_output: torch.Tensor, overlap_threshold: float,
+                              object_mask_threshold: float, thing_ids: Sequence[int], min_C, scene_size,
+                              input_query_logit: bool = True, input_voxel_logit: bool = False,
+                              vox_occ_threshold: float = 0.3):
     bs = query_output.shape[0]
     n_classes = query_output.shape[-1] - 1
     vF = torch.sigmoid(voxel_output.F) if input_voxel_logit else voxel_output.F

@@ -24,7 +24,7 @@ from .bottleneck import SPCDense3Dv2
 from .decoder import DecoderGenerativeSepConvV2
 from .encoder import Encoder3DSepV2
 from .ensemble import Ensembler
-from .panoptic import panoptic_inference
+from .panoptic import panoptic_inference, panoptic_inference_many
 from .transformer import TransformerPredictorV2
 
 # SemanticKITTI "thing" class ids (pasco/data/semantic_kitti/params.py, `thing_ids`)
@@ -367,14 +367,21 @@ class PascoNet(nn.Module):
         x = self.prepare_input(in_feats, in_coords)
         ret = self(x, global_min_coords, global_max_coords, min_Cs, max_Cs, keep_override=keep_override)
         ssc_conf, sem_probs, panop = self.ensemble(ret, Ts)
-        outs = []
-        for i in (range(len(panop)) if eval_list is None else eval_list):
-            o = panoptic_inference(panop[i]["voxel_probs"], panop[i]["query_probs"],
-                                   overlap_threshold=self.overlap_threshold,
-                                   object_mask_threshold=self.object_mask_threshold, thing_ids=self.thing_ids,
-                                   scene_size=self.ensembler.scene_size,
-                                   min_C=torch.zeros(3, dtype=torch.int32, device=x.device),
-                                   input_query_logit=False, input_voxel_logit=False)
-            o["ssc_confidence"] = ssc_conf[i]
-            outs.append(o)
+        outs = self.panoptic(panop, ssc_conf, eval_list)
         return outs, sem_probs, panop
+
+    def panoptic(self, panop, ssc_conf=None, eval_list=None):
+        """`panoptic_inference` of the M subnets' outputs and the ensemble's (net_panoptic_sparse.py:578-608): every output's
+        launches first, then one device->host copy for all their segment tables."""
+        ids = list(range(len(panop)) if eval_list is None else eval_list)
+        dev = panop[0]["voxel_probs"].F.device
+        outs = panoptic_inference_many([(panop[i]["voxel_probs"], panop[i]["query_probs"]) for i in ids],
+                                       overlap_threshold=self.overlap_threshold,
+                                       object_mask_threshold=self.object_mask_threshold, thing_ids=self.thing_ids,
+                                       scene_size=self.ensembler.scene_size,
+                                       min_C=torch.zeros(3, dtype=torch.int32, device=dev),
+                                       input_query_logit=False, input_voxel_logit=False)
+        if ssc_conf is not None:
+            for i, o in zip(ids, outs):
+                o["ssc_confidence"] = ssc_conf[i]
+        return outs

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpascohip.so")
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
-ABI_VERSION = 2          # include/pasco_hip.h PH_ABI_VERSION this binding was written against
+ABI_VERSION = 3          # include/pasco_hip.h PH_ABI_VERSION this binding was written against
 
 
 class StatusError(RuntimeError):
@@ -125,6 +125,9 @@ _SIGNATURES = {
     "mask_compact_rank": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
     "points_link": [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "cells_max": [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "panop_queries": [_vp, _i32, _i32, C.c_float, _vp, _vp, _vp],
+    "panop_argmax": [_vp, _i64, _i32, _vp, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp],
+    "panop_write": [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"last_error": C.c_char_p, "workspace_bytes": _i64, "attn_workspace_bytes": _i64}
 _OPTIONAL = {}
@@ -1104,6 +1107,48 @@ class CBackend:
                                    self.stream(anchor.device))
         self._check(rc, "ens_finish")
         return out, flag
+
+
+    # ---- panoptic post-processing (include/pasco_hip.h panop_*) -----------------------------------------------------------
+    PANOP_QMAX = 128
+
+    def panoptic_rows(self, masks: torch.Tensor, qp: torch.Tensor, object_mask_threshold: float, overlap_threshold: float,
+                      vox_occ_threshold: float, thing_ids) -> dict:
+        """`panoptic_inference` of one batch item on its sparse rows (helper.py:91-303), three launches and no host read:
+        masks fp32 [n, q] mask probabilities, qp fp32 [q, c1] class probabilities -> device tensors {"panoptic" int32 [n],
+        "semantic" int32 [n], "ins_unc", "vox_conf", "vox_unc" fp32 [n], "winner" int32 [n] (kept index or -1), "own" uint8
+        [n], "qtab" int32 [4, 128], "nk" int32 [1], "seg" int32 [5, 128], "areas" int32 [2, 128], "tabs" int32 [12, 128] =
+        the four tables in one tensor (rows 0-3 qtab, 4 nk, 5-9 seg, 10-11 areas: one copy brings them to the host)}."""
+        self._chk(masks, torch.float32, "masks")
+        self._chk(qp, torch.float32, "qp")
+        n, q = masks.shape
+        c1 = qp.shape[1]
+        if qp.shape[0] != q or not 1 <= q <= self.PANOP_QMAX or not 2 <= c1 <= 64:
+            raise ValueError("panoptic_rows: masks [n, q], qp [q, c1] with q <= 128 queries and c1 <= 64 classes")
+        dev = masks.device
+        st = self.stream(dev)
+        Q = self.PANOP_QMAX
+        tabs = torch.zeros((4 + 1 + 5 + 2, Q), dtype=torch.int32, device=dev)        # qtab | nk | seg | areas: ONE fill
+        qtab, nk, seg, areas = tabs[0:4], tabs[4, 0:1], tabs[5:10], tabs[10:12]
+        self._check(self.fn["panop_queries"](_ptr(qp), q, c1, float(object_mask_threshold), qtab.data_ptr(), nk.data_ptr(),
+                                             st), "panop_queries")
+        per_i = torch.empty((3, max(n, 1)), dtype=torch.int32, device=dev)            # winner | panoptic | semantic
+        per_f = torch.empty((5, max(n, 1)), dtype=torch.float32, device=dev)          # conf | vunc | ins_unc | vox_conf | vox_unc
+        own = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+        self._check(self.fn["panop_argmax"](_ptr(masks), n, q, qtab.data_ptr(), float(vox_occ_threshold), per_i[0].data_ptr(),
+                                            _ptr(own), per_f[0].data_ptr(), per_f[1].data_ptr(), areas.data_ptr(), st),
+                    "panop_argmax")
+        thing = 0
+        for t in thing_ids:
+            if 0 <= int(t) < 64:
+                thing |= 1 << int(t)
+        self._check(self.fn["panop_write"](n, per_i[0].data_ptr(), _ptr(own), per_f[0].data_ptr(), per_f[1].data_ptr(),
+                                           areas.data_ptr(), qtab.data_ptr(), nk.data_ptr(), float(overlap_threshold), thing,
+                                           per_i[1].data_ptr(), per_i[2].data_ptr(), per_f[2].data_ptr(), per_f[3].data_ptr(),
+                                           per_f[4].data_ptr(), seg.data_ptr(), st), "panop_write")
+        return {"panoptic": per_i[1, :n], "semantic": per_i[2, :n], "ins_unc": per_f[2, :n], "vox_conf": per_f[3, :n],
+                "vox_unc": per_f[4, :n], "winner": per_i[0, :n], "own": own[:n], "qtab": qtab, "nk": nk, "seg": seg,
+                "areas": areas, "tabs": tabs}
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

@@ -32,7 +32,8 @@ def test_hip_library_exports_every_symbol():
     for n in declared():
         assert hasattr(lib, "ph_" + n), f"libpascohip.so lacks ph_{n}"
     lib.ph_abi_version.restype = ctypes.c_int
-    assert lib.ph_abi_version() == 2
+    from pasco_amd.me.backend import ABI_VERSION
+    assert lib.ph_abi_version() == ABI_VERSION == 3
     from pasco_amd.me.backend import ConvDesc
     assert lib.ph_conv_desc_size() == ctypes.sizeof(ConvDesc)
 
@@ -42,7 +43,7 @@ def test_binding_rejects_other_abi_versions(monkeypatch):
     being called with misaligned arguments."""
     from pasco_amd.build import build_hip
     from pasco_amd.me import backend
-    monkeypatch.setattr(backend, "ABI_VERSION", 3)
+    monkeypatch.setattr(backend, "ABI_VERSION", backend.ABI_VERSION + 1)
     with pytest.raises(RuntimeError, match="rebuild"):
         backend.CBackend(build_hip(verbose=False), "ph_", "cuda")
 
