@@ -926,7 +926,10 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st) {
       args.n_row_tiles = (int)((b.n_out + WIN_BM - 1) / WIN_BM);
       args.n_col_tiles = 1;
       const int grid = ((args.n_row_tiles + 7) / 8) * 8;
-      if (g_wop_trace_on) hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, false, true>), dim3(grid), dim3(256), 0, st, args);
+      // the phase trace (tools/wop_trace.py) exists only for the non-emitting instantiation: a launch that has to write the next
+      // layer's operand is never traced (it would silently leave that operand unwritten)
+      if (g_wop_trace_on && args.out_split == nullptr)
+        hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, false, true>), dim3(grid), dim3(256), 0, st, args);
       else if (args.out_split != nullptr) hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, true>), dim3(grid), dim3(256), 0, st, args);
       else hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, false>), dim3(grid), dim3(256), 0, st, args);
       PH_LAUNCH_CHECK();

@@ -174,6 +174,7 @@ class DecoderBlock(nn.Module):
                 tab = torch.stack([((idx / ts) * s64[c_in + a] + b64[c_in + a])[:, None] * w64[c_in + a][None, :]
                                    for a in range(3)]).float().contiguous()                       # [3, T, c_out]
             hit = (ver, wf, bias.float().contiguous(), tab)
+            fused.publish(tab)
             self.__dict__["_ph_resize"] = hit
         _, wf, bias, tab = hit
         coords = mgr.get_coordinates(out_key)

@@ -158,6 +158,18 @@ def _conv_unfused(x, mod, pro_bn, pro_act, epi_bn, epi_act, epi2_bn, residual, r
     return SparseTensor(F, coordinate_map_key=out_key, coordinate_manager=mgr)
 
 
+def publish(t):
+    """Call before a tensor derived from the parameters (split weights, folded BatchNorms, composed projections, tables)
+    is stored in a module-wide cache: the cache is read by every stream (scenes in flight each have their own), but the
+    tensor was made by launches on THIS one - the producing stream is drained first, so that no other stream can find the
+    entry before its data exists.  Once per cache entry and parameter version (warm-up), never per step; inside a graph
+    capture nothing may synchronise (the capture's warm-up calls have built the entries already)."""
+    dev = t.device if torch.is_tensor(t) else t
+    if dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(dev).synchronize()
+    return t
+
+
 def _split_of(w, be):
     return be.split_weight_rows(w) if _PRESPLIT else be.split_weight_f16(w)
 
@@ -169,6 +181,7 @@ def split_weight(mod, be):
     hit = getattr(mod, "_ph_split", None)
     if hit is None or hit[0] != ver:
         hit = (ver, _split_of(w, be))
+        publish(w.device)
         object.__setattr__(mod, "_ph_split", hit)
     return hit[1]
 
@@ -246,6 +259,7 @@ def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_o
     if hit is None or hit[0] != ver:
         wt = weight.detach().t().contiguous()                     # [cin, cout]
         hit = (ver, wt, _split_of(wt, be), bias.detach().contiguous() if bias is not None else None)
+        publish(wt)
         cache_owner.__dict__["_ph_lin_" + cache_key] = hit
     _, wt, split, b = hit
     do_emit = emit and _PRESPLIT and cout % 32 == 0
@@ -304,6 +318,7 @@ def linear_bn_act(x2d: Optional[torch.Tensor], lin: nn.Linear, *, pro_bn=None, e
         wt = w.detach().t().contiguous()                          # [cin, cout]
         split = _split_of(wt, be) if (conv_precision() == "f16x3" and be.split_supported(cin, cout)) else None
         hit = (ver, wt, split, lin.bias.detach().contiguous() if lin.bias is not None else None)
+        publish(wt)
         lin.__dict__["_ph_lin_w"] = hit
     _, wt, split, b = hit
     do_emit = emit and split is not None and _PRESPLIT and cout % 32 == 0
@@ -375,6 +390,7 @@ def fold_bn(bn) -> Tuple[torch.Tensor, torch.Tensor]:
         scale = inv * (m.weight.float() if m.weight is not None else 1.0)
         shift = (m.bias.float() if m.bias is not None else 0.0) - m.running_mean.float() * scale
         scale, shift = scale.contiguous(), shift.contiguous()
+    publish(scale)
     m._ph_folded = (ver, scale, shift)
     return scale, shift
 

@@ -68,6 +68,7 @@ class PositionEmbeddingSineSparse(nn.Module):
         if hit is None or hit.device != device:
             i = torch.arange(self.num_pos_feats, dtype=torch.float32, device=device)
             hit = (self.temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / self.num_pos_feats)).contiguous()
+            fused_mod.publish(hit)
             self.__dict__["_dim_t"] = hit
         return hit
 
@@ -78,6 +79,7 @@ class PositionEmbeddingSineSparse(nn.Module):
         tab = self.__dict__.get("_table")
         if tab is None or tab.device != device:      # 2.6 MB, built once
             tab = backend_for(device).sine_pe_table(self.dim_t(device), self.scale, self.TABLE_LO, self.TABLE_HI)
+            fused_mod.publish(tab)
             self.__dict__["_table"] = tab
         return tab
 
@@ -104,6 +106,7 @@ class PositionEmbeddingSineSparse(nn.Module):
         i_far = hi - lo - 1
         assert float(eps[i_far]) == 0.0 and float(eps[0]) == 0.0, "the far angle must be exact at both ends of the table"
         hit = ((eps * float(2 ** self.EPS_EXP2)).float().contiguous(), G, -lo, i_far)
+        fused_mod.publish(hit[0])
         self.__dict__["_angle_model"] = hit
         return hit
 
@@ -117,6 +120,7 @@ class PositionEmbeddingSineSparse(nn.Module):
             bt = torch.zeros((3, T, 3 * f), dtype=tab.dtype, device=device)
             for a in range(3):
                 bt[a, :, a * f:(a + 1) * f] = tab
+            fused_mod.publish(bt)
             self.__dict__["_block_table"] = bt.contiguous()
             bt = self.__dict__["_block_table"]
         return bt
@@ -142,6 +146,15 @@ def _xavier(module):
             nn.init.xavier_uniform_(p)
 
 
+def _attention_math(q, k, v, bias=None):
+    """softmax(q k^T / sqrt(dh) + bias) v for [B, H, Q, dh] x [B, H, N, dh] in plain fp32 matmuls (what
+    `F.scaled_dot_product_attention`'s math backend computes; the fused backends are never selected here)."""
+    att = torch.matmul(q * (float(q.shape[-1]) ** -0.5), k.transpose(-1, -2))
+    if bias is not None:
+        att = att + bias
+    return torch.matmul(torch.softmax(att, dim=-1), v)
+
+
 class SelfAttentionLayer(nn.Module):
     def __init__(self, d_model, nhead, dropout=0.0):
         super().__init__()
@@ -150,8 +163,21 @@ class SelfAttentionLayer(nn.Module):
         _xavier(self)
 
     def forward(self, x, query_pos=None):
+        """Self-attention of the queries (blocks.py:9-44: q = k = x + query_pos, value = x, post-norm) written out: the
+        projections, softmax(q k^T / sqrt(dh)) v and the output projection as plain fp32 matmuls.  `nn.MultiheadAttention`'s
+        own forward dispatches to scaled_dot_product_attention, which on this ROCm build is an AOTriton flash kernel
+        (`attn_fwd`): a Triton kernel on the path, and one whose fp32 products are not fp32-exact."""
+        mha = self.self_attn
+        B, Q, D = x.shape
+        H = mha.num_heads
+        dh = D // H
+        w, b = mha.in_proj_weight, mha.in_proj_bias
         qk = x if query_pos is None else x + query_pos
-        y = self.self_attn(qk, qk, value=x, need_weights=False)[0]
+        qkp = F.linear(qk, w[:2 * D], b[:2 * D])
+        q = qkp[..., :D].reshape(B, Q, H, dh).transpose(1, 2)
+        k = qkp[..., D:].reshape(B, Q, H, dh).transpose(1, 2)
+        v = F.linear(x, w[2 * D:], b[2 * D:]).reshape(B, Q, H, dh).transpose(1, 2)
+        y = mha.out_proj(_attention_math(q, k, v).transpose(1, 2).reshape(B, Q, D))
         return self.norm(x + y)
 
 
@@ -201,7 +227,7 @@ class CrossAttentionLayer(nn.Module):
             bias = torch.zeros(attn_mask.shape, dtype=q.dtype, device=q.device)
             bias.masked_fill_(attn_mask, float("-inf"))
             bias = bias[:, None]
-        o = F.scaled_dot_product_attention(qq, kk, vv, attn_mask=bias)
+        o = _attention_math(qq, kk, vv, bias)
         o = o.transpose(1, 2).reshape(B, Q, D)
         return q + mha.out_proj(o)
 
@@ -246,6 +272,7 @@ class CrossAttentionLayer(nn.Module):
                 out["w" + name] = (wx @ wp).float().contiguous()
                 out["b" + name] = (wx @ bp + bx).float().contiguous()
                 out["t" + name] = torch.stack([t64 @ wx[:, a * f:(a + 1) * f].t() for a in range(3)]).float().contiguous()
+        fused_mod.publish(w)
         self.__dict__["_ph_composed"] = (ver, out)
         return out
 
@@ -303,6 +330,7 @@ class CrossAttentionLayer(nn.Module):
             co = cv @ wo.double().t() + bo.double()
             out = dict(w2=w2.float().contiguous(), b2=b2.float().contiguous(), mvo=mvo.float().contiguous(),
                        co=co.float().contiguous(), E=E)
+        fused_mod.publish(w)       # the cache serves every stream, the tensors were made on this one
         self.__dict__["_ph_composed_feat"] = (ver, out)
         return out
 
@@ -369,10 +397,33 @@ class LazyRows:
         return getattr(self.materialize(), name)
 
 
+_PREDICTORS = None       # weak set of live predictors: `release_stream_graphs` walks it
+
+
+def release_stream_graphs(stream) -> int:
+    """Drop the query-side hipGraphs every live predictor captured for `stream` (a torch.cuda.Stream or a raw handle): they
+    are keyed by the launch stream, so a serving loop that retires its streams (SceneServer.close) would otherwise leave up
+    to _QGRAPH_MAX captures (graph + static buffers) behind per predictor.  Returns the number dropped."""
+    handle = int(getattr(stream, "cuda_stream", stream) or 0)
+    n = 0
+    for tp in list(_PREDICTORS or ()):
+        graphs = tp.__dict__.get("_qgraphs")
+        if graphs:
+            for k in [k for k in graphs if k[-1] == handle]:
+                del graphs[k]
+                n += 1
+    return n
+
+
 class TransformerPredictorV2(nn.Module):
     def __init__(self, in_channels, num_classes=20, hidden_dim=384, num_queries=100, nheads=8,
                  dim_feedforward=2048, mask_dim=256, n_infers=2, **_ignored):
         super().__init__()
+        global _PREDICTORS
+        if _PREDICTORS is None:
+            import weakref
+            _PREDICTORS = weakref.WeakSet()
+        _PREDICTORS.add(self)
         self.nheads = nheads
         self.n_infers = n_infers
         self.hidden_dim = hidden_dim

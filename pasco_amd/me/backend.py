@@ -214,8 +214,12 @@ class CBackend:
         inherit them together with any status bit nobody read.  Returns the number of buffers dropped."""
         handle = int(getattr(stream, "cuda_stream", stream) or 0)
         dev = getattr(stream, "device", None)
+        if dev is None and torch.cuda.is_available():      # a raw handle: the streams of the current device
+            dev = torch.device("cuda", torch.cuda.current_device())
+        # per-stream entries are exactly the (name, device, handle) keys `_stream_key` makes: nothing else is touched
         drop = [k for k in self._ws
-                if isinstance(k, tuple) and len(k) >= 3 and k[-1] == handle and (dev is None or k[-2] == dev)]
+                if isinstance(k, tuple) and len(k) == 3 and isinstance(k[0], str) and isinstance(k[1], torch.device)
+                and k[2] == handle and (dev is None or k[1] == dev)]
         for k in drop:
             del self._ws[k]
         return len(drop)
