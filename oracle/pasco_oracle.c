@@ -109,7 +109,7 @@ int pho_map_insert(const int32_t *coords, int64_t n, uint64_t *tkeys, int32_t *t
   if (!is_pow2(cap) || cap < 2 * n || cap < 2) return fail("map_insert: cap must be pow2 >= 2n");
   for (int64_t i = 0; i < n && status; ++i)
     if (!packable(coords[4 * i], coords[4 * i + 1], coords[4 * i + 2], coords[4 * i + 3])) *status |= 2;
-  for (int64_t s = 0; s < cap; ++s) { tkeys[s] = EMPTY_KEY; tvals[s] = INT_MAX; }
+  for (int64_t s = 0; s < cap; ++s) { tkeys[s] = EMPTY_KEY; tvals[s] = -1; }   /* unset slots: all ones, as in libpascohip */
   uint64_t mask = (uint64_t)cap - 1;
   int32_t count = 0;
   for (int64_t i = 0; i < n; ++i) {

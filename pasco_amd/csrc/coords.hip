@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256)
     if (prev == PH_EMPTY_KEY || prev == key) break;
     slot = (slot + 1) & mask;
   }
-  atomicMin(&tvals[slot], (int32_t)i);
+  atomicMin((unsigned int *)&tvals[slot], (unsigned int)i);     // first occurrence (unset slots hold 0xFFFFFFFF)
   if (row_slot) row_slot[i] = (int32_t)slot;
 }
 
@@ -209,8 +209,14 @@ extern "C" int ph_map_insert(const int32_t *coords, int64_t n, uint64_t *tkeys, 
   PH_REQUIRE(n >= 0 && n < 0x3FFFFFFF, "map_insert: bad n=%lld", (long long)n);
   PH_REQUIRE(ph_is_pow2(cap) && cap >= 2 * n && cap >= 2, "map_insert: cap=%lld must be pow2 >= 2n",
              (long long)cap);
-  PH_CHECK_HIP(hipMemsetAsync(tkeys, 0xFF, (size_t)cap * 8, st));
-  PH_CHECK_HIP(hipMemsetAsync(tvals, 0x7F, (size_t)cap * 4, st));
+  // empty = all ones in both tables (keys: PH_EMPTY_KEY; values: the largest unsigned row, so that the unsigned atomicMin
+  // of k_insert keeps the first occurrence): ONE fill when the caller laid the value table out right behind the keys
+  if ((const char *)tvals == (const char *)tkeys + (size_t)cap * 8) {
+    PH_CHECK_HIP(hipMemsetAsync(tkeys, 0xFF, (size_t)cap * 12, st));
+  } else {
+    PH_CHECK_HIP(hipMemsetAsync(tkeys, 0xFF, (size_t)cap * 8, st));
+    PH_CHECK_HIP(hipMemsetAsync(tvals, 0xFF, (size_t)cap * 4, st));
+  }
   if (n == 0) {
     if (n_uniq) PH_CHECK_HIP(hipMemsetAsync(n_uniq, 0, 4, st));
     return 0;

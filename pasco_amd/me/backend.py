@@ -265,14 +265,19 @@ class CBackend:
         n = coords.shape[0]
         dev = coords.device
         cap = self.table_capacity(n)
-        tkeys = torch.empty(cap, dtype=torch.int64, device=dev)
-        tvals = torch.empty(cap, dtype=torch.int32, device=dev)
+        # keys and values in ONE allocation, values right behind the keys: the library then clears both with one fill
+        table = torch.empty(cap + cap // 2, dtype=torch.int64, device=dev)
+        tkeys = table[:cap]
+        tvals = table[cap:].view(torch.int32)
         ws = torch.empty(int(self.fn["workspace_bytes"](int(n))), dtype=torch.uint8, device=dev)
         if dedup:
-            row2uniq = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-            uniq_rows = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+            # row2uniq | uniq_rows | the count: one allocation; the library WRITES the count (no zero fill needed)
+            m = max(n, 1)
+            m4 = (m + 3) // 4 * 4                     # every part on a 16-byte boundary
+            rows2 = torch.empty(2 * m4 + 1, dtype=torch.int32, device=dev)
+            row2uniq, uniq_rows = rows2[:m], rows2[m4:m4 + m]
             if n_uniq is None:
-                n_uniq = torch.zeros(1, dtype=torch.int32, device=dev)
+                n_uniq = rows2[2 * m4:]
             rc = self.fn["map_insert"](_ptr(coords), n, _ptr(tkeys), _ptr(tvals), cap, _ptr(row2uniq),
                                        _ptr(uniq_rows), n_uniq.data_ptr(), _ptr(ws), ws.numel(), _ptr(self.status_word(dev)),
                                        self.stream(dev))
@@ -375,7 +380,7 @@ class CBackend:
         dev = nbr.device
         pin = torch.empty_like(nbr)
         pout = torch.empty_like(nbr)
-        counts = torch.zeros(kvol, dtype=torch.int32, device=dev)
+        counts = torch.empty(kvol, dtype=torch.int32, device=dev)       # written by the library's scan
         ws = self.workspace(n_out, dev)
         rc = self.fn["kmap_compact"](_ptr(nbr), kvol, n_out, _ptr(pin), _ptr(pout), _ptr(counts),
                                      _ptr(ws), ws.numel(), self.stream(dev))
@@ -685,10 +690,10 @@ class CBackend:
         self._chk(mask, torch.uint8, "mask")
         n = mask.shape[0]
         dev = mask.device
-        keep = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        buf = torch.empty(max(n, 1) + 1, dtype=torch.int32, device=dev)      # rows | count (written by the library)
+        keep, cnt = buf[:-1], buf[-1:]
         ws = self.workspace(n, dev)
-        rc = self.fn["mask_compact"](_ptr(mask), n, _ptr(keep), _ptr(cnt), _ptr(ws), ws.numel(),
+        rc = self.fn["mask_compact"](_ptr(mask), n, _ptr(keep), cnt.data_ptr(), _ptr(ws), ws.numel(),
                                      self.stream(dev))
         self._check(rc, "mask_compact")
         return keep[: int(cnt.item())]
@@ -730,7 +735,7 @@ class CBackend:
                     "points_mark")
         sites = torch.empty(min(n, nsites), dtype=torch.int32, device=dev)
         rank = torch.empty(nsites, dtype=torch.int32, device=dev)
-        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        cnt = torch.empty(1, dtype=torch.int32, device=dev)
         ws = self.workspace(nsites, dev)
         self._check(self.fn["mask_compact_rank"](_ptr(flags), nsites, _ptr(sites), _ptr(rank), _ptr(cnt), _ptr(ws), ws.numel(),
                                                  st), "mask_compact_rank")
@@ -753,7 +758,7 @@ class CBackend:
         if not masks:
             return []
         dev = masks[0].device
-        cnts = torch.zeros(len(masks), dtype=torch.int32, device=dev)
+        cnts = torch.empty(len(masks), dtype=torch.int32, device=dev)     # every entry written by its compaction
         keeps = []
         for j, mask in enumerate(masks):
             self._chk(mask, torch.uint8, "mask")
@@ -835,7 +840,7 @@ class CBackend:
         dev = dense.device
         nsites = b * x * y * z
         coords = torch.empty((max(nsites, 1), 4), dtype=torch.int32, device=dev)
-        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        cnt = torch.empty(1, dtype=torch.int32, device=dev)
         ws = self.workspace(nsites, dev)
         hdim = (_i32 * 4)(b, x, y, z)
         rc = self.fn["to_sparse_coords"](_ptr(dense), c, C.cast(hdim, _vp), _ptr(coords), _ptr(cnt),

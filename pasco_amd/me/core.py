@@ -209,7 +209,7 @@ class CoordinateManager:
         m = self._maps[in_key]
         be = self.backend()
         ts0 = in_key.tensor_stride[0]
-        cnts = torch.zeros(levels, dtype=torch.int32, device=m.coords.device)
+        cnts = torch.empty(levels, dtype=torch.int32, device=m.coords.device)    # every entry written by its insert
         parts = []
         for l in range(levels):
             floored = be.coords_floor(m.coords, ts0 << (l + 1))

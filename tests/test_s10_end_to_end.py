@@ -29,8 +29,14 @@ pytestmark = pytest.mark.gpu
 
 
 FLOOR = 1.0          # |got - exp| <= 1e-3 (|exp| + FLOOR * mean |exp|): torch.allclose(rtol = 1e-3, atol = 1e-3 mean |exp|)
-FLOOR_FROZEN = 0.25  # the same contract with the attention-mask decisions of the oracle run forced into the HIP run: what is
-                     # left is arithmetic alone, held to the floor two HIP paths are held to against each other
+# Round 5 tested the explanation rounds 3 - 4 gave for the size of the error ("attention masks are thresholds of the previous
+# prediction"): with the oracle run's 189 M mask decisions FORCED into the HIP run (tests/mask_freeze.py) the error does not
+# move (7.2e-4 -> 7.2e-4 of mean |y|; the HIP run decides only ~80 of them differently on its own, all at logits below 1e-3
+# of the mean).  The thresholds are NOT the cause.  What the test shows instead: three fp32 arithmetics of the same graph -
+# the oracle's sequential sums, the exact fp32 MFMA path and the split-precision path - differ pairwise by 3e-4 .. 7e-4 of
+# mean |y| on THIS random-weight net (default inits + random BatchNorm statistics; its query columns are ill-conditioned),
+# while the reference's own graph at the same widths with default-init-scale weights agrees to 6e-5 on the same kernels
+# (tests/test_golden_wide.py).  The floor therefore stays where the conditioning of the benchmark's net puts it.
 PROB_ATOL = 2e-3     # probabilities ([0, 1]): sigmoid / softmax of logits that agree to ~7e-4 of their mean magnitude
 
 
@@ -129,7 +135,7 @@ def test_s10_step_hip_vs_oracle_end_to_end(hip, oracle):
     # ---- the same step with the oracle run's attention-mask decisions forced into the HIP run -----------------------------
     # The masks of decoder layer l are thresholds (mask logit > 0, transformer_predictor_v2.py:224) of layer l - 1's
     # prediction: a near-zero logit that the two arithmetics round to different sides changes one key of one query's
-    # attention.  With the decisions frozen, what remains is arithmetic alone and must meet the tighter floor.
+    # attention.  With the decisions frozen, what remains is arithmetic alone - measured: the same error (see the top).
     stats = {}
     with mask_freeze.forcing(mask_decisions, stats):
         frozen = run(torch.device("cuda", 0), unet_only=True)
@@ -141,16 +147,35 @@ def test_s10_step_hip_vs_oracle_end_to_end(hip, oracle):
         pairs += [(a["voxel_logits"].F, b["voxel_logits"].F, f"voxel logits subnet {i}"),
                   (a["query_logits"], b["query_logits"], f"query logits subnet {i}")]
     for a, b, what in pairs:
-        m, r = _rel(a.cpu(), b, FLOOR_FROZEN)
+        m, r = _rel(a.cpu(), b, FLOOR)
         fw["max/mean"], fw["elementwise"] = max(fw["max/mean"], m), max(fw["elementwise"], r)
         if r > 1e-3:
-            failures.append(f"frozen masks: {what}: element-wise relative {r:.3e} (floor {FLOOR_FROZEN} mean |y|)")
+            failures.append(f"frozen masks: {what}: element-wise relative {r:.3e} (floor {FLOOR} mean |y|)")
     print(f"[s10 e2e] attention-mask decisions: {stats['decisions']} in {stats['calls']} layers, {stats['differ']} decided "
           f"differently by the HIP run on its own, {stats['differ_above_noise']} of them with a logit above 1e-3 of the mean")
     print(f"[s10 e2e] logits with the oracle's mask decisions forced: worst max-error / mean |y| {fw['max/mean']:.2e}, "
-          f"element-wise relative (floor {FLOOR_FROZEN}) {fw['elementwise']:.2e}  [free-running: {worst['max/mean']:.2e}]")
+          f"element-wise relative (floor {FLOOR}) {fw['elementwise']:.2e}  [free-running: {worst['max/mean']:.2e}]")
     if stats["differ_above_noise"]:
         failures.append(f"{stats['differ_above_noise']} attention-mask decisions differ with a logit above the noise")
+    # ---- a third arithmetic: every product on the exact fp32 MFMA, against the oracle and against the split path -----------
+    from pasco_amd.graph import fused
+    fused.set_conv_precision("f32")
+    try:
+        exact = run(torch.device("cuda", 0), unet_only=True)
+    finally:
+        fused.set_conv_precision("f16x3")
+    torch.cuda.synchronize()
+    tri = {"exact fp32 MFMA vs oracle": 0.0, "split precision vs oracle": worst["max/mean"], "split vs exact fp32 MFMA": 0.0}
+    for i, (a, b, c) in enumerate(zip(exact["panop_predictions"], e_ret["panop_predictions"], g_ret["panop_predictions"])):
+        assert torch.equal(a["voxel_logits"].C.cpu(), b["voxel_logits"].C)
+        m, r = _rel(a["voxel_logits"].F.cpu(), b["voxel_logits"].F)
+        tri["exact fp32 MFMA vs oracle"] = max(tri["exact fp32 MFMA vs oracle"], m)
+        if m > 1e-3 or r > 1e-3:
+            failures.append(f"exact fp32 MFMA vs oracle: voxel logits subnet {i}: {m:.3e} / {r:.3e}")
+        m2, _ = _rel(c["voxel_logits"].F.cpu(), a["voxel_logits"].F.cpu())
+        tri["split vs exact fp32 MFMA"] = max(tri["split vs exact fp32 MFMA"], m2)
+    print("[s10 e2e] three fp32 arithmetics of the same graph, voxel logits, max error / mean |y|: " +
+          ", ".join(f"{k} {v:.2e}" for k, v in tri.items()))
 
     # ensembled semantic probabilities + confidences (dense [C, X, Y, Z] / [X, Y, Z] per subnet and for the ensemble)
     d_sem = max(float((a.cpu() - b).abs().max()) for a, b in zip(got[2], exp[2]))
