@@ -213,9 +213,18 @@ def run_scene(net, scene, teacher, window=None, panoptic=False):
 
 
 def run_scene_subnet_heads(net, scene, teacher):
-    """Config C4 step: shared trunk on every rank, this rank's subnet heads, all-gather, ensembling."""
-    from pasco_amd.graph.dist import subnet_parallel_forward
+    """Config C4 step: shared trunk on every rank, this rank's subnet heads, one exchange, ensembling.  Default exchange
+    (round 5): all-to-all of canonical-site SLABS of the resampled masks + a site-sharded ensembler (pasco_amd/graph/dist.py
+    `site_sharded_ensemble`: each rank receives (W - 1) / W of ONE mask tensor instead of W - 1 whole ones, results
+    bit-identical); PASCO_C4_EXCHANGE=allgather (or f16): the all-gather by subnet of rounds 2 - 4."""
+    from pasco_amd.graph.dist import site_sharded_ensemble, subnet_parallel_forward, subnet_parallel_local
     x = net.prepare_input(scene.in_feats, scene.in_coords)
+    if os.environ.get("PASCO_C4_EXCHANGE", "slab") == "slab":
+        ret = subnet_parallel_local(net, x, scene.global_min_Cs, scene.global_max_Cs, scene.min_Cs, scene.max_Cs,
+                                    keep_override=teacher)
+        sem_probs, sharded, stats = site_sharded_ensemble(net, ret, scene.Ts)
+        ret["exchange"] = stats
+        return ret, sharded
     ret = subnet_parallel_forward(net, x, scene.global_min_Cs, scene.global_max_Cs, scene.min_Cs, scene.max_Cs,
                                   keep_override=teacher)
     ssc_conf, sem_probs, panop = net.ensemble(ret, scene.Ts)
@@ -720,6 +729,8 @@ def main():
         if heads and world > 1 and last.get("out") is not None and "exchange" in last["out"]:
             ex = dict(last["out"]["exchange"])
             ex["MB_sent_per_rank_per_scene"] = round(ex["bytes_sent"] / 1e6, 2)
+            ex["MB_received_per_rank_per_scene"] = round(ex.get("bytes_received", 0) / 1e6, 2)
+            ex["kind"] = os.environ.get("PASCO_C4_EXCHANGE", "slab")
             res["exchange"] = ex
         if one_in_flight is not None:
             res["in_flight_1"] = one_in_flight

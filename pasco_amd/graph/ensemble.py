@@ -89,6 +89,45 @@ def _gram(a: torch.Tensor, b: torch.Tensor, chunks: int = 256) -> torch.Tensor:
     return out
 
 
+GRAM_SLABS = 8       # the union rows are cut into this many contiguous slabs; every reduction over the rows (the matching's
+                     # Gram matrix and column sums) is formed per slab and the slab results are added in slab order.  The
+                     # order is part of the result: a run that shards the rows by slab over 2 / 4 / 8 ranks (config C4,
+                     # dist.site_sharded_ensemble) adds the same partial results in the same order -> bit-identical.
+
+
+def slab_bounds(n_rows: int, slabs: int = GRAM_SLABS) -> List[int]:
+    """Row boundaries of the slabs: slab k = rows [b[k], b[k + 1])."""
+    return [(k * n_rows) // slabs for k in range(slabs + 1)]
+
+
+def match_partials(anchor_mask: torch.Tensor, aux_mask: torch.Tensor) -> torch.Tensor:
+    """What ONE slab of rows contributes to the soft-IoU matching: [Q * Q + 2 Q] = anchor^T aux | column sums of the
+    anchor | column sums of the aux masks (fp32, rows [n, Q] each)."""
+    q = anchor_mask.shape[1]
+    if anchor_mask.shape[0] == 0:
+        return anchor_mask.new_zeros(q * q + 2 * q)
+    return torch.cat([_gram(anchor_mask, aux_mask).reshape(-1), anchor_mask.sum(0), aux_mask.sum(0)])
+
+
+def match_from_partials(partials: Sequence[torch.Tensor], q: int, iou_threshold: float):
+    """Slab contributions (in slab order) -> the Hungarian matching: (a_idx, b_idx on the partials' device, matched IoUs
+    on the host) (utils.py:153-198)."""
+    tot = partials[0].clone()
+    for p in partials[1:]:
+        tot += p                                                             # fixed order: slab 0, 1, 2, ...
+    inter = tot[:q * q].reshape(q, q)
+    union = tot[q * q:q * q + q][:, None] + tot[q * q + q:][None, :] - inter
+    iou = torch.where(union != 0, inter / union, torch.zeros_like(inter))
+    iou = iou * (iou > iou_threshold)
+    iou_h = iou.cpu()                                                        # the one host read of the matching step
+    a_idx, b_idx = linear_sum_assignment((1.0 - iou_h).numpy())
+    matched_h = iou_h[a_idx, b_idx]                                          # host copy: the query filter is decided there too
+    ab = torch.as_tensor(np.stack([a_idx, b_idx]))
+    if iou.is_cuda:                                                          # pinned staging: the upload does not synchronise
+        ab = ab.pin_memory().to(iou.device, non_blocking=True)
+    return ab[0], ab[1], matched_h
+
+
 ENS_KERNEL_MAX_Q, ENS_KERNEL_MAX_C = 128, 64     # shapes the ph_ens_* row kernels take (one wave64 per row, two columns a lane)
 
 
@@ -173,18 +212,11 @@ class Ensembler(torch.nn.Module):
     # -- a22 -----------------------------------------------------------------------------------------
     @staticmethod
     def match_queries(anchor_mask: torch.Tensor, aux_mask: torch.Tensor, iou_threshold: float):
-        """Soft-IoU Hungarian matching of query masks given as [U, Q] site rows (utils.py:153-198)."""
-        inter = _gram(anchor_mask, aux_mask)                                 # anchor^T aux, [Q, Q]
-        union = anchor_mask.sum(0)[:, None] + aux_mask.sum(0)[None, :] - inter
-        iou = torch.where(union != 0, inter / union, torch.zeros_like(inter))
-        iou = iou * (iou > iou_threshold)
-        iou_h = iou.cpu()                                                    # the one host read of the matching step
-        a_idx, b_idx = linear_sum_assignment((1.0 - iou_h).numpy())
-        matched_h = iou_h[a_idx, b_idx]                                      # host copy: the query filter is decided there too
-        ab = torch.as_tensor(np.stack([a_idx, b_idx]))
-        if iou.is_cuda:                                                      # pinned staging: the upload does not synchronise
-            ab = ab.pin_memory().to(iou.device, non_blocking=True)
-        return ab[0], ab[1], matched_h
+        """Soft-IoU Hungarian matching of query masks given as [U, Q] site rows (utils.py:153-198).  The sums over the rows
+        are formed slab by slab and added in slab order (GRAM_SLABS)."""
+        b = slab_bounds(anchor_mask.shape[0])
+        parts = [match_partials(anchor_mask[b[k]:b[k + 1]], aux_mask[b[k]:b[k + 1]]) for k in range(GRAM_SLABS)]
+        return match_from_partials(parts, anchor_mask.shape[1], iou_threshold)
 
     def ensemble_panop(self, panop_predictions, ensemble_sem_prob_denses, Ts, iou_threshold=0.2, cache: dict = None):
         """-> one dict per subnet + the ensemble: {"sem_probs", "voxel_probs" (SparseTensors on the

@@ -90,19 +90,31 @@ def panoptic_inference_many(outputs, overlap_threshold: float, object_mask_thres
     step (net_panoptic_sparse.py:578-608) - with ONE device->host copy for all their segment tables."""
     outputs = list(outputs)
     be = _device_backend(outputs[0][0].F) if outputs else None
-    if be is None or any(q.shape[0] != 1 or q.shape[1] > be.PANOP_QMAX or q.shape[2] > 64 for _, q in outputs):
-        return [_panoptic_inference_torch(v, q, overlap_threshold, object_mask_threshold, thing_ids, min_C, scene_size,
-                                          input_query_logit, input_voxel_logit, vox_occ_threshold) for v, q in outputs]
+    torch_form = lambda v, q: _panoptic_inference_torch(v, q, overlap_threshold, object_mask_threshold, thing_ids, min_C,
+                                                        scene_size, input_query_logit, input_voxel_logit, vox_occ_threshold)
+    if be is None:
+        return [torch_form(v, q) for v, q in outputs]
+    # the row kernels take one scene, 1 .. 128 queries, <= 64 classes; anything else (a batch of scenes, an ensemble whose
+    # queries were all filtered out, a checkpoint with more queries) is served by the torch form of the same function
+    served = [q.shape[0] == 1 and 1 <= q.shape[1] <= be.PANOP_QMAX and 2 <= q.shape[2] <= 64 for _, q in outputs]
     work = []
-    for v, q in outputs:
+    for (v, q), ok in zip(outputs, served):
+        if not ok:
+            work.append(None)
+            continue
         masks = (torch.sigmoid(v.F) if input_voxel_logit else v.F).contiguous()
         qp = (F.softmax(q[0], dim=-1) if input_query_logit else q[0]).contiguous().float()
         rows = be.panoptic_rows(masks, qp, object_mask_threshold, overlap_threshold, vox_occ_threshold, thing_ids)
         work.append((v, masks, qp, rows))
     # one copy for every output's tables: qtab (rows 0-3) | nk (4) | seg (5-9) | areas (10-11), 128 int32 each
-    tabs = torch.stack([w[3]["tabs"] for w in work]).cpu()
+    live = [w for w in work if w is not None]
+    tabs = iter(torch.stack([w[3]["tabs"] for w in live]).cpu()) if live else iter(())
     results = []
-    for (v, masks, qp, rows), t in zip(work, tabs):
+    for w, (v0, q0) in zip(work, outputs):
+        if w is None:
+            results.append(torch_form(v0, q0))
+            continue
+        (v, masks, qp, rows), t = w, next(tabs)
         probs = t[3].view(torch.float32)
         K, n_seg = int(t[4, 0]), int(t[9, 0])
         infos = [{"id": int(t[5, s]), "isthing": bool(t[6, s]), "category_id": int(t[7, s]), "query_id": int(t[8, s]),
@@ -136,7 +148,8 @@ def _panoptic_inference_torch(voxel_output: ME.SparseTensor, query_output: torch
     thing = set(int(t) for t in thing_ids)
     res = {k: [] for k in ("vox_all_mask_probs_denses", "panoptic_seg_denses", "semantic_seg_denses",
                            "ins_uncertainty_denses", "vox_confidence_denses", "vox_uncertainty_denses",
-                           "panoptic_seg_sparses", "segments_infos")}
+                           "panoptic_seg_sparses", "segments_infos", "semantic_seg_sparses", "ins_uncertainty_sparses",
+                           "vox_confidence_sparses", "vox_uncertainty_sparses")}
     for b in range(bs):
         qp = F.softmax(query_output[b], dim=-1) if input_query_logit else query_output[b]
         probs, labels = qp.max(-1)
@@ -196,6 +209,10 @@ def _panoptic_inference_torch(voxel_output: ME.SparseTensor, query_output: torch
         dense = lambda v: to_dense(v.unsqueeze(-1) if v.dim() == 1 else v, coords, scene_size, min_C).squeeze()
         res["semantic_seg_denses"].append(dense(semantic))
         res["panoptic_seg_sparses"].append(panoptic)
+        res["semantic_seg_sparses"].append(semantic)
+        res["ins_uncertainty_sparses"].append(ins_unc)
+        res["vox_confidence_sparses"].append(vox_conf)
+        res["vox_uncertainty_sparses"].append(vox_unc)
         res["panoptic_seg_denses"].append(dense(panoptic))
         res["segments_infos"].append(segments_info)
         res["ins_uncertainty_denses"].append(dense(ins_unc))

@@ -1122,12 +1122,14 @@ class CBackend:
     PANOP_QMAX = 128
 
     def panoptic_rows(self, masks: torch.Tensor, qp: torch.Tensor, object_mask_threshold: float, overlap_threshold: float,
-                      vox_occ_threshold: float, thing_ids) -> dict:
+                      vox_occ_threshold: float, thing_ids, reduce_areas=None) -> dict:
         """`panoptic_inference` of one batch item on its sparse rows (helper.py:91-303), three launches and no host read:
         masks fp32 [n, q] mask probabilities, qp fp32 [q, c1] class probabilities -> device tensors {"panoptic" int32 [n],
         "semantic" int32 [n], "ins_unc", "vox_conf", "vox_unc" fp32 [n], "winner" int32 [n] (kept index or -1), "own" uint8
         [n], "qtab" int32 [4, 128], "nk" int32 [1], "seg" int32 [5, 128], "areas" int32 [2, 128], "tabs" int32 [12, 128] =
-        the four tables in one tensor (rows 0-3 qtab, 4 nk, 5-9 seg, 10-11 areas: one copy brings them to the host)}."""
+        the four tables in one tensor (rows 0-3 qtab, 4 nk, 5-9 seg, 10-11 areas: one copy brings them to the host)}.
+        `reduce_areas(areas)`: called between the competition and the write pass - rows sharded over ranks (config C4,
+        dist.site_sharded_panoptic) add their per-query areas there (exact integers), everything else is row-wise."""
         self._chk(masks, torch.float32, "masks")
         self._chk(qp, torch.float32, "qp")
         n, q = masks.shape
@@ -1147,6 +1149,8 @@ class CBackend:
         self._check(self.fn["panop_argmax"](_ptr(masks), n, q, qtab.data_ptr(), float(vox_occ_threshold), per_i[0].data_ptr(),
                                             _ptr(own), per_f[0].data_ptr(), per_f[1].data_ptr(), areas.data_ptr(), st),
                     "panop_argmax")
+        if reduce_areas is not None:
+            reduce_areas(areas)
         thing = 0
         for t in thing_ids:
             if 0 <= int(t) < 64:

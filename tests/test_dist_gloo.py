@@ -190,3 +190,101 @@ def test_bench_launches_its_own_ranks():
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "0", "--dry-run"],
                          capture_output=True, text=True, timeout=120, env=env, cwd=root)
     assert one.returncode == 0 and json.loads(one.stdout.strip().splitlines()[-1])["n_ranks"] == 1
+
+
+# ---- config C4 with the ensembling sharded by canonical-site slab (dist.site_sharded_ensemble) ------------------------------
+def _sharded_worker(rank, world, port, q, n_infers):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.conftest import load_oracle
+        from pasco_amd.me import backend
+        from pasco_amd.graph import PascoNet
+        from pasco_amd.graph.dist import (allgather_rows, gather_sharded, shard_indices, site_sharded_ensemble,
+                                          site_sharded_panoptic, subnet_parallel_forward)
+        from pasco_amd.graph.synth import TeacherKeep, make_scene
+        backend.register_checker_backend(load_oracle())
+        torch.manual_seed(3)
+        net = PascoNet(n_classes=20, n_infers=n_infers, in_channels=12, f=8, num_queries=8, heavy_decoder=False,
+                       object_mask_threshold=0.05).eval()          # random queries: a low bar so that segments exist
+        net.ensembler.scene_size = (24, 24, 8)
+        sc = make_scene(4, n_infers=n_infers, in_channels=12, grid=(24, 24, 8), occupancy=0.12)
+        tk = TeacherKeep(sc, "cpu")
+        why = []
+        with torch.no_grad():
+            x = net.prepare_input(sc.in_feats, sc.in_coords)
+            args = (x, sc.global_min_Cs, sc.global_max_Cs, sc.min_Cs, sc.max_Cs)
+            got = subnet_parallel_forward(net, *args, keep_override=tk)       # all-gather by subnet: every rank holds all
+            _, _, ref = net.ensemble(got, sc.Ts)                              # the single-process ensembler on those logits
+            ref_pi = net.panoptic(ref)
+            mine = shard_indices(n_infers, rank, world)
+            local = dict(got)
+            local["panop_predictions"] = [got["panop_predictions"][i] for i in mine]   # what this rank computed itself
+            sem, sharded, st = site_sharded_ensemble(net, local, sc.Ts)
+            full = gather_sharded(net, sharded)
+            if len(full) != len(ref):
+                why.append("number of outputs")
+            for i, (a, b) in enumerate(zip(full, ref)):                       # BIT for bit
+                if not torch.equal(a["voxel_probs"].C, b["voxel_probs"].C):
+                    why.append(f"output {i}: rows")
+                elif not torch.equal(a["voxel_probs"].F, b["voxel_probs"].F):
+                    why.append(f"output {i}: mask probabilities differ by {float((a['voxel_probs'].F - b['voxel_probs'].F).abs().max()):.2e}")
+                if not torch.equal(a["sem_probs"].F, b["sem_probs"].F) or not torch.equal(a["query_probs"], b["query_probs"]):
+                    why.append(f"output {i}: semantic / query probabilities")
+            # the panoptic stage on the sharded rows: areas added over the ranks, label rows gathered
+            pis = site_sharded_panoptic(net, sharded)
+            for i, (p, r) in enumerate(zip(pis, ref_pi)):
+                lab = torch.cat(allgather_rows(p["panoptic"].reshape(-1, 1)))[:, 0]
+                semc = torch.cat(allgather_rows(p["semantic"].reshape(-1, 1)))[:, 0]
+                info = lambda s: [(v["id"], v["isthing"], v["category_id"], v["query_id"]) for v in s]
+                if info(p["segments_infos"]) != info(r["segments_infos"][0]):
+                    why.append(f"output {i}: segments {info(p['segments_infos'])} vs {info(r['segments_infos'][0])}")
+                if not torch.equal(lab, r["panoptic_seg_sparses"][0]) or not torch.equal(semc, r["semantic_seg_sparses"][0]):
+                    why.append(f"output {i}: panoptic / semantic label rows")
+            n_seg = sum(len(p["segments_infos"]) for p in pis)
+            # bytes: the slab exchange against the all-gather of whole mask tensors
+            if world > 1 and not st["bytes_received"] < got["exchange"]["bytes_received"]:
+                why.append(f"bytes received {st['bytes_received']} vs all-gather {got['exchange']['bytes_received']}")
+        q.put((rank, why, st["bytes_received"], got["exchange"]["bytes_received"], st["rows"], n_seg))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_sharded(world, n_infers):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, n_infers)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(res) == world
+    for rank, why, sent, gathered, rows, n_seg in res:
+        assert not why, f"rank {rank}: {why}"
+    print(f"[site-sharded C4] world {world}, M = {n_infers}: bytes RECEIVED per rank {[r[2] for r in res]} (slab exchange) vs "
+          f"{[r[3] for r in res]} (all-gather by subnet); rows {res[0][4]}; {res[0][5]} segments")
+    assert sum(r[4]["mine"] for r in res) == res[0][4]["union"], "the slabs cover the union rows exactly once"
+    return res
+
+
+def test_site_sharded_ensemble_world2_gloo():
+    """The ensembler + panoptic stage of config C4 with the union rows sharded over 2 ranks: bit-identical to the
+    single-process stage on the same subnet predictions (masks, semantic rows, query probabilities, segments, labels)."""
+    _run_sharded(2, 2)
+
+
+def test_site_sharded_ensemble_world4_ragged_gloo():
+    """M = 6 subnets on 4 ranks: two exchange rounds, the second with two idle senders; 8 slabs over 4 ranks."""
+    res = _run_sharded(4, 6)
+    assert res[0][5] > 0, "the case should produce panoptic segments"
+
+
+def test_site_sharded_ensemble_world1_gloo():
+    """One rank owns every slab: the sharded code path itself against `Ensembler.ensemble_panop`."""
+    _run_sharded(1, 3)

@@ -92,6 +92,18 @@ def test_many_outputs_share_one_copy(oracle_registered):
         compare(res, P._panoptic_inference_torch(v, qp, **kw))
 
 
+def test_output_without_queries_is_served(oracle_registered):
+    """An ensemble whose queries were all filtered out by the matching (ensembler.py:100-110) has [N, 0] masks: the call
+    must still answer (no segments, zero labels), next to a normal output in the same step."""
+    c, m, qp, ext = make_case(seed=40, n=500, q=10)
+    kw = dict(overlap_threshold=0.4, object_mask_threshold=0.7, thing_ids=THINGS, scene_size=ext,
+              min_C=torch.zeros(3, dtype=torch.int32), input_query_logit=False, input_voxel_logit=False)
+    empty = (ME.SparseTensor(m[:, :0].contiguous(), c), qp[:, :0])
+    res = P.panoptic_inference_many([(ME.SparseTensor(m, c), qp), empty], **kw)
+    assert isinstance(res[0], P.PanopticResult) and res[1]["segments_infos"] == [[]]
+    assert int(res[1]["panoptic_seg_sparses"][0].abs().sum()) == 0 and res[1]["panoptic_seg_denses"].shape[1:] == ext
+
+
 def test_without_a_backend_the_torch_form_serves():
     c, m, qp, ext = make_case(seed=30, n=400, q=10)
     with pytest.raises(RuntimeError):
