@@ -182,6 +182,24 @@ def test_subnet_parallel_forward_nccl_world1(hip):
             assert torch.equal(a["voxel_logits"].C, b["voxel_logits"].C)
             assert torch.allclose(a["voxel_logits"].F, b["voxel_logits"].F, rtol=1e-4, atol=1e-5)
             assert torch.allclose(a["query_logits"], b["query_logits"], rtol=1e-4, atol=1e-5)
+        # round 5: the site-sharded ensembler + panoptic stage on RCCL (all_reduce of the occupancy bytes, all_to_all of
+        # the mask slabs, all_gather of the matching partials, all_reduce of the panoptic areas) == the single-process
+        # stage on the same predictions, bit for bit (the 2 / 4-rank semantics: tests/test_dist_gloo.py)
+        from pasco_amd.graph.dist import gather_sharded, site_sharded_ensemble, site_sharded_panoptic
+        net.ensembler.scene_size = (40, 40, 8)
+        with torch.no_grad():
+            _, _, ens_ref = net.ensemble(got, sc.Ts)
+            pi_ref = net.panoptic(ens_ref)
+            _, sharded, st = site_sharded_ensemble(net, got, sc.Ts)
+            full = gather_sharded(net, sharded)
+            pis = site_sharded_panoptic(net, sharded)
+        assert len(full) == len(ens_ref) == 5 and st["collectives"] >= 3
+        for a, b in zip(full, ens_ref):
+            assert torch.equal(a["voxel_probs"].C, b["voxel_probs"].C) and torch.equal(a["voxel_probs"].F, b["voxel_probs"].F)
+            assert torch.equal(a["sem_probs"].F, b["sem_probs"].F) and torch.equal(a["query_probs"], b["query_probs"])
+        for p, r in zip(pis, pi_ref):
+            assert torch.equal(p["panoptic"], r["panoptic_seg_sparses"][0])
+            assert [s["query_id"] for s in p["segments_infos"]] == [s["query_id"] for s in r["segments_infos"][0]]
     finally:
         dist.destroy_process_group()
 
