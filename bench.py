@@ -159,6 +159,18 @@ def roofline_object(per_kernel, steps, classes=None):
                                              + ("" if len(same_name) == 1 else f" ({len(same_name)} layer classes run on it)")}
     else:
         out = dict(by_kernel[0])
+    if out.get("traffic") and out.get("alg_bytes_per_launch"):
+        ratio = out["traffic"] / out["alg_bytes_per_launch"]
+        if ratio < 0.5 and out.get("bound") == "hbm":
+            # the contract's `achieved` counts every gathered row once per kernel-map pair; this kernel serves the repeats
+            # from LDS-resident windows, so the HBM it actually moves is far less and the roof it sits under is the matrix pipe
+            out["note"] = (f"`achieved` = ALGORITHMIC bytes / time (SURVEY.md 8(d)); the measured HBM traffic is {ratio:.2f} of "
+                           f"them ({out['traffic'] / max(out['avg_launch_us'], 1e-9) / 1e3:.0f} GB/s = "
+                           f"{out['traffic'] / max(out['avg_launch_us'], 1e-9) / 1e3 / HBM_PEAK_GBS:.2f} of the HBM peak): the "
+                           f"gathers are LDS / L2 hits and this class sits under the MATRIX roof at {out['mfma_frac_of_peak']:.2f} "
+                           f"of the f16 MFMA peak (3 issued products per useful one)")
+            out["matrix_roof"] = {"bound": "mfma", "achieved": out["mfma_TFLOPs_issued"], "peak": F16_MFMA_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": out["mfma_frac_of_peak"]}
     if HBM_COPY_GBS:
         out["hbm_box_copy_GBps"] = round(HBM_COPY_GBS, 1)       # float4 copy of 1 GiB on this box, read + write
     out["conv_ms_per_step"] = round(sum(per_kernel[n]["time_s"] for n in names) / steps * 1e3, 3)
