@@ -429,9 +429,11 @@ int PH_FN(project_canonical)(const float *T, int32_t X, int32_t Y, int32_t Z, do
                              int32_t *out_coords, ph_stream_t stream);
 
 /* COO kernel map (ph_kmap_compact) -> the padded row lists of ph_conv_desc.rl_*: cap = rl_rows (multiple of 128, >= n_out +
- * 127 * kvol rounded up), tcap = entries of tile_k (>= cap / 128).  Counts stay on the device. */
+ * 127 * kvol rounded up), tcap = entries of tile_k (>= cap / 128).  Counts stay on the device; `status` (may be NULL): bit 5
+ * (32) is raised when the map does not hold exactly one pair per output row (sum of counts != n_out). */
 int PH_FN(rowlist_pack)(const int32_t *pairs_in, const int32_t *pairs_out, const int32_t *counts, int32_t kvol, int64_t n_out,
-                        int32_t *rl_in, int32_t *rl_out, int32_t *tile_k, int64_t cap, int64_t tcap, ph_stream_t stream);
+                        int32_t *rl_in, int32_t *rl_out, int32_t *tile_k, int64_t cap, int64_t tcap, int32_t *status,
+                        ph_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Input stage: voxel max of the point features + MIMO channel concatenation (CylinderFeat.forward after its PPmodel,

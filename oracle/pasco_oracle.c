@@ -1115,10 +1115,13 @@ int pho_project_canonical(const float *T, int32_t X, int32_t Y, int32_t Z, doubl
 
 /* padded row lists of a kernel map given in COO form (one list segment per offset, 128-aligned) */
 int pho_rowlist_pack(const int32_t *pairs_in, const int32_t *pairs_out, const int32_t *counts, int32_t kvol, int64_t n_out,
-                     int32_t *rl_in, int32_t *rl_out, int32_t *tile_k, int64_t cap, int64_t tcap, ph_stream_t stream) {
+                     int32_t *rl_in, int32_t *rl_out, int32_t *tile_k, int64_t cap, int64_t tcap, int32_t *status,
+                     ph_stream_t stream) {
   (void)stream;
   if (kvol < 1 || kvol > PH_MAX_KVOL || cap % 128 != 0 || tcap * 128 < cap) return fail("rowlist_pack: bad shape");
-  int64_t pos = 0;
+  int64_t pos = 0, pairs = 0;
+  for (int k = 0; k < kvol; ++k) pairs += counts[k];
+  if (status && pairs != n_out) *status |= 32;          /* not one pair per output row */
   for (int64_t i = 0; i < cap; ++i) rl_in[i] = rl_out[i] = -1;
   for (int64_t t = 0; t < tcap; ++t) tile_k[t] = -1;
   for (int k = 0; k < kvol; ++k) {

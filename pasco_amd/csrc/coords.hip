@@ -431,15 +431,18 @@ extern "C" int ph_kmap_compact(const int32_t *nbr, int32_t kvol, int64_t n_out, 
 __global__ void __launch_bounds__(256)
     k_rowlist_pack(const int32_t *__restrict__ pairs_in, const int32_t *__restrict__ pairs_out, const int32_t *__restrict__ counts,
                    int kvol, int64_t n_out, int32_t *__restrict__ rl_in, int32_t *__restrict__ rl_out,
-                   int32_t *__restrict__ tile_k, int64_t cap, int64_t tcap) {
+                   int32_t *__restrict__ tile_k, int64_t cap, int64_t tcap, int32_t *__restrict__ status) {
   __shared__ int64_t off[PH_MAX_KVOL + 1];
   if (threadIdx.x == 0) {
-    int64_t o = 0;
+    int64_t o = 0, pairs = 0;
     for (int k = 0; k < kvol; ++k) {
       off[k] = o;
       o += ((int64_t)counts[k] + 127) / 128 * 128;
+      pairs += counts[k];
     }
     off[kvol] = o;
+    // the caller's promise "exactly one pair per output row": a map that breaks it would leave output rows unwritten
+    if (status != nullptr && blockIdx.x == 0 && pairs != n_out) atomicOr(status, 32);
   }
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -462,7 +465,7 @@ __global__ void __launch_bounds__(256)
 
 extern "C" int ph_rowlist_pack(const int32_t *pairs_in, const int32_t *pairs_out, const int32_t *counts, int32_t kvol,
                                int64_t n_out, int32_t *rl_in, int32_t *rl_out, int32_t *tile_k, int64_t cap, int64_t tcap,
-                               ph_stream_t stream) {
+                               int32_t *status, ph_stream_t stream) {
   PH_REQUIRE(kvol >= 1 && kvol <= PH_MAX_KVOL, "rowlist_pack: kvol=%d out of range", kvol);
   PH_REQUIRE(cap % 128 == 0 && cap >= n_out + (int64_t)kvol * 127 - (kvol * 127) % 128 && tcap * 128 >= cap,
              "rowlist_pack: list capacity %lld too small for %lld rows and %d offsets", (long long)cap, (long long)n_out, kvol);
@@ -470,7 +473,7 @@ extern "C" int ph_rowlist_pack(const int32_t *pairs_in, const int32_t *pairs_out
   int64_t blocks = (cap + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_rowlist_pack, dim3((unsigned)blocks), dim3(256), 0, ph_stream(stream), pairs_in, pairs_out, counts, kvol,
-                     n_out, rl_in, rl_out, tile_k, cap, tcap);
+                     n_out, rl_in, rl_out, tile_k, cap, tcap, status);
   PH_LAUNCH_CHECK();
   return 0;
 }

@@ -92,7 +92,7 @@ _SIGNATURES = {
     "nbr_build": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "nbr_build_same": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _vp],
     "kmap_compact": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _vp],
-    "rowlist_pack": [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _i64, _vp],
+    "rowlist_pack": [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp],
     "conv_fwd": [C.POINTER(ConvDesc), _vp],
     "conv_last_config": [_vp],
     "win_build": [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
@@ -338,8 +338,7 @@ class CBackend:
         kvol, n_out = nbr.shape
         pin, pout, counts = self.kmap_compact(nbr)
         # the caller's promise "exactly one pair per output row": a map that breaks it would leave output rows unwritten.
-        # Checked on the device (pairs != rows -> status bit 5, reported by the end-of-step check); no host read here.
-        self.status_word(nbr.device).bitwise_or_((counts.sum() != n_out).to(torch.int32) * 32)
+        # Checked on the device by the pack kernel itself (pairs != rows -> status bit 5, reported by the end-of-step check)
         cap = (n_out + kvol * 127 + 127) // 128 * 128
         tcap = cap // 128
         dev = nbr.device
@@ -347,7 +346,7 @@ class CBackend:
         rl_out = torch.empty(cap, dtype=torch.int32, device=dev)
         tile_k = torch.empty(tcap, dtype=torch.int32, device=dev)
         rc = self.fn["rowlist_pack"](_ptr(pin), _ptr(pout), _ptr(counts), kvol, n_out, _ptr(rl_in), _ptr(rl_out), _ptr(tile_k),
-                                     cap, tcap, self.stream(dev))
+                                     cap, tcap, _ptr(self.status_word(dev)), self.stream(dev))
         self._check(rc, "rowlist_pack")
         return {"in": rl_in, "out": rl_out, "tile_k": tile_k}
 
