@@ -385,7 +385,7 @@ int PH_FN(attn_cross_split)(const float *q, const void *k_split, const void *v_s
  * on the rows [x | aug] and K / V are never formed (at the finest level of the benchmark scene: 2 x 970 MB less written
  * and read, two projection launches less).
  *   x_split [B*N, c/32, 2, 32] f16: the level's features as a split operand (value * 2^exp2; ph_split_rows)
- *   aug     [B*N, 16] f16          : position columns of every key (pos_aug below), unscaled
+ *   aug     [B*N, 16] f16          : position columns of every key (pos_aug below), value * 2^exp2 like x_split
  *   q2      [B, H, Qn, c + 16]     : per head q_h [A_h^T | position coefficients] (host), 1/sqrt(Dh) included
  *   out     [B, Qn, H * (c + 16)]  : Y = softmax(q2 [x | aug]^T + mask) [x | aug]; the caller applies (B_h ; position rows)
  *                                    and the constants (folded into the output projection)
@@ -394,12 +394,14 @@ int PH_FN(attn_cross_split)(const float *q, const void *k_split, const void *v_s
  * pos_aug: aug[i] = ([c_x == 0], [c_y == 0], [c_z == 0], eps[c_x - tab_lo], eps[c_y - tab_lo], eps[c_z - tab_lo], 0 x 10)
  * for coords [N, 4] (b, x, y, z).  The sine encoding normalises c / (c + 1e-6) * 2 pi (position_encoding.py:100-104): the
  * angle is 0 for c = 0, exactly 2 pi for |c| >= 32 and 2 pi + eps_c in between, which is all a key's position term depends
- * on (eps [tab_n] fp32 in the caller's scale, eps of the value 0 = 0).  A coordinate outside the table raises status bit 2. */
+ * on (eps [tab_n] fp32 in the caller's scale, eps of the value 0 = 0).  Every column is written times 2^exp2 (the feature
+ * operand's scale: the Q2 position columns then need no extra factor and meet the f16 range flag only above 256, like the
+ * feature columns).  A coordinate outside the table raises status bit 2. */
 int PH_FN(attn_cross_feat)(const float *q2, const void *x_split, const void *aug, int32_t c, int32_t exp2,
                            const uint32_t *bits, const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h,
                            int32_t qn, void *ws, int64_t ws_bytes, int32_t *status, ph_stream_t stream);
 
-int PH_FN(pos_aug)(const int32_t *coords, int64_t n, const float *eps, int32_t tab_lo, int32_t tab_n, void *aug,
+int PH_FN(pos_aug)(const int32_t *coords, int64_t n, const float *eps, int32_t tab_lo, int32_t tab_n, int32_t exp2, void *aug,
                    int32_t *status, ph_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

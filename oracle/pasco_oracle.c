@@ -841,6 +841,7 @@ int pho_attn_cross_feat(const float *q2, const void *x_split, const void *aug, i
   if (qn < 1 || qn > 128 || b < 1 || h < 1 || n < 1) return fail("attn_cross_feat: bad shape");
   const int d = c + 16;
   float *x = unsplit_rows(x_split, (int64_t)b * n, c, ldexpf(1.f, -exp2));
+  const float aug_unscale = ldexpf(1.f, -exp2);         /* the position columns carry the operand's scale (pho_pos_aug) */
   if (!x) return fail("attn_cross_feat: out of memory");
 #pragma omp parallel for collapse(2) schedule(dynamic)
   for (int bi = 0; bi < b; ++bi)
@@ -858,7 +859,7 @@ int pho_attn_cross_feat(const float *q2, const void *x_split, const void *aug, i
         if (ok) {
           s = 0.f;
           for (int ch = 0; ch < c; ++ch) s += qv[ch] * x[row * c + ch];
-          for (int ch = 0; ch < 16; ++ch) s += qv[c + ch] * f16_to_f32_at(aug, row * 16 + ch);
+          for (int ch = 0; ch < 16; ++ch) s += qv[c + ch] * (f16_to_f32_at(aug, row * 16 + ch) * aug_unscale);
         }
         sc[j] = s;
         if (s > mx) mx = s;
@@ -873,7 +874,7 @@ int pho_attn_cross_feat(const float *q2, const void *x_split, const void *aug, i
           const float p = expf(sc[j] - mx);
           l += p;
           for (int ch = 0; ch < c; ++ch) o[ch] += p * x[row * c + ch];
-          for (int ch = 0; ch < 16; ++ch) o[c + ch] += p * f16_to_f32_at(aug, row * 16 + ch);
+          for (int ch = 0; ch < 16; ++ch) o[c + ch] += p * (f16_to_f32_at(aug, row * 16 + ch) * aug_unscale);
         }
         for (int ch = 0; ch < d; ++ch) o[ch] /= l;
       }
@@ -884,10 +885,11 @@ int pho_attn_cross_feat(const float *q2, const void *x_split, const void *aug, i
 }
 
 
-int pho_pos_aug(const int32_t *coords, int64_t n, const float *eps, int32_t tab_lo, int32_t tab_n, void *aug, int32_t *status,
-                ph_stream_t stream) {
+int pho_pos_aug(const int32_t *coords, int64_t n, const float *eps, int32_t tab_lo, int32_t tab_n, int32_t exp2, void *aug,
+                int32_t *status, ph_stream_t stream) {
   (void)stream;
-  if (n < 0 || tab_n < 1) return fail("pos_aug: bad shape");
+  if (n < 0 || tab_n < 1 || exp2 < -14 || exp2 > 14) return fail("pos_aug: bad shape / exponent");
+  const float pow2 = ldexpf(1.f, exp2);                 /* the columns extend the feature operand: same 2^exp2 */
   uint16_t *o = (uint16_t *)aug;
   for (int64_t i = 0; i < n; ++i) {
     for (int k = 0; k < 16; ++k) o[i * 16 + k] = 0;
@@ -898,8 +900,8 @@ int pho_pos_aug(const int32_t *coords, int64_t n, const float *eps, int32_t tab_
         if (status) *status |= 4;
         t = t < 0 ? 0 : tab_n - 1;
       }
-      o[i * 16 + ax] = f32_to_f16_bits(v == 0 ? 1.f : 0.f);
-      o[i * 16 + 3 + ax] = f32_to_f16_bits(eps[t]);
+      o[i * 16 + ax] = f32_to_f16_bits(v == 0 ? pow2 : 0.f);
+      o[i * 16 + 3 + ax] = f32_to_f16_bits(eps[t] * pow2);
     }
   }
   return 0;

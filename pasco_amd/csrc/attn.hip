@@ -633,7 +633,6 @@ struct AttnFeatArgs {
   const _Float16 *xs;         // split feature operand [B*N, 2, 2, 32]
   const _Float16 *aug;        // position columns [B*N, 16]
   float kv_unscale;           // 2^-exp2 of the feature operand
-  float aug_scale;            // 2^exp2: the position columns are stored unscaled, their Q2 columns carry the operand's scale
   int *status;
   int groups;                 // B * splits
 };
@@ -727,7 +726,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_feat(AttnFeatArgs s) {
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float t = v8[i] * (c == 4 ? AS_QSCALE * s.aug_scale : AS_QSCALE);
+      const float t = v8[i] * AS_QSCALE;      // position columns too: their key columns carry the operand's 2^exp2 (ph_pos_aug)
       qbad |= !(fabsf(t) <= 65504.f);
       const _Float16 th = (_Float16)t;
       qh[c][i] = th;
@@ -944,18 +943,20 @@ __global__ void __launch_bounds__(256, 2) k_attn_feat(AttnFeatArgs s) {
     for (int g = 0; g < 4; ++g) {
       const int d = 32 * mt + 8 * g + 4 * h2;
       if (d >= AF_D) continue;
-      // the position columns were written unscaled (ph_pos_aug): only the feature columns carry the operand's 2^exp2
-      const float us = mt < 2 ? s.kv_unscale : 1.f;
+      // feature AND position columns of the keys carry the operand's 2^exp2 (ph_pos_aug writes them pre-scaled, so that
+      // their Q2 columns need no extra factor and raise the f16 range flag only above 256 like the feature columns: ADVICE r4)
+      const float us = s.kv_unscale;
       *reinterpret_cast<float4 *>(row + d) = make_float4(oacc[mt][4 * g] * us, oacc[mt][4 * g + 1] * us, oacc[mt][4 * g + 2] * us,
                                                          oacc[mt][4 * g + 3] * us);
     }
 }
 
 // Position columns of the keys (see k_attn_feat): aug[i] = [c_x == 0, c_y == 0, c_z == 0, eps[c_x], eps[c_y], eps[c_z], 0 ...]
+// x 2^exp2 (the scale of the feature operand they extend: exact powers of two, 32.0 and eps * 32 are normal f16 values)
 // as f16; eps [tab_n] (fp32, already in the caller's scale; eps of the value 0 must be 0) serves the coordinate values
 // tab_lo .. tab_lo + tab_n - 1; a coordinate outside raises status bit 2 (as the per-axis tables of ph_conv_desc do).
 __global__ void __launch_bounds__(256)
-    k_pos_aug(const int4 *__restrict__ coords, int64_t n, const float *__restrict__ eps, int tab_lo, int tab_n,
+    k_pos_aug(const int4 *__restrict__ coords, int64_t n, const float *__restrict__ eps, int tab_lo, int tab_n, float pow2,
               uint4 *__restrict__ aug, int *__restrict__ status) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -970,8 +971,8 @@ __global__ void __launch_bounds__(256)
       bad = true;
       t = t > 0x7fffffffu ? 0u : (unsigned)(tab_n - 1);
     }
-    o[ax] = (_Float16)(v[ax] == 0 ? 1.f : 0.f);
-    o[3 + ax] = (_Float16)eps[t];
+    o[ax] = (_Float16)(v[ax] == 0 ? pow2 : 0.f);
+    o[3 + ax] = (_Float16)(eps[t] * pow2);
   }
   if (bad && status != nullptr) atomicOr(status, 4);
   uint4 w0;
@@ -983,13 +984,13 @@ __global__ void __launch_bounds__(256)
   aug[2 * i + 1] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-extern "C" int ph_pos_aug(const int32_t *coords, int64_t n, const float *eps, int32_t tab_lo, int32_t tab_n, void *aug,
-                          int32_t *status, ph_stream_t stream) {
-  PH_REQUIRE(n >= 0 && tab_n >= 1, "pos_aug: bad shape");
+extern "C" int ph_pos_aug(const int32_t *coords, int64_t n, const float *eps, int32_t tab_lo, int32_t tab_n, int32_t exp2,
+                          void *aug, int32_t *status, ph_stream_t stream) {
+  PH_REQUIRE(n >= 0 && tab_n >= 1 && exp2 >= -14 && exp2 <= 14, "pos_aug: bad shape / exponent");
   if (n == 0) return 0;
   PH_REQUIRE(coords && eps && aug, "pos_aug: null buffer");
   hipLaunchKernelGGL(k_pos_aug, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ph_stream(stream), (const int4 *)coords, n, eps,
-                     tab_lo, tab_n, (uint4 *)aug, status);
+                     tab_lo, tab_n, ldexpf(1.f, exp2), (uint4 *)aug, status);
   PH_LAUNCH_CHECK();
   return 0;
 }
@@ -1237,7 +1238,6 @@ extern "C" int ph_attn_cross_feat(const float *q2, const void *x_split, const vo
   a.n = n; a.B = b; a.H = h; a.Qn = qn; a.Dh = AF_D;
   s.xs = (const _Float16 *)x_split; s.aug = (const _Float16 *)aug;
   s.kv_unscale = ldexpf(1.f, -exp2);
-  s.aug_scale = ldexpf(1.f, exp2);
   s.status = status;
   const int64_t ntile = (n + AS_KT - 1) / AS_KT;
   const int bh = b * h;

@@ -118,7 +118,7 @@ _SIGNATURES = {
     "ens_finish": [_vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp],
     "attn_cross_split": [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
     "attn_cross_feat": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
-    "pos_aug": [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _vp],
+    "pos_aug": [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "keep_mask": [_vp, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp],
     "points_bounds": [_vp, _i64, _vp, _vp],
     "points_mark": [_vp, _i64, _vp, _vp, _vp, _vp, _vp],
@@ -1024,15 +1024,16 @@ class CBackend:
 
     POS_AUG_COLS = 16
 
-    def pos_aug(self, coords: torch.Tensor, eps: torch.Tensor, tab_lo: int) -> torch.Tensor:
+    def pos_aug(self, coords: torch.Tensor, eps: torch.Tensor, tab_lo: int, exp2: Optional[int] = None) -> torch.Tensor:
         """coords int32 [N, 4] -> position columns f16 [N, 16] of the keys (include/pasco_hip.h pos_aug): [c == 0] and
-        eps[c - tab_lo] per axis."""
+        eps[c - tab_lo] per axis, times 2^exp2 (default SPLIT_ACT_EXP2: the scale of the feature operand they extend)."""
+        exp2 = SPLIT_ACT_EXP2 if exp2 is None else int(exp2)
         self._chk(coords, torch.int32, "coords")
         self._chk(eps, torch.float32, "eps")
         n = coords.shape[0]
         assert coords.shape[1] == 4
         out = torch.empty((n, self.POS_AUG_COLS), dtype=torch.float16, device=coords.device)
-        rc = self.fn["pos_aug"](_ptr(coords), n, _ptr(eps), int(tab_lo), eps.numel(), _ptr(out),
+        rc = self.fn["pos_aug"](_ptr(coords), n, _ptr(eps), int(tab_lo), eps.numel(), exp2, _ptr(out),
                                 _ptr(self.status_word(coords.device)), self.stream(coords.device))
         self._check(rc, "pos_aug")
         return out

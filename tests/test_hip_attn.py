@@ -200,7 +200,8 @@ def feat_ref(q2, x_split, aug, B, N, allow):
     from pasco_amd.me.backend import SPLIT_ACT_EXP2
     xs = x_split.double()
     x = (xs[:, :, 0] + xs[:, :, 1]).reshape(B, N, -1) * 2.0 ** -SPLIT_ACT_EXP2
-    r = torch.cat([x, aug.double().reshape(B, N, 16)], dim=-1)             # [B, N, E]
+    # the position columns carry the operand's 2^exp2 like the feature columns (ph_pos_aug, round 5)
+    r = torch.cat([x, aug.double().reshape(B, N, 16) * 2.0 ** -SPLIT_ACT_EXP2], dim=-1)             # [B, N, E]
     s = torch.einsum("bhqe,bne->bhqn", q2.double(), r)
     if allow is not None:
         al = allow.permute(0, 2, 1)
@@ -247,6 +248,27 @@ def test_attn_cross_feat_matches_fp64(hip, B, H, Q, N, masked):
     hip.check_status(x.device)
     assert torch.isfinite(got).all()
     assert torch.allclose(got, exp, rtol=1e-4, atol=2e-5), float((got - exp).abs().max())
+
+
+def test_attn_feat_position_coefficients_share_the_feature_range(hip):
+    """the Q2 position columns used to be split as q * 2^8 * 2^exp2, so a coefficient above ~8 raised the f16
+    range flag (status bit 0) and cost a whole-step redo on the exact path - a cliff trained weights could hit silently.
+    The key columns now carry the 2^exp2 (ph_pos_aug), the coefficients meet the flag only above 256 like the feature
+    columns: coefficients of ~100 give fp64-accurate results and no flag; above 256 the flag still fires."""
+    B, H, Q, N = 2, 8, 100, 3000
+    x, coords, q2, eps, lo = feat_inputs(B, H, Q, N, 21, hip)
+    q2 = q2.clone()
+    q2[..., 64:70] *= 100.0 / float(q2[..., 64:70].abs().max())
+    xs, aug = hip.split_rows(x), hip.pos_aug(coords, eps, lo)
+    got = hip.attn_cross_feat(q2, xs, aug, N)
+    hip.check_status(x.device)                        # no flag
+    exp = feat_ref(q2, xs, aug, B, N, None)
+    assert torch.allclose(got, exp, rtol=1e-4, atol=1e-4), float((got - exp).abs().max())
+    q2[0, 0, 0, 64] = 300.0
+    hip.attn_cross_feat(q2, xs, aug, N)
+    from pasco_amd.me.backend import F16RangeError
+    with pytest.raises(F16RangeError):
+        hip.check_status(x.device)
 
 
 def test_pos_aug_and_feat_attention_match_the_oracle(hip, oracle):
