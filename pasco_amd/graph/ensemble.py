@@ -89,10 +89,12 @@ def _gram(a: torch.Tensor, b: torch.Tensor, chunks: int = 256) -> torch.Tensor:
     return out
 
 
-GRAM_SLABS = 8       # the union rows are cut into this many contiguous slabs; every reduction over the rows (the matching's
-                     # Gram matrix and column sums) is formed per slab and the slab results are added in slab order.  The
-                     # order is part of the result: a run that shards the rows by slab over 2 / 4 / 8 ranks (config C4,
-                     # dist.site_sharded_ensemble) adds the same partial results in the same order -> bit-identical.
+GRAM_SLABS = 8       # config C4 (dist.site_sharded_ensemble) cuts the union rows into this many contiguous slabs owned by the
+                     # ranks; every reduction over the rows (the matching's Gram matrix and column sums) is formed per slab and
+                     # the slab results are added in slab order.  The order is part of the result: `Ensembler(gram_slabs=8)`
+                     # adds the same partial results in the same order in ONE process -> bit-identical to the sharded run.
+                     # The default single-GPU ensembler keeps one slab (one batched GEMM per matching: 8 slabs cost 8 x the
+                     # launches, +1.0 ms per step measured in profiles/r5z_bench_kernel_stats.csv's predecessor).
 
 
 def slab_bounds(n_rows: int, slabs: int = GRAM_SLABS) -> List[int]:
@@ -152,9 +154,10 @@ def _ens_finish_torch(anchor, keep, sem, sel):
 
 
 class Ensembler(torch.nn.Module):
-    def __init__(self, scene_size=CANONICAL_SIZE):
+    def __init__(self, scene_size=CANONICAL_SIZE, gram_slabs: int = 1):
         super().__init__()
         self.scene_size = tuple(scene_size)
+        self.gram_slabs = int(gram_slabs)      # 1 = one reduction over all union rows; GRAM_SLABS = the order of config C4
         self._sites = {}
 
     def projected(self, T: torch.Tensor, device, cache: dict) -> torch.Tensor:
@@ -211,11 +214,11 @@ class Ensembler(torch.nn.Module):
 
     # -- a22 -----------------------------------------------------------------------------------------
     @staticmethod
-    def match_queries(anchor_mask: torch.Tensor, aux_mask: torch.Tensor, iou_threshold: float):
-        """Soft-IoU Hungarian matching of query masks given as [U, Q] site rows (utils.py:153-198).  The sums over the rows
-        are formed slab by slab and added in slab order (GRAM_SLABS)."""
-        b = slab_bounds(anchor_mask.shape[0])
-        parts = [match_partials(anchor_mask[b[k]:b[k + 1]], aux_mask[b[k]:b[k + 1]]) for k in range(GRAM_SLABS)]
+    def match_queries(anchor_mask: torch.Tensor, aux_mask: torch.Tensor, iou_threshold: float, slabs: int = 1):
+        """Soft-IoU Hungarian matching of query masks given as [U, Q] site rows (utils.py:153-198).  `slabs` > 1: the sums
+        over the rows are formed slab by slab and added in slab order (what the site-sharded run of config C4 does)."""
+        b = slab_bounds(anchor_mask.shape[0], slabs)
+        parts = [match_partials(anchor_mask[b[k]:b[k + 1]], aux_mask[b[k]:b[k + 1]]) for k in range(slabs)]
         return match_from_partials(parts, anchor_mask.shape[1], iou_threshold)
 
     def ensemble_panop(self, panop_predictions, ensemble_sem_prob_denses, Ts, iou_threshold=0.2, cache: dict = None):
@@ -257,7 +260,10 @@ class Ensembler(torch.nn.Module):
         anchor_m = masks[0].clone() if n_sub > 1 else masks[0]
         ious = []
         for i in range(1, n_sub):
-            a_idx, b_idx, iou = self.match_queries(anchor_m, masks[i], iou_threshold)
+            if self.gram_slabs > 1:
+                a_idx, b_idx, iou = self.match_queries(anchor_m, masks[i], iou_threshold, self.gram_slabs)
+            else:
+                a_idx, b_idx, iou = self.match_queries(anchor_m, masks[i], iou_threshold)
             # the assignment of a square cost matrix lists every anchor query once, in order (a_idx = 0..Q-1)
             anchor_q = (anchor_q * i + query_probs[i][:, b_idx, :]) / (i + 1)
             ens_merge(anchor_m, masks[i], b_idx.to(torch.int32).contiguous(), i)

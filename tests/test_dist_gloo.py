@@ -211,6 +211,8 @@ def _sharded_worker(rank, world, port, q, n_infers):
         net = PascoNet(n_classes=20, n_infers=n_infers, in_channels=12, f=8, num_queries=8, heavy_decoder=False,
                        object_mask_threshold=0.05).eval()          # random queries: a low bar so that segments exist
         net.ensembler.scene_size = (24, 24, 8)
+        from pasco_amd.graph.ensemble import GRAM_SLABS
+        net.ensembler.gram_slabs = GRAM_SLABS              # the single-process reference adds the slabs in the sharded run's order
         sc = make_scene(4, n_infers=n_infers, in_channels=12, grid=(24, 24, 8), occupancy=0.12)
         tk = TeacherKeep(sc, "cpu")
         why = []

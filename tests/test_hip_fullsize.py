@@ -187,6 +187,8 @@ def test_subnet_parallel_forward_nccl_world1(hip):
         # stage on the same predictions, bit for bit (the 2 / 4-rank semantics: tests/test_dist_gloo.py)
         from pasco_amd.graph.dist import gather_sharded, site_sharded_ensemble, site_sharded_panoptic
         net.ensembler.scene_size = (40, 40, 8)
+        from pasco_amd.graph.ensemble import GRAM_SLABS
+        net.ensembler.gram_slabs = GRAM_SLABS              # the reference adds the slabs in the sharded run's order
         with torch.no_grad():
             _, _, ens_ref = net.ensemble(got, sc.Ts)
             pi_ref = net.panoptic(ens_ref)
