@@ -772,7 +772,7 @@ int pho_attn_cross_fwd(const float *q, const float *k, const float *v, const uin
                        float *out, int64_t n, int32_t b, int32_t h, int32_t qn, int32_t dh, void *ws,
                        int64_t ws_bytes, ph_stream_t stream) {
   (void)ws; (void)ws_bytes; (void)stream;
-  if (qn < 1 || qn > 128 || dh < 1) return fail("attn_cross_fwd: bad shape");
+  if (qn < 1 || qn > 128 || dh < 1 || dh > 512) return fail("attn_cross_fwd: bad shape");
   const int D = h * dh;
 #pragma omp parallel for collapse(2) schedule(dynamic)
   for (int bi = 0; bi < b; ++bi)
@@ -788,24 +788,29 @@ int pho_attn_cross_fwd(const float *q, const float *k, const float *v, const uin
         float s = -INFINITY;
         if (ok) {
           const float *kv = k + ((int64_t)bi * n + j) * D + hi * dh;
-          s = 0.f;
-          for (int d = 0; d < dh; ++d) s += qv[d] * kv[d];
+          double sd = 0.0;
+          for (int d = 0; d < dh; ++d) sd += (double)qv[d] * (double)kv[d];
+          s = (float)sd;
         }
         sc[j] = s;
         if (s > mx) mx = s;
       }
       float *o = out + ((int64_t)bi * qn + qi) * D + hi * dh;
       for (int d = 0; d < dh; ++d) o[d] = 0.f;
-      float l = 0.f;
+      /* the sums over the keys run over up to ~10^6 terms (631 k keys at S10): accumulated in double - a sequential fp32 sum
+       * of that length carries ~3e-5 of rounding of its own, which the decoder layers behind it amplify; the checker should
+       * not be the less exact side of a comparison (round 5: tests/test_s10_end_to_end.py, three arithmetics) */
+      double l = 0.0, od[512];
+      for (int d = 0; d < dh && d < 512; ++d) od[d] = 0.0;
       if (mx > -INFINITY) {
         for (int64_t j = 0; j < n; ++j) {
           if (sc[j] == -INFINITY) continue;
-          float p = expf(sc[j] - mx);
+          const double p = (double)expf(sc[j] - mx);
           l += p;
           const float *vv = v + ((int64_t)bi * n + j) * D + hi * dh;
-          for (int d = 0; d < dh; ++d) o[d] += p * vv[d];
+          for (int d = 0; d < dh; ++d) od[d] += p * (double)vv[d];
         }
-        for (int d = 0; d < dh; ++d) o[d] /= l;
+        for (int d = 0; d < dh; ++d) o[d] = (float)(od[d] / l);
       }
       free(sc);
     }
@@ -837,7 +842,7 @@ int pho_attn_cross_feat(const float *q2, const void *x_split, const void *aug, i
                         const uint32_t *any, float *out, int64_t n, int32_t b, int32_t h, int32_t qn, void *ws,
                         int64_t ws_bytes, int32_t *status, ph_stream_t stream) {
   (void)ws; (void)ws_bytes; (void)status; (void)stream;
-  if (c < 32 || c % 32 != 0) return fail("attn_cross_feat: channels must be a multiple of 32");
+  if (c < 32 || c % 32 != 0 || c > 1024) return fail("attn_cross_feat: channels must be a multiple of 32 (<= 1024)");
   if (qn < 1 || qn > 128 || b < 1 || h < 1 || n < 1) return fail("attn_cross_feat: bad shape");
   const int d = c + 16;
   float *x = unsplit_rows(x_split, (int64_t)b * n, c, ldexpf(1.f, -exp2));
@@ -857,26 +862,28 @@ int pho_attn_cross_feat(const float *q2, const void *x_split, const void *aug, i
         int ok = force || ((bits[row * 4 + (qi >> 5)] >> (qi & 31)) & 1u);
         float s = -INFINITY;
         if (ok) {
-          s = 0.f;
-          for (int ch = 0; ch < c; ++ch) s += qv[ch] * x[row * c + ch];
-          for (int ch = 0; ch < 16; ++ch) s += qv[c + ch] * (f16_to_f32_at(aug, row * 16 + ch) * aug_unscale);
+          double sd = 0.0;
+          for (int ch = 0; ch < c; ++ch) sd += (double)qv[ch] * (double)x[row * c + ch];
+          for (int ch = 0; ch < 16; ++ch) sd += (double)qv[c + ch] * (double)(f16_to_f32_at(aug, row * 16 + ch) * aug_unscale);
+          s = (float)sd;
         }
         sc[j] = s;
         if (s > mx) mx = s;
       }
       float *o = out + ((int64_t)bi * qn + qi) * ((int64_t)h * d) + (int64_t)hi * d;
       for (int ch = 0; ch < d; ++ch) o[ch] = 0.f;
-      float l = 0.f;
+      double l = 0.0, od[1024 + 16];                     /* sums over the keys in double, as in pho_attn_cross_fwd */
+      for (int ch = 0; ch < d; ++ch) od[ch] = 0.0;
       if (mx > -INFINITY) {
         for (int64_t j = 0; j < n; ++j) {
           if (sc[j] == -INFINITY) continue;
           const int64_t row = (int64_t)bi * n + j;
-          const float p = expf(sc[j] - mx);
+          const double p = (double)expf(sc[j] - mx);
           l += p;
-          for (int ch = 0; ch < c; ++ch) o[ch] += p * x[row * c + ch];
-          for (int ch = 0; ch < 16; ++ch) o[c + ch] += p * (f16_to_f32_at(aug, row * 16 + ch) * aug_unscale);
+          for (int ch = 0; ch < c; ++ch) od[ch] += p * (double)x[row * c + ch];
+          for (int ch = 0; ch < 16; ++ch) od[c + ch] += p * (double)(f16_to_f32_at(aug, row * 16 + ch) * aug_unscale);
         }
-        for (int ch = 0; ch < d; ++ch) o[ch] /= l;
+        for (int ch = 0; ch < d; ++ch) o[ch] = (float)(od[ch] / l);
       }
       free(sc);
     }

@@ -9,12 +9,10 @@ and once on the host through the oracle library + torch-CPU (the ~20 s `bench.py
 The contract, stated once (DESIGN.md section 2 quotes this file):
   * coordinates of every sparse output: bit-exact, same row order;
   * every floating-point logit tensor (`sem_logits_at_scales`, `voxel_logits`, `query_logits`):
-    |got - exp| <= 1e-3 (|exp| + mean |exp|), i.e. torch.allclose with rtol = 1e-3 and atol = 1e-3 of the tensor's mean
-    magnitude (a logit that cancels to ~0 has no meaningful relative error of its own).  Measured: 7.2e-4 of mean |y| at
-    the worst element - the voxel logits of one query column move together with that query's mask embedding, which has
-    been through three decoder layers whose attention masks are thresholds (logit > 0) of the previous prediction; the
-    CPU restatement sums every convolution sequentially in fp32.  Two HIP paths against each other (split precision vs
-    exact fp32 MFMA, tests/test_hip_bench_shapes.py) are held to the tighter floor of 0.25 mean |y| (measured 2.9e-4);
+    |got - exp| <= 1e-3 (|exp| + 0.25 mean |exp|) (a logit that cancels to ~0 has no meaningful relative error of its
+    own) - the same floor two HIP paths are held to against each other (tests/test_hip_bench_shapes.py).  Measured (round
+    5): 7.9e-5 of mean |y| at the worst element, 1.85e-5 with the oracle's attention-mask decisions forced into the HIP
+    run (asserted <= 1e-4); see FLOOR below for how the 7.2e-4 of rounds 3 - 4 turned out to be the checker's own;
   * semantic ensemble and the subnets' mask probabilities of the chain: |difference| <= 2e-3 (they live in [0, 1]);
   * the ensembling + panoptic stage (Hungarian matching of queries, merged masks, segments) is compared on IDENTICAL inputs
     - the device's stage fed the oracle's subnet predictions: rows bit-exact, probabilities to 1e-5, same segments, panoptic
@@ -28,16 +26,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-FLOOR = 1.0          # |got - exp| <= 1e-3 (|exp| + FLOOR * mean |exp|): torch.allclose(rtol = 1e-3, atol = 1e-3 mean |exp|)
-# Round 5 tested the explanation rounds 3 - 4 gave for the size of the error ("attention masks are thresholds of the previous
-# prediction"): with the oracle run's 189 M mask decisions FORCED into the HIP run (tests/mask_freeze.py) the error does not
-# move (7.2e-4 -> 7.2e-4 of mean |y|; the HIP run decides only ~80 of them differently on its own, all at logits below 1e-3
-# of the mean).  The thresholds are NOT the cause.  What the test shows instead: three fp32 arithmetics of the same graph -
-# the oracle's sequential sums, the exact fp32 MFMA path and the split-precision path - differ pairwise by 3e-4 .. 7e-4 of
-# mean |y| on THIS random-weight net (default inits + random BatchNorm statistics; its query columns are ill-conditioned),
-# while the reference's own graph at the same widths with default-init-scale weights agrees to 6e-5 on the same kernels
-# (tests/test_golden_wide.py).  The floor therefore stays where the conditioning of the benchmark's net puts it.
-PROB_ATOL = 2e-3     # probabilities ([0, 1]): sigmoid / softmax of logits that agree to ~7e-4 of their mean magnitude
+FLOOR = 0.25         # |got - exp| <= 1e-3 (|exp| + FLOOR * mean |exp|): the floor two HIP paths are held to against each other
+# History of this number.  Rounds 3 - 4 measured 7.2e-4 of mean |y| at the worst voxel logit, held FLOOR at 1.0 and blamed the
+# attention masks being thresholds of the previous prediction.  Round 5 tested that: with the oracle run's 189 M mask decisions
+# FORCED into the HIP run (tests/mask_freeze.py) the error did not move, and a third arithmetic (every product on the exact fp32
+# MFMA) sat 5.5e-5 from the split path but the same 7.2e-4 from the oracle - the outlier was the CHECKER: its attention summed the
+# softmax denominator and the weighted values over up to 631 k keys sequentially in fp32.  With those two sums in double
+# (oracle/pasco_oracle.c pho_attn_cross_*) the HIP path is 7.9e-5 of mean |y| from the oracle (3.2e-4 under this floor), and
+# with the mask decisions frozen 1.85e-5: what was left WAS the thresholds (~60 of 189 M decisions land on the other side of 0).
+FROZEN_MAX_OVER_MEAN = 1e-4   # with the oracle's mask decisions forced: max |error| / mean |y| (measured 1.85e-5)
+PROB_ATOL = 1e-3     # probabilities ([0, 1]): sigmoid / softmax of logits that agree to ~8e-5 of their mean magnitude
 
 
 def _rel(a, b, floor=FLOOR):
@@ -135,7 +133,7 @@ def test_s10_step_hip_vs_oracle_end_to_end(hip, oracle):
     # ---- the same step with the oracle run's attention-mask decisions forced into the HIP run -----------------------------
     # The masks of decoder layer l are thresholds (mask logit > 0, transformer_predictor_v2.py:224) of layer l - 1's
     # prediction: a near-zero logit that the two arithmetics round to different sides changes one key of one query's
-    # attention.  With the decisions frozen, what remains is arithmetic alone - measured: the same error (see the top).
+    # attention.  With the decisions frozen, what remains is arithmetic alone (measured 1.85e-5 against 7.9e-5 free-running).
     stats = {}
     with mask_freeze.forcing(mask_decisions, stats):
         frozen = run(torch.device("cuda", 0), unet_only=True)
@@ -149,8 +147,9 @@ def test_s10_step_hip_vs_oracle_end_to_end(hip, oracle):
     for a, b, what in pairs:
         m, r = _rel(a.cpu(), b, FLOOR)
         fw["max/mean"], fw["elementwise"] = max(fw["max/mean"], m), max(fw["elementwise"], r)
-        if r > 1e-3:
-            failures.append(f"frozen masks: {what}: element-wise relative {r:.3e} (floor {FLOOR} mean |y|)")
+        if r > 1e-3 or m > FROZEN_MAX_OVER_MEAN:
+            failures.append(f"frozen masks: {what}: max error {m:.3e} of mean |y| (bound {FROZEN_MAX_OVER_MEAN}), element-wise "
+                            f"relative {r:.3e} (floor {FLOOR} mean |y|)")
     print(f"[s10 e2e] attention-mask decisions: {stats['decisions']} in {stats['calls']} layers, {stats['differ']} decided "
           f"differently by the HIP run on its own, {stats['differ_above_noise']} of them with a logit above 1e-3 of the mean")
     print(f"[s10 e2e] logits with the oracle's mask decisions forced: worst max-error / mean |y| {fw['max/mean']:.2e}, "
