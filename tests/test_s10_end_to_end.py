@@ -35,7 +35,7 @@ FLOOR = 0.25         # |got - exp| <= 1e-3 (|exp| + FLOOR * mean |exp|): the flo
 # (oracle/pasco_oracle.c pho_attn_cross_*) the HIP path is 7.9e-5 of mean |y| from the oracle (3.2e-4 under this floor), and
 # with the mask decisions frozen 1.85e-5: what was left WAS the thresholds (~60 of 189 M decisions land on the other side of 0).
 FROZEN_MAX_OVER_MEAN = 1e-4   # with the oracle's mask decisions forced: max |error| / mean |y| (measured 1.85e-5)
-PROB_ATOL = 1e-3     # probabilities ([0, 1]): sigmoid / softmax of logits that agree to ~8e-5 of their mean magnitude
+PROB_ATOL = 2e-4     # probabilities ([0, 1]) of the chain: measured 2.5e-5 at most (logits agree to 8e-5 of their mean magnitude)
 
 
 def _rel(a, b, floor=FLOOR):
