@@ -159,16 +159,18 @@ def small_scene(n_infers, in_ch):
 
 
 @torch.no_grad()
-def golden_unet(n_infers, heavy, tag):
+def golden_unet(n_infers, heavy, tag, empty_subnet=None):
     """Random weights make `argmax != 0` pruning erratic; walk seeds until every level keeps a
-    non-degenerate voxel set (the chosen seed is stored in the fixture)."""
+    non-degenerate voxel set (the chosen seed is stored in the fixture).  `empty_subnet`: that subnet's completion heads
+    answer class 0 everywhere, so its panoptic branch takes the reference's "nothing kept -> the first 1000 rows" fallback
+    at every scale (decoder_v3.py:415-418)."""
     for seed in range(40):
-        if _golden_unet(n_infers, heavy, tag, seed):
+        if _golden_unet(n_infers, heavy, tag, seed, empty_subnet):
             return
     raise RuntimeError("no seed gave a non-degenerate pruning trajectory")
 
 
-def _golden_unet(n_infers, heavy, tag, seed):
+def _golden_unet(n_infers, heavy, tag, seed, empty_subnet=None):
     """Whole U-Net + transformer graph of the reference on the ME surface (oracle arithmetic)."""
     from pasco.models.unet3d_sparse_v2 import UNet3DV2
     from pasco.models.transformer.transformer_predictor_v2 import TransformerPredictorV2
@@ -189,6 +191,8 @@ def _golden_unet(n_infers, heavy, tag, seed):
     for blk in net.decoder_generative.dec_blocks:
         for head in blk.completion_heads.values():
             head[0].kernel.data[:, 0] *= HEAD_GAIN
+        if empty_subnet is not None:
+            blk.completion_heads[str(empty_subnet)][0].bias.data[0, 0] += 1e3
     sc = small_scene(n_infers, f)
     # per-voxel input features (the reference's point MLP is GPU-only)
     coords, feats = [], []
@@ -506,6 +510,9 @@ if __name__ == "__main__":
     if "--ensemble-only" in sys.argv:
         golden_ensemble()
         sys.exit(0)
+    if "--fallback-only" in sys.argv:
+        golden_unet(2, False, "m2_fallback", empty_subnet=1)
+        sys.exit(0)
     if "--wide-only" in sys.argv:
         golden_unet_wide()
         sys.exit(0)
@@ -518,6 +525,7 @@ if __name__ == "__main__":
     golden_unet(1, False, "m1_light")
     golden_unet(2, False, "m2_light")
     golden_unet(1, True, "m1_heavy")
+    golden_unet(2, False, "m2_fallback", empty_subnet=1)
     golden_unet_wide()
     golden_ensemble()
     golden_transform_and_matching()
