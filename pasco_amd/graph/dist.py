@@ -19,6 +19,23 @@ import torch
 import torch.distributed as dist
 
 
+def _host_staged(t: torch.Tensor, group=None) -> bool:
+    """gloo moves host memory only (its device support is broadcast / all_reduce): device tensors of the other collectives are
+    staged through the host.  RCCL ("nccl") takes device tensors directly - this branch is never taken on the product path."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_gather(outs: List[torch.Tensor], t: torch.Tensor, group=None) -> None:
+    if _host_staged(t, group):
+        th = t.cpu()
+        hs = [torch.empty_like(th) for _ in outs]
+        dist.all_gather(hs, th, group=group)
+        for o, h in zip(outs, hs):
+            o.copy_(h)
+        return
+    dist.all_gather(outs, t, group=group)
+
+
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     """Round-robin ownership of independent scenes."""
     return list(range(rank, n_items, world))
@@ -29,13 +46,13 @@ def allgather_rows(rows: torch.Tensor, group=None) -> List[torch.Tensor]:
     world = dist.get_world_size(group)
     n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
+    _all_gather(sizes, n, group=group)
     sizes = [int(s.item()) for s in sizes]
     n_max = max(sizes) if sizes else 0
     pad = rows.new_zeros((n_max,) + tuple(rows.shape[1:]))
     pad[: rows.shape[0]] = rows
     out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad.contiguous(), group=group)
+    _all_gather(out, pad.contiguous(), group=group)
     return [o[:s] for o, s in zip(out, sizes)]
 
 
@@ -55,7 +72,7 @@ def packed_allgather(parts: Sequence[torch.Tensor], group=None) -> Tuple[List[Li
     dev = parts[0].device
     rows = torch.tensor([int(p.shape[0]) for p in parts], dtype=torch.int64, device=dev)
     all_rows = [torch.zeros_like(rows) for _ in range(world)]
-    dist.all_gather(all_rows, rows, group=group)
+    _all_gather(all_rows, rows, group=group)
     counts = torch.stack(all_rows).tolist()                       # the one host read of the step
     row_bytes = [p.element_size() * math.prod(p.shape[1:]) for p in parts]
     ALIGN = 16                                                    # every part starts on a 16-byte boundary of the buffer: the
@@ -80,7 +97,7 @@ def packed_allgather(parts: Sequence[torch.Tensor], group=None) -> Tuple[List[Li
         if nb:
             mine[off:off + nb] = p.contiguous().view(-1).view(torch.uint8)
     box = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(box, mine, group=group)
+    _all_gather(box, mine, group=group)
     out = []
     for r in range(world):
         offs, _ = layout(counts[r])
@@ -289,17 +306,24 @@ def exchange_blocks(send: List[torch.Tensor], recv: List[torch.Tensor], group=No
         return
     if recv[rank].numel():
         recv[rank].copy_(send[rank])
+    staged = any(_host_staged(t, group) for t in send + recv)
+    hsend = [t.cpu() if (staged and t.numel()) else t for t in send]
+    hrecv = [torch.empty(t.shape, dtype=t.dtype) if (staged and t.numel()) else t for t in recv]
     ops = []
     for k in range(world):
         if k == rank:
             continue
         if send[k].numel():
-            ops.append(dist.P2POp(dist.isend, send[k], k, group))
+            ops.append(dist.P2POp(dist.isend, hsend[k], k, group))
         if recv[k].numel():
-            ops.append(dist.P2POp(dist.irecv, recv[k], k, group))
+            ops.append(dist.P2POp(dist.irecv, hrecv[k], k, group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    if staged:
+        for k in range(world):
+            if k != rank and recv[k].numel():
+                recv[k].copy_(hrecv[k])
 
 
 def site_sharded_ensemble(net, ret, Ts, group=None):
@@ -354,7 +378,7 @@ def site_sharded_ensemble(net, ret, Ts, group=None):
     for r in range(len(mine)):
         qmine[r] = F.softmax(local[r]["query_logits"].reshape(nq, n_cls1), dim=-1)
     qall = [torch.empty_like(qmine) for _ in range(world)]
-    dist.all_gather(qall, qmine, group=group)
+    _all_gather(qall, qmine, group=group)
     stats["bytes_sent"] += int(qmine.numel() * 4)
     stats["bytes_received"] += int(qmine.numel() * 4 * (world - 1))
     stats["collectives"] += 1
@@ -400,7 +424,7 @@ def site_sharded_ensemble(net, ret, Ts, group=None):
         for j in range(len(my_slabs)):
             part[j] = E.match_partials(anchor_m[local_b[j]:local_b[j + 1]], masks[i][local_b[j]:local_b[j + 1]])
         allp = [torch.empty_like(part) for _ in range(world)]
-        dist.all_gather(allp, part, group=group)
+        _all_gather(allp, part, group=group)
         stats["bytes_sent"] += int(part.numel() * 4)
         stats["bytes_received"] += int(part.numel() * 4 * (world - 1))
         stats["collectives"] += 1

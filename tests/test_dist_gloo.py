@@ -193,7 +193,7 @@ def test_bench_launches_its_own_ranks():
 
 
 # ---- config C4 with the ensembling sharded by canonical-site slab (dist.site_sharded_ensemble) ------------------------------
-def _sharded_worker(rank, world, port, q, n_infers):
+def _sharded_worker(rank, world, port, q, n_infers, device="cpu"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["OMP_NUM_THREADS"] = "2"
@@ -206,15 +206,16 @@ def _sharded_worker(rank, world, port, q, n_infers):
         from pasco_amd.graph.dist import (allgather_rows, gather_sharded, shard_indices, site_sharded_ensemble,
                                           site_sharded_panoptic, subnet_parallel_forward)
         from pasco_amd.graph.synth import TeacherKeep, make_scene
-        backend.register_checker_backend(load_oracle())
+        if device == "cpu":
+            backend.register_checker_backend(load_oracle())
         torch.manual_seed(3)
         net = PascoNet(n_classes=20, n_infers=n_infers, in_channels=12, f=8, num_queries=8, heavy_decoder=False,
-                       object_mask_threshold=0.05).eval()          # random queries: a low bar so that segments exist
+                       object_mask_threshold=0.05).eval().to(device)          # random queries: a low bar so that segments exist
         net.ensembler.scene_size = (24, 24, 8)
         from pasco_amd.graph.ensemble import GRAM_SLABS
         net.ensembler.gram_slabs = GRAM_SLABS              # the single-process reference adds the slabs in the sharded run's order
-        sc = make_scene(4, n_infers=n_infers, in_channels=12, grid=(24, 24, 8), occupancy=0.12)
-        tk = TeacherKeep(sc, "cpu")
+        sc = make_scene(4, n_infers=n_infers, in_channels=12, grid=(24, 24, 8), occupancy=0.12).to(device)
+        tk = TeacherKeep(sc, device)
         why = []
         with torch.no_grad():
             x = net.prepare_input(sc.in_feats, sc.in_coords)
@@ -255,11 +256,11 @@ def _sharded_worker(rank, world, port, q, n_infers):
         dist.destroy_process_group()
 
 
-def _run_sharded(world, n_infers):
+def _run_sharded(world, n_infers, device="cpu"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, n_infers)) for r in range(world)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, n_infers, device)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(world))
@@ -290,3 +291,16 @@ def test_site_sharded_ensemble_world4_ragged_gloo():
 def test_site_sharded_ensemble_world1_gloo():
     """One rank owns every slab: the sharded code path itself against `Ensembler.ensemble_panop`."""
     _run_sharded(1, 3)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_site_sharded_ensemble_two_ranks_on_one_gpu():
+    """Two ranks that SHARE cuda:0 (RCCL refuses two ranks on one device, so the process group is gloo, which stages device
+    tensors through the host): the sharded stage end to end on libpascohip.so - resampling, slab exchange, partial sums,
+    merge, finish, panoptic kernels with areas added over the ranks - bit-identical to the single-process stage on the GPU."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _run_sharded(2, 4, device="cuda")
