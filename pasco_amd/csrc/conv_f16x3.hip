@@ -598,8 +598,6 @@ struct ConvHKnobs {
   bool win_on = true;      // PASCO_CONV_WIN=0: no LDS-window kernel
   bool win_wide = false;   // PASCO_CONV_WIN=2: also on 128-wide tiles
   bool rl_on = true;       // PASCO_CONV_RL=0: ignore row lists (walk all offsets of one-pair maps)
-  bool win256 = false;     // PASCO_CONV_WIN256=1: 256-wide window workgroups for 256-channel layers (measured: 568 vs 547 us
-                           // for the gather kernel once its DMA is issued between the MFMAs)
   bool dma_on = true;      // PASCO_CONV_DMA=0: keep every launch on the register-staged k_conv_h2 (A/B comparisons)
   bool wide_on = true;     // PASCO_CONV_WIDE=0: no 256 x 256 tiles (conv_wide.hip) for the 256-output-channel gather launches
   ConvHKnobs() {
@@ -614,7 +612,6 @@ struct ConvHKnobs {
       win_wide = atoi(e) == 2;
     }
     if (const char *e = getenv("PASCO_CONV_RL")) rl_on = atoi(e) != 0;
-    if (const char *e = getenv("PASCO_CONV_WIN256")) win256 = atoi(e) != 0;
     if (const char *e = getenv("PASCO_CONVH_CFG")) has_cfg = sscanf(e, "%d,%d", &cfg_bm, &cfg_kc) >= 1;
     if (const char *e = getenv("PASCO_CONVH_KSPLIT")) {
       has_ksplit = true;
@@ -802,17 +799,16 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   // Measured (profiles/README.md, round 2): 64-wide tiles 638 -> 540 us on the 683 k-row map (two workgroups per CU);
   // 128-wide tiles lose to the gather kernel (one workgroup per CU: 668 vs 567 us) and stay there unless
   // PASCO_CONV_WIN=2.
-  // 256 output channels: ONE 128 x 256 window workgroup per row tile (8 waves of 64 x 64): window and weight bytes per
-  // MFMA are 0.3x of the gather kernel's, yet no faster (opt-in: PASCO_CONV_WIN256=1 and window tables from the caller)
-  const bool win256 = bn == 128 && d->cout == 256 && knobs.win256;
+  // (a 256-wide window workgroup for 256-channel layers was built and measured in round 2: 568 vs 547 us for the gather
+  // kernel - removed in round 5, profiles/README.md)
   if (pre && knobs.win_on && !env && d->kvol == 27 &&
-      (bn == 64 || win256 || (bn == 128 && (knobs.win_wide || (ph_win_force_bits() & 0x100)))) &&
+      (bn == 64 || (bn == 128 && (knobs.win_wide || (ph_win_force_bits() & 0x100)))) &&
       a.ksplit == 1 &&
       d->win_rows && d->win_cnt && d->win_slots && d->win_stats) {
     a.win_stats = d->win_stats;
     a.win_which = (bn == 64 ? 0 : 1) | ph_win_force_bits();
     a.win_gather = 0;
-    if (int rc = ph_conv_win_launch(a, win256 ? 256 : bn, st)) return rc;
+    if (int rc = ph_conv_win_launch(a, bn, st)) return rc;
     a.win_gather = 1;
     win_pair = true;
     if (bm != 128) bm = 128;   // pairs are only formed on big maps: the gather side keeps its 128-row tile

@@ -907,7 +907,7 @@ static int launch_win(const ConvArgsH &a, hipStream_t st) {
   return 0;
 }
 
-// Launches the window kernel (it returns at once on maps the predicate hands to the gather kernel).  bn: 64, 128 or 256.
+// Launches the window kernel (it returns at once on maps the predicate hands to the gather kernel).  bn: 64 or 128.
 int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st) {
   ConvArgsH b = a;
   b.ksplit = 1;
@@ -938,7 +938,5 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st) {
     return launch_win<4, 4, 1, 1, 2, WIN_MAX_64>(b, st);
   }
   b.win_which = 1 | ph_win_force_bits();
-  if (bn == 256)   // all 256 output channels in one workgroup: the window is DMA'd once per chunk for the whole layer width
-    return launch_win<8, 2, 4, 2, 2, WIN_MAX_128>(b, st);
   return launch_win<8, 2, 4, 2, 1, WIN_MAX_128>(b, st);
 }
