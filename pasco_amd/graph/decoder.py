@@ -121,15 +121,32 @@ class DecoderBlock(nn.Module):
         # children -> bounds prune -> features only for surviving children
         out_key = mgr.expand_pruned(x.coordinate_map_key, up.stride, lambda kids: inside_bounds(kids, global_min, global_max))
         nbr = mgr.kernel_map(x.coordinate_map_key, out_key, up.kernel_size, up.dilation, transposed=True)
-        dec = self._resize_absorbed(x, out_key, nbr)
-        if dec is None:
+        # `dec + shortcut` (decoder_v3.py:163) lists the rows of `dec` first: when the absorbed `resize` applies, its launch
+        # writes them straight into the union's feature tensor (round 5) - the up-sampled features are never copied (the
+        # finest level's copy was 2 x 175 MB per step); same values, same order of the additions
+        y_in = None
+        if self._resize_applies(x, out_key):
+            ukey, _, b2o = mgr.union(out_key, shortcut.coordinate_map_key)
+            n_un, n_dec = mgr.size(ukey), mgr.size(out_key)
+            buf = torch.empty((n_un, self.resize[1].out_channels), dtype=torch.float32, device=x.F.device)
+            dec = self._resize_absorbed(x, out_key, nbr, out=buf[:n_dec])
+            if dec is not None and dec.F.data_ptr() == buf.data_ptr():
+                if n_un > n_dec:
+                    buf[n_dec:].zero_()
+                mgr.backend().scatter_add_rows(shortcut.F.contiguous(), b2o.contiguous(), buf)
+                y_in = ME.SparseTensor(buf, coordinate_map_key=ukey, coordinate_manager=mgr)
+        else:
+            dec = None
+        if y_in is None and dec is None:
             dec = self.upsample(x, out_key=out_key, nbr=nbr)
             # coordinate channels (absolute coords / tensor stride) + BN + conv k1 with bias
             ts = dec.tensor_stride[0]
             feats = torch.cat([dec.F, dec.C[:, 1:].float() / ts], dim=1)
             dec = ME.SparseTensor(feats, coordinate_map_key=out_key, coordinate_manager=mgr)
             dec = fused.conv(dec, self.resize[1], pro_bn=self.resize[0], pro_act=ACT_NONE)
-        y = run_sequential(self.process, dec + shortcut)
+        if y_in is None:
+            y_in = dec + shortcut
+        y = run_sequential(self.process, y_in)
         logits = [fused.conv(y, self.completion_heads[str(i)][0]) for i in range(self.n_heads)]
         return y, logits
 
@@ -137,7 +154,17 @@ class DecoderBlock(nn.Module):
     # -- `resize` without the concatenation --------------------------------------------------------------------------
     RESIZE_LO, RESIZE_ROWS = -1024, 5120     # coordinate values the tables cover (a coordinate outside raises the status flag)
 
-    def _resize_absorbed(self, x, out_key, nbr):
+    def _resize_applies(self, x, out_key) -> bool:
+        """The conditions of the absorbed form (`_resize_absorbed`)."""
+        mgr = x.coordinate_manager
+        conv = self.resize[1]
+        c_in, c_out = conv.in_channels - 3, conv.out_channels
+        be = mgr.backend()
+        return bool(fused.fusion() and fused.conv_precision() == "f16x3" and fused._PRESPLIT and fused._kernel_device(x.F.device)
+                    and mgr.size(out_key) >= fused.MIN_ROWS_LINEAR and c_in % 32 == 0 and be.split_supported(c_in, c_out)
+                    and os.environ.get("PASCO_RESIZE_ABSORB", "1") != "0")
+
+    def _resize_absorbed(self, x, out_key, nbr, out=None):
         """upsample -> [features | coords / ts] -> BN -> 1x1 conv (decoder_v3.py:103,133) without forming the C + 3 channel
         tensor: BN has no activation behind it, so
             out = F (s_f * W_f) + (bias + b_f W_f) + sum_axis ((c_axis / ts) s_axis + b_axis) W_axis
@@ -150,9 +177,7 @@ class DecoderBlock(nn.Module):
         c_out = conv.out_channels
         c_in = conv.in_channels - 3
         be = mgr.backend()
-        if not (fused.fusion() and fused.conv_precision() == "f16x3" and fused._PRESPLIT and fused._kernel_device(x.F.device)
-                and n_out >= fused.MIN_ROWS_LINEAR and c_in % 32 == 0 and be.split_supported(c_in, c_out)
-                and os.environ.get("PASCO_RESIZE_ABSORB", "1") != "0"):
+        if not self._resize_applies(x, out_key):
             return None
         dec = self.upsample(x, out_key=out_key, nbr=nbr, emit_next=(None, ACT_NONE), split_only=True)
         if not isinstance(dec, fused.SplitRows):
@@ -179,7 +204,7 @@ class DecoderBlock(nn.Module):
         _, wf, bias, tab = hit
         coords = mgr.get_coordinates(out_key)
         out = fused.linear_rows(None, wf, bias, self, "resize", in_split=dec.split,
-                                axis=(tab, coords.contiguous(), self.RESIZE_LO))
+                                axis=(tab, coords.contiguous(), self.RESIZE_LO), out=out)
         return ME.SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
 
     def _resize_plain(self, dec, out_key):

@@ -226,7 +226,7 @@ def split_rows_2d(x2d: torch.Tensor):
 
 def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_owner, cache_key: str,
                 min_rows: Optional[int] = None, in_split=None, residual: Optional[torch.Tensor] = None,
-                emit: bool = False, want_out: bool = True, axis=None):
+                emit: bool = False, want_out: bool = True, axis=None, out: Optional[torch.Tensor] = None):
     """y = x @ weight.T + bias for a tall [N, cin] operand (`weight` is an nn.Linear-style [cout, cin] tensor
     or a row slice of one).  Large N on the GPU goes through the convolution kernel as an identity-map k=1
     convolution - the same split-precision MFMA GEMM with fused bias - instead of an fp32 library GEMM;
@@ -236,7 +236,8 @@ def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_o
     (the sine position encoding without materialising it).
     `x2d` may be None when `in_split` (its pre-split operand) is given.
     `emit`: also return the pre-split operand of y for a following linear_rows / batched_rows_matmul -> (y, y_split);
-    y_split is None when the split path did not apply, and with `want_out=False` y is None when it did."""
+    y_split is None when the split path did not apply, and with `want_out=False` y is None when it did.
+    `out` (optional, contiguous fp32 [N, cout]): the kernel path writes y there (a row slice of a larger tensor)."""
     cout, cin = weight.shape
     n = x2d.shape[0] if x2d is not None else in_split.shape[0]
     dev = x2d.device if x2d is not None else in_split.device
@@ -253,6 +254,9 @@ def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_o
         y = y if residual is None else y + residual
         if axis is not None:
             y = y + axis_rows(axis)
+        if out is not None:
+            out.copy_(y)
+            y = out
         return (y, None) if emit else y
     ver = (weight._version, weight.device, weight.data_ptr(), _PRESPLIT)
     hit = cache_owner.__dict__.get("_ph_lin_" + cache_key)
@@ -268,7 +272,7 @@ def linear_rows(x2d: Optional[torch.Tensor], weight: torch.Tensor, bias, cache_o
                       in_split=in_split if _PRESPLIT else None,
                       residual=None if residual is None else residual.contiguous(),
                       emit_split=(None, None, ACT_NONE) if do_emit else None, want_out=want_out or not do_emit,
-                      axis=axis)
+                      axis=axis, out=out)
     if not emit:
         return out
     return out if do_emit else (out, None)
