@@ -176,6 +176,7 @@ class CBackend:
                 f.restype = C.c_int
                 self.fn[name] = f
         self._ws: Dict[torch.device, torch.Tensor] = {}
+        self._status_ptrs: Dict[tuple, int] = {}         # (device type, index, stream handle) -> address of the status pair
         self._tls = threading.local()
         # tests may let a CPU checker library take the split-operand (mode 2) descriptors as well, so that the
         # host-side plumbing of that path (operand emission, split-only tensors) is exercised without a GPU
@@ -222,6 +223,8 @@ class CBackend:
                 and k[2] == handle and (dev is None or k[1] == dev)]
         for k in drop:
             del self._ws[k]
+        for k in [k for k in self._status_ptrs if k[2] == handle and (dev is None or k[1] == dev.index)]:
+            del self._status_ptrs[k]
         return len(drop)
 
     def workspace(self, n: int, device: torch.device) -> torch.Tensor:
@@ -279,12 +282,12 @@ class CBackend:
             if n_uniq is None:
                 n_uniq = rows2[2 * m4:]
             rc = self.fn["map_insert"](_ptr(coords), n, _ptr(tkeys), _ptr(tvals), cap, _ptr(row2uniq),
-                                       _ptr(uniq_rows), n_uniq.data_ptr(), _ptr(ws), ws.numel(), _ptr(self.status_word(dev)),
+                                       _ptr(uniq_rows), n_uniq.data_ptr(), _ptr(ws), ws.numel(), self.status_ptr(dev),
                                        self.stream(dev))
             self._check(rc, "map_insert")
             return tkeys, tvals, row2uniq[:n], uniq_rows, n_uniq
         rc = self.fn["map_insert"](_ptr(coords), n, _ptr(tkeys), _ptr(tvals), cap, None, None, None,
-                                   _ptr(ws), ws.numel(), _ptr(self.status_word(dev)), self.stream(dev))
+                                   _ptr(ws), ws.numel(), self.status_ptr(dev), self.stream(dev))
         self._check(rc, "map_insert")
         return tkeys, tvals, None, None, None
 
@@ -346,7 +349,7 @@ class CBackend:
         rl_out = torch.empty(cap, dtype=torch.int32, device=dev)
         tile_k = torch.empty(tcap, dtype=torch.int32, device=dev)
         rc = self.fn["rowlist_pack"](_ptr(pin), _ptr(pout), _ptr(counts), kvol, n_out, _ptr(rl_in), _ptr(rl_out), _ptr(tile_k),
-                                     cap, tcap, _ptr(self.status_word(dev)), self.stream(dev))
+                                     cap, tcap, self.status_ptr(dev), self.stream(dev))
         self._check(rc, "rowlist_pack")
         return {"in": rl_in, "out": rl_out, "tile_k": tile_k}
 
@@ -508,7 +511,7 @@ class CBackend:
                 d.mma_mode, d.w_f16_hi, d.w_f16_lo = 1, _ptr(w_hi), _ptr(w_lo)
             d.split_exp2 = SPLIT_ACT_EXP2
             d.w_unscale = float(unscale) * 2.0 ** (-SPLIT_ACT_EXP2)
-            d.status = _ptr(self.status_word(dev))
+            d.status = self.status_ptr(dev)
             if kvol > 1 or n_out * cout <= (1 << 23):
                 # scratch for a split over the kernel offsets: few-row layers split whole (up to 12 partial copies), big maps only
                 # their last partial round of row tiles (ph_conv_dma_try's tail split: slices x tail tiles <= the 512 resident
@@ -538,6 +541,22 @@ class CBackend:
         that can raise a flag of a scene and the read-and-clear of `check_status` are then ordered by the stream, so scenes
         in flight on other streams neither lose a flag nor see a foreign one."""
         return self._status_pair(device)[0:1]
+
+    def status_ptr(self, device) -> int:
+        """Address of `status_word(device)` - what the launches take.  ~260 calls per step: the address of a stream's pair is
+        looked up by (device index, raw stream handle) without building a torch.device, a key tuple or a one-element view."""
+        pinned = getattr(self._tls, "status_pin", None)
+        if pinned is not None:
+            return pinned.data_ptr()
+        idx = device.index
+        if idx is None and device.type == "cuda":
+            idx = torch.cuda.current_device()
+        k = (device.type, idx, _raw_stream(idx) if device.type == "cuda" else 0)
+        hit = self._status_ptrs.get(k)
+        if hit is None:
+            hit = self._status_pair(device).data_ptr()
+            self._status_ptrs[k] = hit
+        return hit
 
     def optimistic_word(self, device) -> torch.Tensor:
         """Second word of the stream's status pair: kernels and torch ops OR a non-zero value into it when an OPTIMISTIC
@@ -646,7 +665,7 @@ class CBackend:
                 if t.numel() != c:
                     raise ValueError(f"split_rows: {name} has {t.numel()} entries, expected {c}")
         rc = self.fn["split_rows"](_ptr(x), n, c, _ptr(pro_scale), _ptr(pro_shift), pro_act, float(slope), exp2, _ptr(out),
-                                   _ptr(self.status_word(x.device)), self.stream(x.device))
+                                   self.status_ptr(x.device), self.stream(x.device))
         self._check(rc, "split_rows")
         return out
 
@@ -729,7 +748,7 @@ class CBackend:
         hlo, hdim = (_i32 * 3)(*lo), (_i32 * 3)(*dims)
         hst = (_i64 * (m + 1))(*[int(v) for v in starts])
         flags = torch.zeros(nsites, dtype=torch.uint8, device=dev)
-        status = _ptr(self.status_word(dev))
+        status = self.status_ptr(dev)
         self._check(self.fn["points_mark"](_ptr(xyz), n, C.cast(hlo, _vp), C.cast(hdim, _vp), _ptr(flags), status, st),
                     "points_mark")
         sites = torch.empty(min(n, nsites), dtype=torch.int32, device=dev)
@@ -1016,7 +1035,7 @@ class CBackend:
             ws = torch.empty(need, dtype=torch.uint8, device=q.device)
             self._ws[key] = ws
         rc = self.fn["attn_cross_split"](_ptr(q), _ptr(k_split), _ptr(v_split), exp2, _ptr(bits), _ptr(any_), _ptr(out),
-                                         n, b, h, qn, dh, _ptr(ws), ws.numel(), _ptr(self.status_word(q.device)),
+                                         n, b, h, qn, dh, _ptr(ws), ws.numel(), self.status_ptr(q.device),
                                          self.stream(q.device))
         self._check(rc, "attn_cross_split")
         return out
@@ -1034,7 +1053,7 @@ class CBackend:
         assert coords.shape[1] == 4
         out = torch.empty((n, self.POS_AUG_COLS), dtype=torch.float16, device=coords.device)
         rc = self.fn["pos_aug"](_ptr(coords), n, _ptr(eps), int(tab_lo), eps.numel(), exp2, _ptr(out),
-                                _ptr(self.status_word(coords.device)), self.stream(coords.device))
+                                self.status_ptr(coords.device), self.stream(coords.device))
         self._check(rc, "pos_aug")
         return out
 
@@ -1058,7 +1077,7 @@ class CBackend:
             ws = torch.empty(need, dtype=torch.uint8, device=q2.device)
             self._ws[key] = ws
         rc = self.fn["attn_cross_feat"](_ptr(q2), _ptr(x_split), _ptr(aug), c, exp2, _ptr(bits), _ptr(any_), _ptr(out), n, b, h,
-                                        qn, _ptr(ws), ws.numel(), _ptr(self.status_word(q2.device)), self.stream(q2.device))
+                                        qn, _ptr(ws), ws.numel(), self.status_ptr(q2.device), self.stream(q2.device))
         self._check(rc, "attn_cross_feat")
         return out
 
