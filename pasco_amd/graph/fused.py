@@ -383,10 +383,11 @@ def fold_bn(bn) -> Tuple[torch.Tensor, torch.Tensor]:
     m = bn.bn if isinstance(bn, MinkowskiBatchNorm) else bn
     assert isinstance(m, nn.modules.batchnorm._BatchNorm)
     assert not m.training, "fused graph serves inference (module.eval()) only"
-    ver = (m.running_mean._version, m.running_var._version,
-           m.weight._version if m.weight is not None else -1,
-           m.bias._version if m.bias is not None else -1, m.running_mean.device)
-    hit = getattr(m, "_ph_folded", None)
+    # ~90 calls per step: the tensors straight from the module's dictionaries (nn.Module.__getattr__ costs ~1 us a name)
+    bufs, pars = m._buffers, m._parameters
+    rm, rv, w, b = bufs["running_mean"], bufs["running_var"], pars.get("weight"), pars.get("bias")
+    ver = (rm._version, rv._version, w._version if w is not None else -1, b._version if b is not None else -1, rm.device)
+    hit = m.__dict__.get("_ph_folded")
     if hit is not None and hit[0] == ver:
         return hit[1], hit[2]
     with torch.no_grad():
