@@ -242,3 +242,34 @@ def test_scenes_in_flight_match_one_at_a_time(hip, n_flight):
         assert len(got[j]) == len(ref[j])
         for a, b in zip(got[j], ref[j]):
             assert a.shape == b.shape and torch.equal(a, b)
+
+
+def test_scene_server_close_restores_what_it_changed(hip):
+    """`SceneServer` changes the interpreter's switch interval and keys workspaces, status pairs and query-side
+    hipGraphs by its worker streams; `close()` puts the interval back and drops exactly those entries."""
+    import sys
+    from pasco_amd.graph import PascoNet
+    from pasco_amd.graph.serve import SceneServer
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(5)
+    net = PascoNet(n_classes=20, n_infers=2, in_channels=16, f=16, num_queries=12, heavy_decoder=False).eval().to(dev)
+    sc = make_scene(7, n_infers=2, in_channels=16, grid=(40, 40, 8), occupancy=0.12).to(dev)
+    tk = TeacherKeep(sc, dev)
+
+    def step(_):
+        x = net.prepare_input(sc.in_feats, sc.in_coords)
+        return net(x, sc.global_min_Cs, sc.global_max_Cs, sc.min_Cs, sc.max_Cs, keep_override=tk)
+
+    before = sys.getswitchinterval()
+    server = SceneServer(dev, step, in_flight=2, switch_interval_ms=0.5, allocator_rounding=None)
+    assert abs(sys.getswitchinterval() - 0.5e-3) < 1e-9
+    server.run([0, 1, 2, 3])
+    handles = {int(s.cuda_stream) for s in server.streams}
+    graphs = net.transformer_predictor.__dict__.get("_qgraphs", {})
+    assert any(k[-1] in handles for k in graphs) or net.transformer_predictor.query_graph_state() != "graph"
+    assert any(k[2] in handles for k in hip._status_ptrs), "the workers' status pairs are cached by stream handle"
+    server.close()
+    assert sys.getswitchinterval() == before
+    assert not any(k[-1] in handles for k in net.transformer_predictor.__dict__.get("_qgraphs", {}))
+    assert not any(k[2] in handles for k in hip._status_ptrs)
+    assert not any(isinstance(k, tuple) and len(k) == 3 and k[2] in handles for k in hip._ws)
