@@ -332,7 +332,9 @@ def site_sharded_ensemble(net, ret, Ts, group=None):
     the subnets this rank owns, `shard_indices(M, rank, W)` in order).  -> (sem_prob_denses, sharded, stats): `sharded` =
     one dict per output (the M subnets, then the ensemble): {"sites" int32 [n] canonical site ids of this rank's kept rows,
     "voxel_probs" [n, Q'], "sem_probs" [n, C], "query_probs"}; rows of rank 0, 1, ... concatenated are the single-process
-    `Ensembler.ensemble_panop` outputs (`gather_sharded` does that)."""
+    `Ensembler.ensemble_panop` outputs (`gather_sharded` does that).
+    One scene at a time per process: the receive arena is persistent and shared by successive calls (config C4 issues its
+    collectives from one thread, `bench.py --mode subnet-heads` sets `in_flight` to 1)."""
     import torch.nn.functional as F
     from ..me.backend import backend_for
     from . import ensemble as E
