@@ -387,16 +387,18 @@ def allocator_state(device):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False, heavy=False):
+def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False, heavy=False, me_conv="guarded"):
     """Short timed row of another BASELINE.json configuration on this GPU (1 warm-up + `steps` scenes)."""
     from pasco_amd.graph import fused
     from pasco_amd.graph.synth import make_scene, TeacherKeep
     net = build_net(n_infers, in_channels, device, n_classes=n_classes, heavy=heavy)
     scene = make_scene(seed=0, n_infers=n_infers, in_channels=in_channels).to(device)
     teacher = TeacherKeep(scene, device)
-    if unfused:                 # INTEGRATION.md route (a): reference-style module sequence, exact fp32 products
+    if unfused:                 # INTEGRATION.md route (a): reference-style module sequence on the plain pasco_amd.me modules
+        from pasco_amd.me import modules as me_modules
         fused.set_fusion(False)
         fused.set_conv_precision("f32")
+        me_modules.set_me_conv(me_conv)     # "guarded": split-precision kernels + exact fp32 device-side fallback (default)
     try:
         with torch.no_grad():
             run_scene(net, scene, teacher)
@@ -410,6 +412,7 @@ def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False, 
         if unfused:
             fused.set_fusion(True)
             fused.set_conv_precision("f16x3")
+            me_modules.set_me_conv("guarded")
     row = {"scenes_per_s": round(1.0 / dt, 3), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": 1,
            "allocator": allocator_state(device)}
     redone = {k: int(getattr(net, k, 0)) for k in ("range_fallbacks", "input_fallbacks", "optimistic_fallbacks") if getattr(net, k, 0)}
@@ -778,7 +781,9 @@ def main():
                              ("mimo8_one_gpu", dict(n_infers=8, in_channels=283, n_classes=20)),
                              # SURVEY.md 8(d) "second row": the logged run's decoder depth (hparams.yaml heavy_decoder: true)
                              ("mimo3_heavy_decoder", dict(n_infers=3, in_channels=283, n_classes=20, heavy=True)),
-                             ("mimo1_unfused_me_modules", dict(n_infers=1, in_channels=283, n_classes=20, unfused=True))):
+                             ("mimo1_unfused_me_modules", dict(n_infers=1, in_channels=283, n_classes=20, unfused=True)),
+                             ("mimo1_unfused_me_modules_exact", dict(n_infers=1, in_channels=283, n_classes=20, unfused=True,
+                                                                     me_conv="exact"))):
                 try:
                     rows[name] = short_row(device=device, **kw)
                 except Exception as e:  # a side row must never take the headline down

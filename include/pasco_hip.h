@@ -213,6 +213,12 @@ typedef struct ph_conv_desc {
   const int32_t *rl_in, *rl_out, *rl_tile_k;
   int64_t rl_rows;
   int32_t rl_tiles;       /* entries of rl_tile_k (an upper bound of the used tiles) */
+  /* mode 0 only, optional: a device word that GUARDS the launch - it does its work only when (*exact_if & 1) != 0 and
+   * returns at once otherwise.  The guarded form of the split path, no host read: ph_split_rows and the mode-2 launch get
+   * `status` = this word (bit 0 = an operand left the f16 range), then the same convolution is launched in mode 0 with
+   * exact_if = this word and the same `out`: the exact fp32 result replaces the split one exactly when it has to.  What
+   * the plain MinkowskiConvolution modules of pasco_amd.me do (round 5). */
+  const int32_t *exact_if;
 } ph_conv_desc;
 
 int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);

@@ -325,6 +325,7 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   if (!d) return fail("conv_fwd: null desc");
   if (d->cin <= 0 || d->cout <= 0 || d->kvol < 1 || d->kvol > 4096) return fail("conv_fwd: bad shape");
   if (d->n_out == 0) return 0;
+  if (d->mma_mode == 0 && d->exact_if && (*d->exact_if & 1) == 0) return 0;   /* guarded launch: nothing to redo */
   /* mma_mode 0 / 1: plain fp32 on in / weight (how the device forms the products does not change the values
    * beyond rounding).  mma_mode 2 follows the device's data flow (include/pasco_hip.h): the operands are
    * in_split / w_split, read back as hi + lo, with the prologue already inside in_split; in / weight may be NULL. */

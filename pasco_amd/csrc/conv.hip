@@ -40,6 +40,7 @@ struct ConvArgs {
   int epi_act, res_act;
   float slope;
   int n_row_tiles, n_col_tiles;
+  const int32_t *pred;     // ph_conv_desc.exact_if: work only when (*pred & 1) != 0
 };
 
 // activations: neg = 1 (none), 0 (ReLU), slope (leaky); NaN-preserving select (ph_common.h)
@@ -72,6 +73,8 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
 
   __shared__ __attribute__((aligned(16))) float As[BM * A_LD];
   __shared__ __attribute__((aligned(16))) float Bs[BKC * B_LD];
+
+  if (a.pred != nullptr && (*a.pred & 1) == 0) return;      // guarded launch (ph_conv_desc.exact_if): nothing to redo
 
   // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of
   // tiles so that neighbouring row tiles (shared gathered rows) meet in one L2.
@@ -380,6 +383,7 @@ extern "C" int ph_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   a.res_act = d->res_act;
   a.slope = d->epi_slope;
   a.n_row_tiles = a.n_col_tiles = 0;
+  a.pred = d->exact_if;
   hipStream_t st = ph_stream(stream);
   int bm = 128;
   const int bn = pick_cfg(a, &bm);

@@ -69,6 +69,7 @@ class ConvDesc(C.Structure):
         ("win_rows", _vp), ("win_cnt", _vp), ("win_slots", _vp), ("win_stats", _vp),
         ("axis_table", _vp), ("axis_coords", _vp), ("axis_lo", _i32), ("axis_rows", _i32),
         ("rl_in", _vp), ("rl_out", _vp), ("rl_tile_k", _vp), ("rl_rows", _i64), ("rl_tiles", _i32),
+        ("exact_if", _vp),
     ]
 
 
@@ -400,7 +401,8 @@ class CBackend:
                  epi2_scale=None, epi2_shift=None, split=None, in_split: Optional[torch.Tensor] = None,
                  emit_split=None, want_out: bool = True,
                  out: Optional[torch.Tensor] = None, win=None, in_split_has_prologue: bool = False, axis=None,
-                 rowlist=None, out_split: Optional[torch.Tensor] = None):
+                 rowlist=None, out_split: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None,
+                 exact_if: Optional[torch.Tensor] = None):
         """out = epilogue(sum_k gather(prologue(x))[k] @ W[k]) - one `ph_conv_fwd` launch (include/pasco_hip.h).
 
         `split` selects the split-precision products: (w_hi, w_lo, unscale) from `split_weight_f16` = mode 1
@@ -413,7 +415,10 @@ class CBackend:
         `win` = `win_build(nbr)` (3x3x3 maps, mode 2): lets the library serve the launch from LDS-resident input windows
         where the map is local enough (decided on the device).
         `axis` = (table fp32 [3, T, cout], coords int32 [n_out, 4], lo) (mode 2): the per-axis table residual
-        table[0][x - lo] + table[1][y - lo] + table[2][z - lo] is added where `residual` is added."""
+        table[0][x - lo] + table[1][y - lo] + table[2][z - lo] is added where `residual` is added.
+        `status` (int32 [1] device word): the launch reports its flags there instead of into the stream's status pair;
+        `exact_if` (exact fp32 launches only): the launch does its work only when bit 0 of that word is set - the guarded
+        form of the split path (include/pasco_hip.h ph_conv_desc.exact_if; `pasco_amd.me.modules`)."""
         if x is None:          # rows that exist only as a pre-split operand (mode 2): `xshape` = (n_in, cin)
             if xshape is None or in_split is None or split is None or len(split) != 2 or not self.split_capable():
                 raise ValueError("conv: x=None needs xshape, in_split and a mode-2 split on the device backend")
@@ -515,7 +520,7 @@ class CBackend:
                 d.mma_mode, d.w_f16_hi, d.w_f16_lo = 1, _ptr(w_hi), _ptr(w_lo)
             d.split_exp2 = SPLIT_ACT_EXP2
             d.w_unscale = float(unscale) * 2.0 ** (-SPLIT_ACT_EXP2)
-            d.status = self.status_ptr(dev)
+            d.status = self.status_ptr(dev) if status is None else status.data_ptr()
             if kvol > 1 or n_out * cout <= (1 << 23):
                 # scratch for a split over the kernel offsets: few-row layers split whole (up to 12 partial copies), big maps only
                 # their last partial round of row tiles (ph_conv_dma_try's tail split: slices x tail tiles <= the 512 resident
@@ -527,6 +532,10 @@ class CBackend:
                     sk = torch.empty(need, dtype=torch.uint8, device=dev)
                     self._ws[key] = sk
                 d.splitk_ws, d.splitk_ws_bytes = _ptr(sk), sk.numel()
+        if exact_if is not None:
+            if split is not None:
+                raise ValueError("conv: exact_if guards an exact fp32 launch (no split)")
+            d.exact_if = exact_if.data_ptr()
         rc = self.fn["conv_fwd"](C.byref(d), self.stream(dev))
         self._check(rc, "conv_fwd")
         return (out, out_split) if emit else out
@@ -651,7 +660,8 @@ class CBackend:
         return hi.contiguous(), lo.contiguous(), float(2.0 ** (-e))
 
     def split_rows(self, x: torch.Tensor, *, pro_scale=None, pro_shift=None, pro_act=ACT_NONE, slope=0.01,
-                   out: Optional[torch.Tensor] = None, exp2: Optional[int] = None) -> torch.Tensor:
+                   out: Optional[torch.Tensor] = None, exp2: Optional[int] = None,
+                   status: Optional[torch.Tensor] = None) -> torch.Tensor:
         """fp32 rows [n, c] -> f16 [n, cpad/32, 2, 32] (hi | lo groups) of act(x * scale + shift) * 2^exp2: the
         operand layout of mma_mode 2 (include/pasco_hip.h ph_split_rows).  exp2 defaults to SPLIT_ACT_EXP2 (an
         activation operand, what `conv_fwd` expects as `in_split`); pre-scaled weights pass 0."""
@@ -669,7 +679,7 @@ class CBackend:
                 if t.numel() != c:
                     raise ValueError(f"split_rows: {name} has {t.numel()} entries, expected {c}")
         rc = self.fn["split_rows"](_ptr(x), n, c, _ptr(pro_scale), _ptr(pro_shift), pro_act, float(slope), exp2, _ptr(out),
-                                   self.status_ptr(x.device), self.stream(x.device))
+                                   self.status_ptr(x.device) if status is None else status.data_ptr(), self.stream(x.device))
         self._check(rc, "split_rows")
         return out
 

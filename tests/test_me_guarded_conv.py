@@ -1,0 +1,92 @@
+"""The plain `pasco_amd.me` convolution modules (the literal drop-in route: reference code on `import pasco_amd.me as ME`)
+run their products on the split-precision kernels GUARDED by a device-side predicate: the operand split reports an f16 range
+overflow into a word of the call, the exact fp32 kernel is launched behind the split one with that word as its predicate
+(`ph_conv_desc.exact_if`) - exact results whenever the range is left, no host read, nothing for the caller to check."""
+import pytest
+import torch
+
+import pasco_amd.me as ME
+from pasco_amd.me import modules as M
+
+
+def _scene(n=4000, extent=(24, 24, 10), c=64, seed=0, big=None):
+    g = torch.Generator().manual_seed(seed)
+    X, Y, Z = extent
+    site = torch.randperm(X * Y * Z, generator=g)[:n]
+    coords = torch.stack([torch.zeros_like(site), site // (Y * Z), (site // Z) % Y, site % Z], 1).int()
+    feats = torch.randn(n, c, generator=g)
+    if big is not None:
+        feats[17, 3] = big                       # one activation beyond the f16 range of the scaled operand (|x| > 2047)
+    return coords, feats
+
+
+def _run(device, big, mode):
+    torch.manual_seed(3)
+    conv = ME.MinkowskiConvolution(64, 64, kernel_size=3, bias=True, dimension=3).to(device).eval()
+    coords, feats = _scene(big=big)
+    x = ME.SparseTensor(feats.to(device), coords.to(device))
+    M.set_me_conv(mode)
+    try:
+        with torch.no_grad():
+            return conv(x).F.cpu()
+    finally:
+        M.set_me_conv("guarded")
+
+
+def _check(device, be):
+    exact = _run(device, None, "exact")
+    guarded = _run(device, None, "guarded")
+    scale = float(exact.abs().mean())
+    assert float((guarded - exact).abs().max()) <= 2e-5 * scale            # split precision: fp32-class, not bit-equal
+    assert not torch.equal(guarded, exact) or device == "cpu"              # i.e. the split kernel did the work
+    # an activation outside the range: the guard fires and the exact kernel's result is what comes back, bit for bit
+    exact_big = _run(device, 5000.0, "exact")
+    guarded_big = _run(device, 5000.0, "guarded")
+    assert torch.isfinite(guarded_big).all() and torch.equal(guarded_big, exact_big)
+    be.check_status(torch.device(device))                                  # and the stream's own status pair stayed clean
+
+
+def test_guarded_module_conv_on_the_checker(oracle_registered):
+    oracle_registered.checker_split = True
+    try:
+        _check("cpu", oracle_registered)
+    finally:
+        oracle_registered.checker_split = False
+
+
+def test_exact_if_guards_an_exact_launch(oracle):
+    coords, feats = _scene(n=500, c=16)
+    tk, tv, _, uq, nu = oracle.map_insert(coords.contiguous())
+    from pasco_amd.me.core import kernel_offsets
+    nbr = oracle.nbr_build(coords, tk, tv, kernel_offsets(3, 1))
+    w = torch.randn(27, 16, 8, generator=torch.Generator().manual_seed(1))
+    out = torch.full((500, 8), 7.0)
+    flag = torch.zeros(1, dtype=torch.int32)
+    oracle.conv_fwd(feats, w, nbr, 500, out=out, exact_if=flag)
+    assert bool((out == 7.0).all()), "flag clear: the guarded launch must not touch the output"
+    flag.fill_(1)
+    oracle.conv_fwd(feats, w, nbr, 500, out=out, exact_if=flag)
+    assert torch.equal(out, oracle.conv_fwd(feats, w, nbr, 500))
+    with pytest.raises(ValueError):
+        oracle.conv_fwd(feats, w, nbr, 500, exact_if=flag, split=(w, 1.0))
+
+
+@pytest.mark.gpu
+def test_guarded_module_conv_on_the_gpu(hip):
+    _check("cuda", hip)
+
+
+@pytest.mark.gpu
+def test_exact_if_guards_an_exact_launch_gpu(hip):
+    coords, feats = _scene(n=20000, c=64, extent=(48, 48, 16))
+    x = ME.SparseTensor(feats.cuda(), coords.cuda())
+    mgr = x.coordinate_manager
+    nbr = mgr.kernel_map(x.coordinate_map_key, x.coordinate_map_key, 3)
+    w = torch.randn(27, 64, 64, generator=torch.Generator().manual_seed(1)).cuda() * 0.05
+    out = torch.full((20000, 64), 7.0, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hip.conv_fwd(x.F, w, nbr, 20000, out=out, exact_if=flag)
+    assert bool((out == 7.0).all())
+    flag.fill_(1)
+    hip.conv_fwd(x.F, w, nbr, 20000, out=out, exact_if=flag)
+    assert torch.equal(out, hip.conv_fwd(x.F, w, nbr, 20000))
