@@ -144,7 +144,7 @@ def _conv_unfused(x, mod, pro_bn, pro_act, epi_bn, epi_act, epi2_bn, residual, r
         out_key = y.coordinate_map_key
         F = y.F
     else:                               # the caller fixed the output map (pruned generative expansion)
-        F = mod.conv_rows(mgr.backend(), y.F, nbr, mgr.size(out_key))      # the module's own (guarded) launches
+        F = mod.conv_rows(mgr.backend(), y.F, nbr, mgr.size(out_key), mgr=mgr)      # the module's own (guarded) launches
     bn_rows = lambda bn, t: (bn.bn if isinstance(bn, MinkowskiBatchNorm) else bn)(t)
     if epi_bn is not None:
         F = bn_rows(epi_bn, F)

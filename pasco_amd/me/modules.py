@@ -26,6 +26,7 @@ def _kvol(kernel_size) -> int:
 
 
 _ME_CONV = os.environ.get("PASCO_ME_CONV", "guarded")
+ME_MIN_ROWS_WINDOWS = 16384     # 3x3x3 maps with at least this many rows get window tables (as pasco_amd.graph.fused does)
 
 
 def set_me_conv(mode: str) -> None:
@@ -90,10 +91,10 @@ class _ConvBase(MinkowskiModuleBase):
         assert coordinates is None, "explicit output coordinates are not served"
         out_key, nbr = self._maps(x)
         mgr = x.coordinate_manager
-        out = self.conv_rows(mgr.backend(), x.F, nbr, mgr.size(out_key))
+        out = self.conv_rows(mgr.backend(), x.F, nbr, mgr.size(out_key), mgr=mgr)
         return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
 
-    def conv_rows(self, be, feats: torch.Tensor, nbr, n_out: int) -> torch.Tensor:
+    def conv_rows(self, be, feats: torch.Tensor, nbr, n_out: int, mgr=None) -> torch.Tensor:
         """The module's own launch(es): exact fp32 results, as upstream's.  Where the split-precision kernels apply (GPU,
         cin % 8 == 0) the products run on them GUARDED: the operand split reports an f16 range overflow (|x| > 2047) into a
         word of this call, and the exact fp32 kernel is launched behind the split one with that word as its predicate
@@ -117,7 +118,11 @@ class _ConvBase(MinkowskiModuleBase):
             self.__dict__["_ph_me_split"] = hit
         flag = torch.zeros(1, dtype=torch.int32, device=feats.device)
         xs = be.split_rows(feats, status=flag)
-        out = be.conv_fwd(feats, kernel, nbr, n_out, bias=bias, split=hit[1], in_split=xs, status=flag)
+        win = None
+        if mgr is not None and nbr is not None and nbr.shape[0] == 27 and 33 <= self.out_channels <= 64 and \
+                n_out >= ME_MIN_ROWS_WINDOWS and be.device_type == "cuda":
+            win = mgr.kernel_windows(nbr)       # LDS-window tables of the map (cached by the manager): k_conv_wop
+        out = be.conv_fwd(feats, kernel, nbr, n_out, bias=bias, split=hit[1], in_split=xs, status=flag, win=win)
         be.conv_fwd(feats, kernel, nbr, n_out, bias=bias, out=out, exact_if=flag)
         return out
 

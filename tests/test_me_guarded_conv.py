@@ -20,10 +20,10 @@ def _scene(n=4000, extent=(24, 24, 10), c=64, seed=0, big=None):
     return coords, feats
 
 
-def _run(device, big, mode):
+def _run(device, big, mode, n=4000, extent=(24, 24, 10)):
     torch.manual_seed(3)
     conv = ME.MinkowskiConvolution(64, 64, kernel_size=3, bias=True, dimension=3).to(device).eval()
-    coords, feats = _scene(big=big)
+    coords, feats = _scene(n=n, extent=extent, big=big)
     x = ME.SparseTensor(feats.to(device), coords.to(device))
     M.set_me_conv(mode)
     try:
@@ -33,15 +33,15 @@ def _run(device, big, mode):
         M.set_me_conv("guarded")
 
 
-def _check(device, be):
-    exact = _run(device, None, "exact")
-    guarded = _run(device, None, "guarded")
+def _check(device, be, **kw):
+    exact = _run(device, None, "exact", **kw)
+    guarded = _run(device, None, "guarded", **kw)
     scale = float(exact.abs().mean())
     assert float((guarded - exact).abs().max()) <= 2e-5 * scale            # split precision: fp32-class, not bit-equal
     assert not torch.equal(guarded, exact) or device == "cpu"              # i.e. the split kernel did the work
     # an activation outside the range: the guard fires and the exact kernel's result is what comes back, bit for bit
-    exact_big = _run(device, 5000.0, "exact")
-    guarded_big = _run(device, 5000.0, "guarded")
+    exact_big = _run(device, 5000.0, "exact", **kw)
+    guarded_big = _run(device, 5000.0, "guarded", **kw)
     assert torch.isfinite(guarded_big).all() and torch.equal(guarded_big, exact_big)
     be.check_status(torch.device(device))                                  # and the stream's own status pair stayed clean
 
@@ -74,6 +74,7 @@ def test_exact_if_guards_an_exact_launch(oracle):
 @pytest.mark.gpu
 def test_guarded_module_conv_on_the_gpu(hip):
     _check("cuda", hip)
+    _check("cuda", hip, n=60000, extent=(96, 96, 16))       # >= 16 384 rows: window tables, the k_conv_wop / gather pair
 
 
 @pytest.mark.gpu
