@@ -130,31 +130,40 @@ def _act_rows(F: torch.Tensor, act: int, slope: float) -> torch.Tensor:
     return F
 
 
+def _module_act(y: SparseTensor, act: int, slope: float) -> SparseTensor:
+    """What a MinkowskiReLU / MinkowskiLeakyReLU module in the reference's trees does with `y` (pasco_amd.me.modules: recorded on
+    the returned tensor in inference, applied by the next convolution's prologue or on first read)."""
+    if act == ACT_NONE:
+        return y
+    from ..me.modules import MinkowskiLeakyReLU, MinkowskiReLU
+    mod = MinkowskiReLU() if act == ACT_RELU else MinkowskiLeakyReLU(slope)
+    return mod(y)
+
+
 def _conv_unfused(x, mod, pro_bn, pro_act, epi_bn, epi_act, epi2_bn, residual, res_act, slope, out_key, nbr):
-    """The module-by-module sequence (route (a)): BN -> act -> conv (+ bias) -> BN -> act -> BN -> (+ residual) -> act."""
+    """The module-by-module sequence (route (a)): BN -> act -> conv (+ bias) -> BN -> act -> BN -> (+ residual) -> act, every
+    step through the plain pasco_amd.me modules, as the reference's trees call them."""
     mgr = x.coordinate_manager
+    same = lambda t, feats: SparseTensor(feats, coordinate_map_key=t.coordinate_map_key, coordinate_manager=mgr)
+    bn_of = lambda bn, t: bn(t) if isinstance(bn, MinkowskiBatchNorm) else same(t, bn(t.F))
     y = x
     if pro_bn is not None:
-        y = pro_bn(y) if isinstance(pro_bn, MinkowskiBatchNorm) else SparseTensor(
-            pro_bn(y.F), coordinate_map_key=y.coordinate_map_key, coordinate_manager=mgr)
-    if pro_act != ACT_NONE:
-        y = SparseTensor(_act_rows(y.F, pro_act, slope), coordinate_map_key=y.coordinate_map_key, coordinate_manager=mgr)
+        y = bn_of(pro_bn, y)
+    y = _module_act(y, pro_act, slope)
     if out_key is None:
-        y = mod(y)                      # MinkowskiConvolution.forward: its own maps, plain launch
-        out_key = y.coordinate_map_key
-        F = y.F
+        y = mod(y)                      # MinkowskiConvolution.forward: its own maps, its own (guarded) launches
     else:                               # the caller fixed the output map (pruned generative expansion)
-        F = mod.conv_rows(mgr.backend(), y.F, nbr, mgr.size(out_key), mgr=mgr)      # the module's own (guarded) launches
-    bn_rows = lambda bn, t: (bn.bn if isinstance(bn, MinkowskiBatchNorm) else bn)(t)
+        raw, pending = y.take_prologue()
+        y = SparseTensor(mod.conv_rows(mgr.backend(), raw, nbr, mgr.size(out_key), mgr=mgr, prologue=pending),
+                         coordinate_map_key=out_key, coordinate_manager=mgr)
     if epi_bn is not None:
-        F = bn_rows(epi_bn, F)
-    F = _act_rows(F, epi_act, slope)
+        y = bn_of(epi_bn, y)
+    y = _module_act(y, epi_act, slope)
     if epi2_bn is not None:
-        F = bn_rows(epi2_bn, F)
+        y = bn_of(epi2_bn, y)
     if residual is not None:
-        F = F + residual
-    F = _act_rows(F, res_act, slope)
-    return SparseTensor(F, coordinate_map_key=out_key, coordinate_manager=mgr)
+        y = same(y, y.F + residual)
+    return _module_act(y, res_act, slope)
 
 
 def publish(t):

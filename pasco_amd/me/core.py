@@ -394,17 +394,50 @@ class SparseTensor:
             self.unique_index = None
             self.inverse_mapping = None
         self._F = features
+        self._pending = None       # (scale | None, shift | None, act, slope): F stands for act(_F * scale + shift), see `deferred`
         self._manager = coordinate_manager
         self.coordinate_map_key = coordinate_map_key
+
+    # -- deferred element-wise operations (round 5) --------------------------------------------------
+    # The plain modules of pasco_amd.me (the literal drop-in route) would run every MinkowskiBatchNorm / MinkowskiReLU as its
+    # own pass over [N, C]; in eval mode they only RECORD the affine / activation on the tensor they return, and the next
+    # MinkowskiConvolution applies it in its operand prologue (ph_split_rows / ph_conv_fwd pro_*).  Anything else that looks at
+    # the values (`.F`, arithmetic, pruning, `.dense()`, ...) materialises them first, once: nothing observable changes.
+    @classmethod
+    def deferred(cls, src: "SparseTensor", scale, shift, act: int, slope: float) -> "SparseTensor":
+        """A tensor on src's map whose features are act(src_raw * scale + shift), not yet computed."""
+        assert src._pending is None
+        out = cls(src._F, coordinate_map_key=src.coordinate_map_key, coordinate_manager=src._manager)
+        out._pending = (scale, shift, int(act), float(slope))
+        return out
+
+    def _materialise(self) -> None:
+        scale, shift, act, slope = self._pending
+        y = self._F
+        if scale is not None:
+            y = y * scale
+        if shift is not None:
+            y = y + shift
+        if act == 1:
+            y = torch.relu(y)
+        elif act == 2:
+            y = torch.nn.functional.leaky_relu(y, slope)
+        self._F, self._pending = y, None
+
+    def take_prologue(self):
+        """-> (raw features, (scale, shift, act, slope) | None) for a consumer that applies the pending operations itself."""
+        return self._F, self._pending
 
     # -- attributes --------------------------------------------------------------------------------
     @property
     def F(self) -> torch.Tensor:
+        if self._pending is not None:
+            self._materialise()
         return self._F
 
     @property
     def features(self) -> torch.Tensor:
-        return self._F
+        return self.F
 
     @property
     def C(self) -> torch.Tensor:
@@ -451,11 +484,11 @@ class SparseTensor:
     # -- arithmetic --------------------------------------------------------------------------------
     def _binary(self, other, fn_same, is_add: bool):
         if not isinstance(other, SparseTensor):
-            return SparseTensor(fn_same(self._F, other), coordinate_map_key=self.coordinate_map_key,
+            return SparseTensor(fn_same(self.F, other), coordinate_map_key=self.coordinate_map_key,
                                 coordinate_manager=self._manager)
         assert other._manager is self._manager, "binary ops need tensors of the same coordinate manager"
         if other.coordinate_map_key == self.coordinate_map_key:
-            return SparseTensor(fn_same(self._F, other._F), coordinate_map_key=self.coordinate_map_key,
+            return SparseTensor(fn_same(self.F, other.F), coordinate_map_key=self.coordinate_map_key,
                                 coordinate_manager=self._manager)
         assert is_add, "only + is served across different coordinate maps"
         assert self._F.shape[1] == other._F.shape[1], "channel mismatch in union add"
@@ -466,10 +499,10 @@ class SparseTensor:
         # occurrence): the lhs features are a plain copy into the leading rows, only the rhs rows are scattered
         na = self._F.shape[0]
         out = torch.empty((n_out, self._F.shape[1]), dtype=self._F.dtype, device=self._F.device)
-        out[:na].copy_(self._F)
+        out[:na].copy_(self.F)
         if n_out > na:
             out[na:].zero_()
-        be.scatter_add_rows(other._F.contiguous(), b2o.contiguous(), out)
+        be.scatter_add_rows(other.F.contiguous(), b2o.contiguous(), out)
         return SparseTensor(out, coordinate_map_key=key, coordinate_manager=self._manager)
 
     def __add__(self, other):
@@ -515,12 +548,12 @@ class SparseTensor:
             assert len(shape) == 5, "shape must be [B, C, X, Y, Z]"
             dims = (int(shape[0]), int(shape[2]), int(shape[3]), int(shape[4]))
         be = self._manager.backend()
-        dense = be.to_dense(self._F.contiguous(), coords, min3, step, dims)
+        dense = be.to_dense(self.F.contiguous(), coords, min3, step, dims)
         return dense, min_ret, torch.IntTensor(ts)
 
     # -- training-code helpers (criterion_sparse.py:273-274) ---------------------------------------
     def features_at(self, batch_index: int) -> torch.Tensor:
-        return self._F[self.C[:, 0] == batch_index]
+        return self.F[self.C[:, 0] == batch_index]
 
     def coordinates_at(self, batch_index: int) -> torch.Tensor:
         c = self.C

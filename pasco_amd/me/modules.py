@@ -26,6 +26,7 @@ def _kvol(kernel_size) -> int:
 
 
 _ME_CONV = os.environ.get("PASCO_ME_CONV", "guarded")
+_ME_DEFER = os.environ.get("PASCO_ME_DEFER", "1") != "0"      # eval-mode BatchNorm / ReLU recorded, applied by the next convolution
 ME_MIN_ROWS_WINDOWS = 16384     # 3x3x3 maps with at least this many rows get window tables (as pasco_amd.graph.fused does)
 
 
@@ -91,23 +92,30 @@ class _ConvBase(MinkowskiModuleBase):
         assert coordinates is None, "explicit output coordinates are not served"
         out_key, nbr = self._maps(x)
         mgr = x.coordinate_manager
-        out = self.conv_rows(mgr.backend(), x.F, nbr, mgr.size(out_key), mgr=mgr)
+        raw, pending = x.take_prologue()
+        out = self.conv_rows(mgr.backend(), raw, nbr, mgr.size(out_key), mgr=mgr, prologue=pending)
         return SparseTensor(out, coordinate_map_key=out_key, coordinate_manager=mgr)
 
-    def conv_rows(self, be, feats: torch.Tensor, nbr, n_out: int, mgr=None) -> torch.Tensor:
+    def conv_rows(self, be, feats: torch.Tensor, nbr, n_out: int, mgr=None, prologue=None) -> torch.Tensor:
         """The module's own launch(es): exact fp32 results, as upstream's.  Where the split-precision kernels apply (GPU,
         cin % 8 == 0) the products run on them GUARDED: the operand split reports an f16 range overflow (|x| > 2047) into a
         word of this call, and the exact fp32 kernel is launched behind the split one with that word as its predicate
         (`ph_conv_desc.exact_if`): it replaces the result exactly when it has to and costs an empty launch otherwise.  No
         host read, nothing for the caller to check - a maintainer who only swaps the import gets the fast kernels (round 5:
         the exact fp32 MFMA runs at 1 / 16 of the f16 rate and was ~85 % of the unfused route's time).
-        `PASCO_ME_CONV=exact` (or `set_me_conv("exact")`): the exact kernel only."""
+        `PASCO_ME_CONV=exact` (or `set_me_conv("exact")`): the exact kernel only.
+        `prologue` = (scale, shift, act, slope) of a deferred BatchNorm / activation in front (SparseTensor.deferred): applied
+        to the gathered rows by the launch itself instead of by separate passes over the tensor."""
         feats = feats.contiguous()
         kernel = self.kernel.detach().contiguous()
         bias = self.bias.detach().reshape(-1).contiguous() if self.bias is not None else None
+        pro = {}
+        if prologue is not None:
+            ps, pb, pact, pslope = prologue
+            pro = dict(pro_scale=ps, pro_shift=pb, pro_act=pact, slope=pslope)
         if n_out == 0 or _ME_CONV != "guarded" or not be.split_supported(self.in_channels, self.out_channels) or \
                 torch.is_grad_enabled() and self.kernel.requires_grad and self.training:
-            return be.conv_fwd(feats, kernel, nbr, n_out, bias=bias)
+            return be.conv_fwd(feats, kernel, nbr, n_out, bias=bias, **pro)
         w = self.kernel
         ver = (w._version, w.data_ptr(), w.device)
         hit = self.__dict__.get("_ph_me_split")
@@ -117,13 +125,13 @@ class _ConvBase(MinkowskiModuleBase):
                 torch.cuda.current_stream(w.device).synchronize()     # the cache serves every stream (fused.publish)
             self.__dict__["_ph_me_split"] = hit
         flag = torch.zeros(1, dtype=torch.int32, device=feats.device)
-        xs = be.split_rows(feats, status=flag)
+        xs = be.split_rows(feats, status=flag, **pro)
         win = None
         if mgr is not None and nbr is not None and nbr.shape[0] == 27 and 33 <= self.out_channels <= 64 and \
                 n_out >= ME_MIN_ROWS_WINDOWS and be.device_type == "cuda":
             win = mgr.kernel_windows(nbr)       # LDS-window tables of the map (cached by the manager): k_conv_wop
         out = be.conv_fwd(feats, kernel, nbr, n_out, bias=bias, split=hit[1], in_split=xs, status=flag, win=win)
-        be.conv_fwd(feats, kernel, nbr, n_out, bias=bias, out=out, exact_if=flag)
+        be.conv_fwd(feats, kernel, nbr, n_out, bias=bias, out=out, exact_if=flag, **pro)
         return out
 
     def extra_repr(self):
@@ -163,7 +171,33 @@ class MinkowskiBatchNorm(nn.Module):
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
                                  track_running_stats=track_running_stats)
 
+    def folded(self):
+        """(scale, shift) of the eval-mode normalisation, y = x * scale + shift; cached per parameter version."""
+        m = self.bn
+        bufs, pars = m._buffers, m._parameters
+        rm, rv, w, b = bufs["running_mean"], bufs["running_var"], pars.get("weight"), pars.get("bias")
+        ver = (rm._version, rv._version, w._version if w is not None else -1, b._version if b is not None else -1, rm.device,
+               rm.data_ptr())
+        hit = self.__dict__.get("_ph_me_folded")
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                scale = torch.rsqrt(rv.float() + m.eps) * (w.float() if w is not None else 1.0)
+                shift = (b.float() if b is not None else 0.0) - rm.float() * scale
+                scale, shift = scale.contiguous(), shift.contiguous()
+            if rm.is_cuda and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(rm.device).synchronize()       # the cache serves every stream
+            hit = (ver, scale, shift)
+            self.__dict__["_ph_me_folded"] = hit
+        return hit[1], hit[2]
+
     def forward(self, x: SparseTensor) -> SparseTensor:
+        m = self.bn
+        if _ME_DEFER and not m.training and m.track_running_stats and m._buffers.get("running_mean") is not None \
+                and not torch.is_grad_enabled() and x._F.dtype == torch.float32:
+            if x._pending is not None:
+                x.F                        # an activation is pending: it has to be applied before this affine
+            scale, shift = self.folded()
+            return SparseTensor.deferred(x, scale, shift, B.ACT_NONE, 0.01)
         return _same_map(x, self.bn(x.F))
 
 
@@ -195,12 +229,31 @@ class _Elementwise(MinkowskiModuleBase):
         return _same_map(x, self.module(x.F))
 
 
-class MinkowskiReLU(_Elementwise):
+class _DeferredAct(_Elementwise):
+    """ReLU / LeakyReLU: in inference the activation is recorded on the returned tensor (SparseTensor.deferred) and applied
+    by the next convolution's operand prologue, or the first time anything else reads the values."""
+    ACT = B.ACT_NONE
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        if _ME_DEFER and not torch.is_grad_enabled() and x._F.dtype == torch.float32:
+            slope = float(getattr(self.module, "negative_slope", 0.01))
+            if x._pending is not None and x._pending[2] == B.ACT_NONE:      # behind a deferred BatchNorm: one prologue
+                raw, (scale, shift, _, _) = x.take_prologue()
+                src = SparseTensor(raw, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
+                return SparseTensor.deferred(src, scale, shift, self.ACT, slope)
+            x.F                                                             # (materialises whatever else is pending)
+            return SparseTensor.deferred(x, None, None, self.ACT, slope)
+        return _same_map(x, self.module(x.F))
+
+
+class MinkowskiReLU(_DeferredAct):
     MODULE = nn.ReLU
+    ACT = B.ACT_RELU
 
 
-class MinkowskiLeakyReLU(_Elementwise):
+class MinkowskiLeakyReLU(_DeferredAct):
     MODULE = nn.LeakyReLU
+    ACT = B.ACT_LEAKY
 
 
 class MinkowskiSigmoid(_Elementwise):

@@ -91,3 +91,60 @@ def test_exact_if_guards_an_exact_launch_gpu(hip):
     flag.fill_(1)
     hip.conv_fwd(x.F, w, nbr, 20000, out=out, exact_if=flag)
     assert torch.equal(out, hip.conv_fwd(x.F, w, nbr, 20000))
+
+
+# ---- deferred BatchNorm / activation on the plain modules -----------------------------------------------------------------
+def _chain(device, defer, act="relu"):
+    torch.manual_seed(5)
+    g = torch.Generator().manual_seed(5)
+    bn = ME.MinkowskiBatchNorm(16).eval()
+    bn.bn.running_mean.copy_(torch.randn(16, generator=g) * 0.3)
+    bn.bn.running_var.copy_(torch.rand(16, generator=g) + 0.5)
+    bn.bn.weight.data.copy_(torch.rand(16, generator=g) + 0.5)
+    bn.bn.bias.data.copy_(torch.randn(16, generator=g) * 0.1)
+    relu = ME.MinkowskiReLU() if act == "relu" else ME.MinkowskiLeakyReLU(0.2)
+    conv = ME.MinkowskiConvolution(16, 8, kernel_size=3, bias=True, dimension=3).eval()
+    bn, conv = bn.to(device), conv.to(device)
+    coords, feats = _scene(n=700, c=16, extent=(12, 12, 8), seed=2)
+    x = ME.SparseTensor(feats.to(device), coords.to(device))
+    old = M._ME_DEFER
+    M._ME_DEFER = defer
+    try:
+        with torch.no_grad():
+            h = relu(bn(x))
+            pending = h._pending
+            y = conv(h)
+            # anything else that reads the values sees the computed tensor
+            hF = h.F.clone()
+            s = (h + h).F
+            p = ME.MinkowskiPruning()(h, feats[:, 0].to(device) > 0).F
+        return pending, hF.cpu(), y.F.cpu(), s.cpu(), p.cpu()
+    finally:
+        M._ME_DEFER = old
+
+
+@pytest.mark.parametrize("act", ["relu", "leaky"])
+def test_deferred_batchnorm_and_activation_change_nothing_observable(oracle_registered, act):
+    pend1, h1, y1, s1, p1 = _chain("cpu", True, act)
+    pend0, h0, y0, s0, p0 = _chain("cpu", False, act)
+    assert pend0 is None and pend1 is not None and pend1[2] == (1 if act == "relu" else 2)      # recorded, not computed
+    for a, b in ((h1, h0), (y1, y0), (s1, s0), (p1, p0)):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), float((a - b).abs().max())
+
+
+def test_training_mode_is_never_deferred(oracle_registered):
+    bn = ME.MinkowskiBatchNorm(8).train()
+    coords, feats = _scene(n=100, c=8, extent=(8, 8, 4))
+    x = ME.SparseTensor(feats, coords)
+    with torch.no_grad():
+        assert bn(x)._pending is None
+    with torch.enable_grad():
+        assert ME.MinkowskiReLU()(x)._pending is None
+
+
+@pytest.mark.gpu
+def test_deferred_chain_on_the_gpu(hip):
+    _, h1, y1, s1, p1 = _chain("cuda", True)
+    _, h0, y0, s0, p0 = _chain("cuda", False)
+    for a, b in ((h1, h0), (y1, y0), (s1, s0), (p1, p0)):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), float((a - b).abs().max())
