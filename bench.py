@@ -397,8 +397,12 @@ def short_row(n_infers, in_channels, n_classes, device, steps=3, unfused=False, 
     if unfused:                 # INTEGRATION.md route (a): reference-style module sequence on the plain pasco_amd.me modules
         from pasco_amd.me import modules as me_modules
         fused.set_fusion(False)
-        fused.set_conv_precision("f32")
-        me_modules.set_me_conv(me_conv)     # "guarded": split-precision kernels + exact fp32 device-side fallback (default)
+        # "guarded" (the modules' default): split-precision kernels + exact fp32 device-side fallback, the dense bottleneck (a
+        # torch Conv3d stack in the reference, outside the ME surface) on the implicit-GEMM kernel at the default precision;
+        # "exact": every product on the exact fp32 MFMA, modules and bottleneck alike (what rounds 2 - 4 reported)
+        if me_conv == "exact":
+            fused.set_conv_precision("f32")
+        me_modules.set_me_conv(me_conv)
     try:
         with torch.no_grad():
             run_scene(net, scene, teacher)
