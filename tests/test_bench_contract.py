@@ -53,3 +53,36 @@ def test_committed_pmc_file_serves_the_traffic_field():
         assert rec is not None and rec["hbm_bytes_per_launch"] > 0 and rec["file"].startswith("profiles/")
         assert bench.pmc_traffic(name) == rec["hbm_bytes_per_launch"]
     assert bench.pmc_traffic("no_such_kernel") is None
+
+
+def test_printed_line_stays_parseable():
+    """Round 5's line was 20.5 KB and the driver could not parse it.  `compact_line` of a FULL-SIZE result (round 5's own,
+    profiles/r5last_bench_full.json) must stay under LINE_LIMIT and keep the contract fields, the headline roofline and
+    the CPU baseline; everything else lives in the detail file."""
+    with open(os.path.join(ROOT, "profiles", "r5last_bench_full.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 16000
+    line = bench.compact_line(full, os.path.join(ROOT, "bench_detail.json"))
+    text = json.dumps(line)
+    assert len(text) <= bench.LINE_LIMIT < 8192 and "\n" not in text
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["config"]["workload"] == full["config"]["workload"]
+    assert line["config"]["also_measured"]["in_flight_1_scenes_per_s"] == full["in_flight_1"]["value"]
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "alg_bytes_per_launch",
+              "launches_per_step", "matrix_roof"):
+        assert k in r, k
+    assert "by_kernel" not in r and "by_layer_class" not in r
+    assert r["frac"] == round(full["roofline"]["frac"], 4) and r["classes"][0][0] == full["roofline"]["class"]
+    cb = line["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb)
+    assert set(line["configs"]) == set(full["configs"]) and all(isinstance(v, float) for v in line["configs"].values())
+    assert line["detail"] == "bench_detail.json"
+    # a pathological result (very long strings everywhere) still fits: optional keys are dropped, never the contract's
+    fat = json.loads(json.dumps(full))
+    fat["configs"] = {f"row{i}": {"scenes_per_s": 1.0} for i in range(400)}
+    fat["exchange"] = {"x": "y" * 5000}
+    slim = bench.compact_line(fat)
+    assert len(json.dumps(slim)) <= bench.LINE_LIMIT and "roofline" in slim and "cpu_baseline" in slim
