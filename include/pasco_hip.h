@@ -37,9 +37,17 @@ extern "C" {
 
 /* 2: ph_conv_desc grew (split_exp2, out_split, window / axis-table / row-list blocks), ph_map_insert and ph_split_rows gained
  * their `status` argument.  A caller built against another version must be rebuilt: the binding checks the version AND the size
- * of ph_conv_desc before the first call. */
-#define PH_ABI_VERSION 3
+ * of ph_conv_desc before the first call.
+ * 3: ph_panop_*.  4: ph_conv_desc.route (was reserved2) replaces the process-global test hooks of rounds 2 - 5. */
+#define PH_ABI_VERSION 4
 #define PH_MAX_KVOL 64 /* largest kernel volume of one nbr_build / pooling call (4x4x4 window); conv_fwd takes tables of up to 4096 offsets (dense bottleneck: 7x7x5 = 245) */
+
+/* ph_conv_desc.route bits */
+#define PH_ROUTE_WIN_ALWAYS 0x1  /* 3x3x3 maps with window tables: the LDS-window kernel, whatever the map's locality */
+#define PH_ROUTE_WIN_NEVER 0x2   /* ... the per-offset gather kernel */
+#define PH_ROUTE_WIDE_ALWAYS 0x4 /* 128 / 256 output channels, >= 8 offsets: the 256-row tile kernel at any size */
+#define PH_ROUTE_WIDE_NEVER 0x8
+#define PH_ROUTE_LIN_NEVER 0x10  /* k = 1 products: not the row-stream kernel */
 
 /* activation codes for fused prologue / epilogue */
 #define PH_ACT_NONE 0
@@ -186,7 +194,11 @@ typedef struct ph_conv_desc {
   const float *osp_scale; /* [cout] */
   const float *osp_shift; /* [cout] */
   int32_t osp_act;
-  int32_t reserved2;
+  /* Kernel choice of THIS call, for parity tests (0 = the library decides - every caller of the product path).  Every route computes
+   * the same products in another fp32 summation order; the bits only pin which hand-written kernel serves a shape that more than
+   * one could serve, so that a test can hold each of them to the oracle (tests/test_hip_win.py, test_hip_wide.py, test_hip_lin.py).
+   * No process-global state: two threads may use different routes at once. */
+  int32_t route;
   /* mode 2, optional: LDS-window tables of the kernel map (ph_win_build; 3x3x3 maps only).  When all four are given
    * the library may serve the launch from per-tile input windows instead of per-offset gathers; which of the two
    * kernels does the work is decided on the device from win_stats (no host read).  Results are the same products

@@ -25,18 +25,26 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_hip(force: bool = False, verbose: bool = True) -> str:
-    """Compile every .hip translation unit and link libpascohip.so. Returns the library path."""
+DEV_LIB_PATH = os.path.join(CSRC, "libpascohip_dev.so")
+
+
+def build_hip(force: bool = False, verbose: bool = True, dev: bool = False) -> str:
+    """Compile every .hip translation unit and link libpascohip.so. Returns the library path.
+
+    dev=True builds the DEVELOPMENT library instead (-DPH_DEV -> libpascohip_dev.so, objects *.dev.o): the same kernels plus the
+    experiment surface the product library does not have - PASCO_* environment switches inside the dispatch, ablation masks,
+    shader-clock traces and their extern "C" setters.  Only tools/ loads it (tools/devlib.py)."""
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     jobs = []
+    lib_path = DEV_LIB_PATH if dev else LIB_PATH
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, s.replace(".hip", ".dev.o" if dev else ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([HIPCC, *FLAGS, *(["-DPH_DEV"] if dev else []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -51,10 +59,10 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB_PATH, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs])
-    return LIB_PATH
+    if force or jobs or _stale(lib_path, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs])
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_hip(force="--force" in sys.argv))
+    print(build_hip(force="--force" in sys.argv, dev="--dev" in sys.argv))

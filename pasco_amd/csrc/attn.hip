@@ -1198,7 +1198,7 @@ extern "C" int ph_attn_cross_split(const float *q, const void *k_split, const vo
   // 512 workgroups = one round of the two resident per CU (round 4; 1536 before: every key range leaves a partial record that
   // k_attn_merge reads again - 229 -> 181 us and 104 -> 66 us at the two coarser levels' sizes, merge included); at most the
   // 2048 + 4 b h partial records the workspace holds
-  static const int target = [] { const char *e = getenv("PASCO_ATTN_SPLIT_WGS"); return e ? atoi(e) : 512; }();
+  static const int target = [] { const char *e = PH_DEV_ENV("PASCO_ATTN_SPLIT_WGS"); return e ? atoi(e) : 512; }();
   int64_t splits = (target > 0 && target <= 2048 ? target : 512) / bh;
   if (splits < 1) splits = 1;
   if (splits > ntile) splits = ntile;
@@ -1210,7 +1210,7 @@ extern "C" int ph_attn_cross_split(const float *q, const void *k_split, const vo
   s.groups = b * (int)splits;
   hipStream_t st = ph_stream(stream);
   const int64_t groups8 = ((int64_t)s.groups + 7) / 8;       // groups per XCD
-  static const bool plain = [] { const char *e = getenv("PASCO_ATTN_INTER"); return e != nullptr && atoi(e) == 0; }();
+  static const bool plain = [] { const char *e = PH_DEV_ENV("PASCO_ATTN_INTER"); return e != nullptr && atoi(e) == 0; }();
   const dim3 grid((unsigned)(groups8 * h * 8));
   if (plain) {
     if (bits != nullptr) hipLaunchKernelGGL((k_attn_split<true, false>), grid, dim3(256), 0, st, s);
@@ -1244,7 +1244,7 @@ extern "C" int ph_attn_cross_feat(const float *q2, const void *x_split, const vo
   // key ranges per (subnet, head): two workgroups are resident per CU (256 registers per wave), so 512 workgroups are one
   // round; every partial record is 43 KB that k_attn_merge reads again (2048 workgroups: 88 MB of partials, 157 us of merge;
   // 846 -> 756 us at the finest level's size, merge included)
-  static const int target = [] { const char *e = getenv("PASCO_ATTN_FEAT_WGS"); return e ? atoi(e) : 512; }();
+  static const int target = [] { const char *e = PH_DEV_ENV("PASCO_ATTN_FEAT_WGS"); return e ? atoi(e) : 512; }();
   int64_t splits = (target > 0 && target <= 2048 ? target : 512) / bh;      // at most the 2048 + 4 b h records the workspace holds
   if (splits < 1) splits = 1;
   if (splits > ntile) splits = ntile;

@@ -338,7 +338,7 @@ static int pick_cfg(const ConvArgs &a, int *bm) {
   const int64_t ncol = (a.cout + bn - 1) / bn;
   int m = bn == 32 ? 128 : 64;
   if (bn == 128 && ((a.n_out + 63) / 64) * ncol < 2 * 256) m = 32;
-  static const char *env = getenv("PASCO_CONV_CFG");   // tuning override, read once
+  static const char *env = PH_DEV_ENV("PASCO_CONV_CFG");   // tuning override, read once
   if (env) {
     const int em = atoi(env);
     if (em == 128 || (em == 64 && bn >= 64) || (em == 32 && bn == 128)) m = em;

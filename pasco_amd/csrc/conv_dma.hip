@@ -24,32 +24,44 @@
 #include <stdlib.h>
 
 #include <hip/hip_runtime.h>
-// development hook (tools/dma_trace.py): shader-clock stamps of the first 64 workgroups' phases when bit 7 of the ablate mask is set
+#include "ph_common.h"
+#ifdef PH_DEV
+// development build only (tools/dma_trace.py): shader-clock stamps of the first 64 workgroups' phases when bit 7 of the ablate mask is set
 __device__ unsigned long long g_dma_trace[64 * 8];
 #define DMA_STAMP(i)                                                                                              \
   do {                                                                                                            \
     if ((a.ablate & 0x80) && threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y == 0)                              \
       g_dma_trace[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter();                                           \
   } while (0)
+#else
+#define DMA_STAMP(i) do { } while (0)
+#endif
 #define H2_STAMP(i) DMA_STAMP(i)
 #include "conv_h2_common.h"
 
 // kernel volumes above this are the bottleneck's (7, 7, 5) implicit GEMMs: their empty (tile, offset) stages are dropped and their
 // slices interleaved (measured: 544 -> 478 us on the 245-offset products; the 75-offset ones, whose light and heavy tiles cannot
 // balance over 4 slices, lose 4 % to the bookkeeping and stay as they were: profiles/r4p_layer_ab_dense_stage_skip.txt)
+#ifdef PH_DEV
 extern "C" int ph_dma_trace_read(unsigned long long *host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dma_trace), sizeof(g_dma_trace)) == hipSuccess ? 0 : 2;
 }
+#endif
 constexpr int DMA_DENSE_KVOL = 100;
 constexpr int DMA_KMAX = 32;   // kernel offsets one workgroup walks (its slice of the split over the offsets)
 
-// Development hook: bit 8 of the mask selects the 256-row / 8-wave tiles (measured no faster: one workgroup per CU convoys).
+#ifdef PH_DEV
+// Development build only: bit 8 of the mask selects the 256-row / 8-wave tiles (measured no faster: one workgroup per CU convoys).
 // The phase-ablation bits of round 2 (skip MFMAs / gathers / fragment reads; profiles/r2c - r2e) are gone from the kernel:
 // their runtime branches cost ~3 % in the loop.
 static int g_dma_ablate = 0;
 static int g_dma_tall = 0;
 int ph_dma_ablate_bits() { return g_dma_ablate; }
 extern "C" void ph_conv_dma_set_ablate(int mask) { g_dma_ablate = mask & 0xff; g_dma_tall = (mask & 0x100) ? 1 : 0; }
+#else
+constexpr int g_dma_ablate = 0, g_dma_tall = 0;     // the product library has no experiment state
+int ph_dma_ablate_bits() { return 0; }
+#endif
 
 // One workgroup = WAVES (4 or 8) waves as WM x WN, tile BM = WM*TM*32 rows (128 / 256) x BN = WN*TN*32 channels,
 // 32 input channels per stage.  Everything that crosses the vector-memory path (gathered rows AND the weight tile of
@@ -101,7 +113,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
   // are empty depends on the tile's z plane and on the offset's dz, the slowest-running index of the enumeration - contiguous
   // slices would be all-empty or all-full, and a launch is as long as its fullest workgroups
   int kstride = 1;
-  if (a.kvol > DMA_DENSE_KVOL && a.tile_k == nullptr && a.ksplit > 1 && !(a.ablate & 4)) {
+  if (a.kvol > DMA_DENSE_KVOL && a.tile_k == nullptr && a.ksplit > 1 && !PH_ABLATE(a, 4)) {
     kstride = a.ksplit;
     k_begin = (int)blockIdx.y;
     kcount = k_begin < a.kvol ? (a.kvol - k_begin + kstride - 1) / kstride : 0;
@@ -145,7 +157,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
     // the tile's 80 KB of LDS are what lets two workgroups share a CU - not one byte more)
     static_assert(BM >= 2 * DMA_KMAX + 4, "the stage list fits one offset slot of the index table");
     int *kmap = idx_lds + (DMA_KMAX - 1) * BM;         // [DMA_KMAX] valid offset slots, then [DMA_KMAX] flags, then the count
-    const bool compact = a.kvol > DMA_DENSE_KVOL && a.tile_k == nullptr && !(a.ablate & 4);
+    const bool compact = a.kvol > DMA_DENSE_KVOL && a.tile_k == nullptr && !PH_ABLATE(a, 4);
     if (compact) {
       int *kflag = kmap + DMA_KMAX;
       for (int k = wave; k < kcount; k += WAVES) {
@@ -325,7 +337,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
     // keeps its loop branch-free by re-loading the last stage up to three more times and draining them before the epilogue -
     // for a two-stage launch that is 5 stage loads for 2 stages of work.  Here every stage is loaded exactly once: the DMA of
     // stage s + 2 goes into the buffer stage s was read from, the last waits are vmcnt(0) -----------------------------------
-    if (nstages <= 8 && !(a.ablate & 1)) {
+    if (nstages <= 8 && !PH_ABLATE(a, 1)) {
       auto wait_landed = [&](bool younger_in_flight) {
         if (younger_in_flight) {
           if (L == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -417,7 +429,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_dma(ConvArgsH a) {
   // every load of the epilogue ahead of its first store (conv_h2_common.h, ParGlobal): 600 -> 510 us on the 64 -> 384 projections
   // together with the epilogue's VALU diet, 547 without the staging (profiles/r3s_layer_ab_epilogue_diet_vs_base.txt)
   h2_store_tile_staged<TM, TN, EMIT, NT, BN, 2 * STAGE + DMA_KMAX * BM * 4>(a, acc, m0, n0, wm, wn, h, l31, tid, lds);
-  if (a.ablate & 0x80) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (PH_ABLATE(a, 0x80)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   DMA_STAMP(4);
 }
 
@@ -430,7 +442,7 @@ static int launch_dma(const ConvArgsH &a, hipStream_t st) {
   const int ntiles = args.n_row_tiles * args.n_col_tiles;
   const int grid = ((ntiles + 7) / 8) * 8;
   const bool emit = args.out_split != nullptr && args.ksplit == 1;
-  static const bool inter = [] { const char *e = getenv("PASCO_CONV_DMA_INTER"); return e == nullptr || atoi(e) != 0; }();
+  static const bool inter = [] { const char *e = PH_DEV_ENV("PASCO_CONV_DMA_INTER"); return e == nullptr || atoi(e) != 0; }();
   if (inter && WAVES == 4) {     // default: DMA instructions between the MFMAs (5-10 % on every layer; =0: in front of them)
     if (emit)
       hipLaunchKernelGGL((k_conv_dma<WAVES, WM, WN, TM, TN, true, true>), dim3(grid, 1), dim3(WAVES * 64), 0, st, args);
@@ -494,7 +506,7 @@ int ph_conv_dma_try(const ConvArgsH &a_in, int bn, hipStream_t st) {
   // round leaves most of the chip idle for a whole tile time (559 tiles: 2 rounds for 1.09 rounds of work).  When fewer than
   // half a round of row tiles is left over, they go into a second launch that is split over the kernel offsets so that it
   // fills the chip with short workgroups; only those rows pay the partial-sum reduction. ----------------------------------
-  static const bool tail_on = [] { const char *e = getenv("PASCO_CONV_TAIL"); return e == nullptr || atoi(e) != 0; }();
+  static const bool tail_on = [] { const char *e = PH_DEV_ENV("PASCO_CONV_TAIL"); return e == nullptr || atoi(e) != 0; }();
   const int64_t trow = (a.n_out + 127) / 128;
   const int64_t slots = 512 / ncol;               // row tiles of one full round
   const int64_t rounds = trow / slots, rest = trow - rounds * slots;
@@ -526,7 +538,8 @@ int ph_conv_dma_try(const ConvArgsH &a_in, int bn, hipStream_t st) {
   return launch_dma<4, 2, 2, 2, 2>(a, st);
 }
 
-// development hook (tools/occupancy.py): resident workgroups per CU of the main instantiations
+#ifdef PH_DEV
+// development build only (tools/occupancy.py): resident workgroups per CU of the main instantiations
 extern "C" int ph_conv_dma_occupancy(int which) {
   int n = -1;
   hipError_t e = hipSuccess;
@@ -539,3 +552,4 @@ extern "C" int ph_conv_dma_occupancy(int which) {
   }
   return e == hipSuccess ? n : -1;
 }
+#endif

@@ -601,19 +601,19 @@ struct ConvHKnobs {
   bool dma_on = true;      // PASCO_CONV_DMA=0: keep every launch on the register-staged k_conv_h2 (A/B comparisons)
   bool wide_on = true;     // PASCO_CONV_WIDE=0: no 256 x 256 tiles (conv_wide.hip) for the 256-output-channel gather launches
   ConvHKnobs() {
-    if (const char *e = getenv("PASCO_CONV_DMA")) {
+    if (const char *e = PH_DEV_ENV("PASCO_CONV_DMA")) {
       dma_on = atoi(e) != 0;
       dma_all = atoi(e) == 2;      // 2: every tile width on the DMA kernel
     }
-    if (const char *e = getenv("PASCO_CONV_WIDE")) wide_on = atoi(e) != 0;
-    if (const char *e = getenv("PASCO_CONVH_MID")) mid_on = atoi(e) != 0;
-    if (const char *e = getenv("PASCO_CONV_WIN")) {
+    if (const char *e = PH_DEV_ENV("PASCO_CONV_WIDE")) wide_on = atoi(e) != 0;
+    if (const char *e = PH_DEV_ENV("PASCO_CONVH_MID")) mid_on = atoi(e) != 0;
+    if (const char *e = PH_DEV_ENV("PASCO_CONV_WIN")) {
       win_on = atoi(e) != 0;
       win_wide = atoi(e) == 2;
     }
-    if (const char *e = getenv("PASCO_CONV_RL")) rl_on = atoi(e) != 0;
-    if (const char *e = getenv("PASCO_CONVH_CFG")) has_cfg = sscanf(e, "%d,%d", &cfg_bm, &cfg_kc) >= 1;
-    if (const char *e = getenv("PASCO_CONVH_KSPLIT")) {
+    if (const char *e = PH_DEV_ENV("PASCO_CONV_RL")) rl_on = atoi(e) != 0;
+    if (const char *e = PH_DEV_ENV("PASCO_CONVH_CFG")) has_cfg = sscanf(e, "%d,%d", &cfg_bm, &cfg_kc) >= 1;
+    if (const char *e = PH_DEV_ENV("PASCO_CONVH_KSPLIT")) {
       has_ksplit = true;
       ksplit = atoi(e);
     }
@@ -699,6 +699,7 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.status = d->status;
   a.zero = nullptr;
   a.ablate = 0;
+  a.route = d->route;
   a.out_rows = nullptr;
   a.tile_k = nullptr;
   a.nbr_stride = d->n_out;
@@ -747,7 +748,7 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
     // ceil(tiles x slices / 512) rounds of resident workgroups, a round lasts as long as its longest slice, and every slice
     // adds a partial-sum round trip - e.g. 146 tiles x 27 offsets: 6 slices = 2 rounds of 5 offsets, 3 slices = ONE round of 9
     // (profiles/r3z_layer_ab_ksplit_model.txt).  PASCO_CONVH_KSPLIT_MODEL=0: the rule above.
-    static const bool model_on = [] { const char *e = getenv("PASCO_CONVH_KSPLIT_MODEL"); return e == nullptr || atoi(e) != 0; }();
+    static const bool model_on = [] { const char *e = PH_DEV_ENV("PASCO_CONVH_KSPLIT_MODEL"); return e == nullptr || atoi(e) != 0; }();
     if (model_on && bn == 128 && t128 < 2 * 256 && d->kvol >= 8 && d->splitk_ws != nullptr) {
       const double stage_us = 1.3, fixed_us = 5.0;           // one 32-channel stage of a workgroup sharing its CU; launch / prologue
       const double nchunks = (double)(a.cpad / 32);
@@ -802,11 +803,11 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   // (a 256-wide window workgroup for 256-channel layers was built and measured in round 2: 568 vs 547 us for the gather
   // kernel - removed in round 5, profiles/README.md)
   if (pre && knobs.win_on && !env && d->kvol == 27 &&
-      (bn == 64 || (bn == 128 && (knobs.win_wide || (ph_win_force_bits() & 0x100)))) &&
+      (bn == 64 || (bn == 128 && (knobs.win_wide || (d->route & PH_ROUTE_WIN_ALWAYS)))) &&
       a.ksplit == 1 &&
       d->win_rows && d->win_cnt && d->win_slots && d->win_stats) {
     a.win_stats = d->win_stats;
-    a.win_which = (bn == 64 ? 0 : 1) | ph_win_force_bits();
+    a.win_which = (bn == 64 ? 0 : 1) | ph_win_force_bits(d->route);
     a.win_gather = 0;
     if (int rc = ph_conv_win_launch(a, bn, st)) return rc;
     a.win_gather = 1;

@@ -44,7 +44,8 @@ struct ConvArgsH {
   int osp_has;
   float act_pow2;             // 2^split_exp2: scale of the activation operand (mode 1 gather, emitted out_split)
   const char *zero;           // k_conv_dma: >= 256 zero bytes in device memory (rows without a neighbour read them)
-  int ablate;                 // k_conv_dma development hook (0 in production)
+  int ablate;                 // development build only (PH_ABLATE): 0 in the product library, its branches compile out
+  int route;                  // ph_conv_desc.route (PH_ROUTE_*): per-call kernel choice of the parity tests, 0 = the library decides
   // LDS-window tables of the kernel map (conv_win.hip); win_stats != nullptr: the launch is one of a window / gather
   // pair and returns at once unless the device-side predicate picks it
   const int32_t *win_rows, *win_cnt, *win_stats;
@@ -114,10 +115,11 @@ __device__ __forceinline__ bool ph_win_pred(const int32_t *stats, int which, int
   if (which & 0x200) return false;
   return (int64_t)stats[which & 1] * 4 <= n_row_tiles * 5;
 }
-int ph_win_force_bits();   // conv_win.hip: 0, 0x100 or 0x200 (ph_conv_win_force, tests only)
+// ph_conv_desc.route -> the predicate override bits of win_which
+static inline int ph_win_force_bits(int route) { return (route & PH_ROUTE_WIN_ALWAYS) ? 0x100 : ((route & PH_ROUTE_WIN_NEVER) ? 0x200 : 0); }
 // conv_dma.hip: 256 zero bytes of device memory for absent neighbours
 const char *ph_dma_zero_line();
-int ph_dma_ablate_bits();   // development hook (tools/dma_ablate.py)
+int ph_dma_ablate_bits();   // 0 in the product library (development build: tools/dma_ablate.py)
 // conv_win.hip
 int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st);
 

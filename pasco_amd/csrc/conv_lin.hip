@@ -150,14 +150,18 @@ __global__ void __launch_bounds__(LIN_NT, 2) k_conv_lin(ConvArgsH a) {
   }
 }
 
-// PASCO_CONV_LIN=0 (or the development hook below, for same-process A/B runs) sends these launches back to k_conv_dma
-// (hook bits: 0 = on, 8.. = workgroups per CU)
-static int g_lin_on = [] { const char *e = getenv("PASCO_CONV_LIN"); return e == nullptr ? 1 : atoi(e); }();
+// ph_conv_desc.route & PH_ROUTE_LIN_NEVER sends a launch back to k_conv_dma (tests/test_hip_lin.py: the two are bit-identical).
+// Development build: PASCO_CONV_LIN=0 / ph_conv_lin_set for same-process A/B runs (bits: 0 = on, 8.. = workgroups per CU)
+#ifdef PH_DEV
+static int g_lin_on = [] { const char *e = PH_DEV_ENV("PASCO_CONV_LIN"); return e == nullptr ? 1 : atoi(e); }();
 extern "C" void ph_conv_lin_set(int on) { g_lin_on = on; }
+#else
+constexpr int g_lin_on = 1;
+#endif
 
 // Takes k = 1 launches on pre-split operands with 64 or 128 (padded) input channels; -1 = not served.
 int ph_conv_lin_try(const ConvArgsH &a_in, hipStream_t st) {
-  if (!(g_lin_on & 1)) return -1;
+  if (!(g_lin_on & 1) || (a_in.route & PH_ROUTE_LIN_NEVER)) return -1;
   if (a_in.kvol != 1 || a_in.ksplit != 1 || a_in.tile_k != nullptr || a_in.out_rows != nullptr) return -1;
   if (a_in.in_split == nullptr || a_in.w_split == nullptr || (a_in.cpad != 64 && a_in.cpad != 128)) return -1;
   if (a_in.n_out < 1) return -1;

@@ -244,8 +244,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_wide(ConvArgsH a) {
   h2_store_tile<TM, TN, EMIT>(a, acc, m0, n0, wm, wn, h, l31);
 }
 
-static int g_wide_all = 0;      // test / experiment hook (tests/test_hip_wide.py): 1 = every served shape whatever its size, -1 = none
-extern "C" void ph_conv_wide_all(int mode) { g_wide_all = mode; }
+// ph_conv_desc.route (tests/test_hip_wide.py): PH_ROUTE_WIDE_ALWAYS = every served shape whatever its size, PH_ROUTE_WIDE_NEVER = none
 
 template <int TN>
 static int launch_wide(const ConvArgsH &a, hipStream_t st) {
@@ -279,8 +278,8 @@ int ph_conv_wide_try(const ConvArgsH &a_in, hipStream_t st) {
   // measured (profiles/r3n_layer_ab_wide.txt): 477 vs 520 us at 53 k rows, 162 vs 188 us at 15.6 k rows; below ~12 k rows
   // (fewer than 48 row tiles: a deep split over the offsets) and on the bottleneck's 245 / 75-offset products k_conv_dma's
   // smaller tiles win
-  if (g_wide_all < 0) return -1;
-  if (g_wide_all == 0) {
+  if (a_in.route & PH_ROUTE_WIDE_NEVER) return -1;
+  if (!(a_in.route & PH_ROUTE_WIDE_ALWAYS)) {
     if (a_in.kvol > WIDE_KMAX) return -1;
     if (a_in.cout == 256 && trow < 48) return -1;
     if (a_in.cout == 128) {      // whole rounds only: the last round at least ~60 % full, no split over the offsets

@@ -330,7 +330,7 @@ extern "C" int ph_win_build(const int32_t *nbr, int32_t kvol, int64_t n_out, int
   const int64_t ntiles = (n_out + WIN_BM - 1) / WIN_BM;
   hipStream_t st = ph_stream(stream);
   PH_CHECK_HIP(hipMemsetAsync(win_stats, 0, 4 * sizeof(int32_t), st));
-  static const bool fast_on = [] { const char *e = getenv("PASCO_WIN_BUILD_FAST"); return e == nullptr || atoi(e) != 0; }();
+  static const bool fast_on = [] { const char *e = PH_DEV_ENV("PASCO_WIN_BUILD_FAST"); return e == nullptr || atoi(e) != 0; }();
   if (fast_on) {
     hipLaunchKernelGGL(k_win_build_fast, dim3((unsigned)ntiles), dim3(256), 0, st, nbr, n_out, win_rows, win_cnt, win_slots,
                        win_stats, WIN_MAX_64, WIN_MAX_128);
@@ -343,11 +343,8 @@ extern "C" int ph_win_build(const int32_t *nbr, int32_t kvol, int64_t n_out, int
   return 0;
 }
 
-// Test hook (tests/test_hip_win.py): 1 = every pair runs on windows (multi-pass path on maps without locality),
-// -1 = never, 0 = the device-side predicate decides
-static int g_win_force = 0;
-extern "C" void ph_conv_win_force(int mode) { g_win_force = mode; }
-int ph_win_force_bits() { return g_win_force > 0 ? 0x100 : (g_win_force < 0 ? 0x200 : 0); }
+// ph_conv_desc.route (tests/test_hip_win.py): PH_ROUTE_WIN_ALWAYS = the pair runs on windows (multi-pass path on maps without
+// locality), PH_ROUTE_WIN_NEVER = never, neither = the device-side predicate decides
 
 // ---- the convolution -------------------------------------------------------------------------------------------
 // WAVES waves as WM x WN: 64-wide tiles run 4 waves (two workgroups per CU), 128-wide tiles 8 waves (one workgroup
@@ -615,7 +612,8 @@ struct WopA {                 // activation fragments of two row blocks: [block]
 #define WOP_WAIT_LGKM(n, f) \
   asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"((f).h[0]), "+v"((f).h[1]), "+v"((f).l[0]), "+v"((f).l[1])::"memory")
 
-// development hook (tools/wop_trace.py): shader-clock stamps of the phases of the first 64 workgroups (wave 0), TRACE builds only
+#ifdef PH_DEV
+// development build only (tools/wop_trace.py): shader-clock stamps of the phases of the first 64 workgroups (wave 0), TRACE instantiation
 __device__ unsigned long long g_wop_trace[64 * 16];
 static int g_wop_trace_on = 0;
 extern "C" void ph_wop_trace_enable(int on) { g_wop_trace_on = on; }
@@ -626,6 +624,9 @@ extern "C" int ph_wop_trace_read(unsigned long long *host_out) {
   do {                                                                                                 \
     if (TRACE && tid == 0 && blockIdx.x < 64) g_wop_trace[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
+#else
+#define WOP_STAMP(i) do { } while (0)
+#endif
 
 template <int WMAX, bool EMIT, bool TRACE = false>
 __global__ void __launch_bounds__(256, 2) k_conv_wop(ConvArgsH a) {
@@ -919,8 +920,8 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st) {
     return 2;
   }
   if (bn == 64) {
-    b.win_which = 0 | ph_win_force_bits();
-    static const bool wop = [] { const char *e = getenv("PASCO_WIN_OFFSET_PARALLEL"); return e == nullptr || atoi(e) != 0; }();
+    b.win_which = 0 | ph_win_force_bits(b.route);
+    static const bool wop = [] { const char *e = PH_DEV_ENV("PASCO_WIN_OFFSET_PARALLEL"); return e == nullptr || atoi(e) != 0; }();
     if (wop && b.cout <= 64) {       // offset-parallel waves (k_conv_wop); PASCO_WIN_OFFSET_PARALLEL=0: the row-parallel kernel
       ConvArgsH args = b;
       args.n_row_tiles = (int)((b.n_out + WIN_BM - 1) / WIN_BM);
@@ -928,15 +929,18 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st) {
       const int grid = ((args.n_row_tiles + 7) / 8) * 8;
       // the phase trace (tools/wop_trace.py) exists only for the non-emitting instantiation: a launch that has to write the next
       // layer's operand is never traced (it would silently leave that operand unwritten)
+#ifdef PH_DEV
       if (g_wop_trace_on && args.out_split == nullptr)
         hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, false, true>), dim3(grid), dim3(256), 0, st, args);
-      else if (args.out_split != nullptr) hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, true>), dim3(grid), dim3(256), 0, st, args);
+      else
+#endif
+      if (args.out_split != nullptr) hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, true>), dim3(grid), dim3(256), 0, st, args);
       else hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, false>), dim3(grid), dim3(256), 0, st, args);
       PH_LAUNCH_CHECK();
       return 0;
     }
     return launch_win<4, 4, 1, 1, 2, WIN_MAX_64>(b, st);
   }
-  b.win_which = 1 | ph_win_force_bits();
+  b.win_which = 1 | ph_win_force_bits(b.route);
   return launch_win<8, 2, 4, 2, 1, WIN_MAX_128>(b, st);
 }

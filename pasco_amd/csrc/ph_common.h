@@ -9,6 +9,19 @@
 
 #define PH_WAVE 64
 
+// ---- development build (-DPH_DEV: pasco_amd/build.py build_hip(dev=True) -> libpascohip_dev.so, loaded only by tools/) ---------
+// The PRODUCT library has no process-global experiment state, no environment switches and no exports beyond include/pasco_hip.h:
+// PH_DEV_ENV answers "unset", PH_ABLATE(...) is the constant 0 (its branches compile out of the kernels), the trace buffers,
+// the ablation masks and their extern "C" setters do not exist.
+#ifdef PH_DEV
+#include <stdlib.h>
+#define PH_DEV_ENV(name) getenv(name)
+#define PH_ABLATE(a, bits) ((a).ablate & (bits))
+#else
+#define PH_DEV_ENV(name) (static_cast<const char *>(nullptr))
+#define PH_ABLATE(a, bits) 0
+#endif
+
 // ---- error plumbing ---------------------------------------------------------------------------
 void ph_set_error(const char *fmt, ...);
 

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpascohip.so")
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
-ABI_VERSION = 3          # include/pasco_hip.h PH_ABI_VERSION this binding was written against
+ABI_VERSION = 4          # include/pasco_hip.h PH_ABI_VERSION this binding was written against
 
 
 class StatusError(RuntimeError):
@@ -65,7 +65,7 @@ class ConvDesc(C.Structure):
         ("mma_mode", _i32), ("w_unscale", C.c_float), ("w_f16_hi", _vp), ("w_f16_lo", _vp),
         ("splitk_ws", _vp), ("splitk_ws_bytes", _i64), ("status", _vp),
         ("in_split", _vp), ("w_split", _vp),
-        ("out_split", _vp), ("osp_scale", _vp), ("osp_shift", _vp), ("osp_act", _i32), ("reserved2", _i32),
+        ("out_split", _vp), ("osp_scale", _vp), ("osp_shift", _vp), ("osp_act", _i32), ("route", _i32),
         ("win_rows", _vp), ("win_cnt", _vp), ("win_slots", _vp), ("win_stats", _vp),
         ("axis_table", _vp), ("axis_coords", _vp), ("axis_lo", _i32), ("axis_rows", _i32),
         ("rl_in", _vp), ("rl_out", _vp), ("rl_tile_k", _vp), ("rl_rows", _i64), ("rl_tiles", _i32),
@@ -142,6 +142,9 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+ROUTE_WIN_ALWAYS, ROUTE_WIN_NEVER, ROUTE_WIDE_ALWAYS, ROUTE_WIDE_NEVER, ROUTE_LIN_NEVER = 0x1, 0x2, 0x4, 0x8, 0x10   # PH_ROUTE_*
+
+
 class CBackend:
     """Thin typed wrapper over one shared library exporting the pasco_hip.h ABI."""
 
@@ -185,6 +188,28 @@ class CBackend:
         self.checker_split = False
 
     # -- helpers -----------------------------------------------------------------------------------
+    def routing(self, bits: int):
+        """Context manager for parity tests: every `conv_fwd` of THIS thread inside it carries `ph_conv_desc.route = bits`
+        (ROUTE_* below = PH_ROUTE_* of include/pasco_hip.h: pin the window / gather, wide / not, row-stream / not kernel of a shape
+        that several kernels can serve).  Per call, no process-global state; the product path never sets it."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = getattr(self._tls, "route", 0)
+            self._tls.route = int(bits)
+            try:
+                yield self
+            finally:
+                self._tls.route = old
+        return cm()
+
+    def set_route(self, bits: int) -> int:
+        """`ph_conv_desc.route` of this thread's following `conv_fwd` calls (see `routing`); returns the previous value."""
+        old = getattr(self._tls, "route", 0)
+        self._tls.route = int(bits)
+        return old
+
     def has(self, name: str) -> bool:
         return name in self.fn
 
@@ -458,6 +483,7 @@ class CBackend:
         if n_out == 0:
             return (out, out_split) if emit else out
         d = ConvDesc()
+        d.route = getattr(self._tls, "route", 0)
         if emit:
             osc, osh, oact = emit_split
             for name, t in (("osp_scale", osc), ("osp_shift", osh)):

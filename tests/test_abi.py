@@ -33,9 +33,33 @@ def test_hip_library_exports_every_symbol():
         assert hasattr(lib, "ph_" + n), f"libpascohip.so lacks ph_{n}"
     lib.ph_abi_version.restype = ctypes.c_int
     from pasco_amd.me.backend import ABI_VERSION
-    assert lib.ph_abi_version() == ABI_VERSION == 3
+    assert lib.ph_abi_version() == ABI_VERSION == 4
     from pasco_amd.me.backend import ConvDesc
     assert lib.ph_conv_desc_size() == ctypes.sizeof(ConvDesc)
+
+
+def _dynamic_exports(path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TW"}
+
+
+def test_product_library_exports_exactly_the_header(tmp_path):
+    """No development surface in the product: the `ph_*` symbols libpascohip.so exports are EXACTLY the entry points
+    include/pasco_hip.h declares (round 5 shipped 8 undeclared ones: ablation masks, traces, process-global kernel
+    forcing), its sources read no environment variable, and the experiment state is compiled only with -DPH_DEV."""
+    from pasco_amd.build import CSRC, build_hip
+    exported = {s for s in _dynamic_exports(build_hip(verbose=False)) if s.startswith("ph_")}
+    assert exported == {"ph_" + n for n in declared()}, sorted(exported ^ {"ph_" + n for n in declared()})
+    for f in os.listdir(CSRC):
+        if f.endswith((".hip", ".h")):
+            src = open(os.path.join(CSRC, f)).read()
+            body = src.split("#ifdef PH_DEV")[0] if f == "ph_common.h" else src
+            assert "getenv(" not in body.replace("PH_DEV_ENV(", ""), f"{f} reads the environment outside the development build"
+    # a.ablate is only ever read through PH_ABLATE (the constant 0 in the product build)
+    for f in ("conv_dma.hip", "conv_win.hip", "conv_wide.hip", "conv_lin.hip", "conv_f16x3.hip", "conv_h2_common.h"):
+        src = open(os.path.join(CSRC, f)).read()
+        product = re.sub(r"#ifdef PH_DEV.*?#(?:else|endif)", "", src, flags=re.S)
+        assert not re.search(r"\ba\.ablate\s*&", product), f"{f}: ablation branch outside PH_ABLATE"
 
 
 def test_binding_rejects_other_abi_versions(monkeypatch):

@@ -11,9 +11,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _switch(hip, on):
-    hip.lib.ph_conv_lin_set.argtypes = [C.c_int]
-    hip.lib.ph_conv_lin_set.restype = None
-    hip.lib.ph_conv_lin_set(int(on))
+    """ph_conv_desc.route of this thread's launches: off = k = 1 products stay on k_conv_dma"""
+    from pasco_amd.me.backend import ROUTE_LIN_NEVER
+    hip.set_route(0 if on else ROUTE_LIN_NEVER)
 
 
 def _case(hip, n, cin, cout, gather, tail, emit, seed):

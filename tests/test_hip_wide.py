@@ -21,10 +21,13 @@ def scene(n, extent, seed):
 
 @pytest.fixture()
 def wide_hook(hip):
-    fn = hip.lib.ph_conv_wide_all
-    fn.argtypes = [ctypes.c_int]
+    """ph_conv_desc.route of this thread's launches: 1 = k_conv_wide for every shape it can serve, -1 = never, 0 = the library's size gate"""
+    from pasco_amd.me.backend import ROUTE_WIDE_ALWAYS, ROUTE_WIDE_NEVER
+
+    def fn(mode):
+        hip.set_route({1: ROUTE_WIDE_ALWAYS, -1: ROUTE_WIDE_NEVER, 0: 0}[mode])
     yield fn
-    fn(0)
+    hip.set_route(0)
 
 
 @pytest.mark.parametrize("n,extent,cin,cout,kind", [(13001, (40, 40, 16), 256, 256, "k3"), (3000, (24, 24, 10), 256, 256, "k3"),

@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _force(hip, mode):
-    hip.lib.ph_conv_win_force.argtypes = [C.c_int]
-    hip.lib.ph_conv_win_force(mode)
+    """ph_conv_desc.route of this thread's launches: 1 = the window kernel whatever the map's locality, -1 = never, 0 = the library decides"""
+    from pasco_amd.me.backend import ROUTE_WIN_ALWAYS, ROUTE_WIN_NEVER
+    hip.set_route({1: ROUTE_WIN_ALWAYS, -1: ROUTE_WIN_NEVER, 0: 0}[mode])
 
 
 def s10_map(hip, shuffle=False, n=None, generative=False):

@@ -11,6 +11,9 @@ from pasco_amd.graph.synth import make_occupancy
 from pasco_amd.me.backend import hip_backend
 from pasco_amd.me.core import kernel_offsets
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from devlib import use_dev_library   # noqa: E402
+use_dev_library()      # the hooks below exist only in the development build (-DPH_DEV)
 be = hip_backend()
 lib = be.lib
 lib.ph_conv_dma_set_ablate.argtypes = [C.c_int]

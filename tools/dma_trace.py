@@ -15,6 +15,9 @@ from pasco_amd.graph.synth import TeacherKeep, make_scene
 from pasco_amd.me.backend import hip_backend
 
 dev = torch.device("cuda", 0)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from devlib import use_dev_library   # noqa: E402
+use_dev_library()      # the hooks below exist only in the development build (-DPH_DEV)
 be = hip_backend()
 net = bench.build_net(3, 283, dev)
 scene = make_scene(0, n_infers=3).to(dev)

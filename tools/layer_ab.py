@@ -25,6 +25,9 @@ masks = [int(v, 0) for v in sys.argv[2:]] or [0, 1]
 min_us = float(os.environ.get("LAYER_AB_MIN_US", "40"))
 n_infers = int(os.environ.get("LAYER_AB_M", "3"))
 dev = torch.device("cuda", 0)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from devlib import use_dev_library   # noqa: E402
+use_dev_library()      # the hooks below exist only in the development build (-DPH_DEV)
 be = hip_backend()
 net = bench.build_net(n_infers, 283, dev)
 scene = make_scene(0, n_infers=n_infers).to(dev)

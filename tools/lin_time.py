@@ -11,6 +11,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pasco_amd.me.backend import hip_backend   # noqa: E402
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from devlib import use_dev_library   # noqa: E402
+use_dev_library()      # the hooks below exist only in the development build (-DPH_DEV)
 be = hip_backend()
 lib = be.lib
 lib.ph_conv_lin_set.argtypes = [C.c_int]

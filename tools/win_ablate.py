@@ -11,6 +11,9 @@ from pasco_amd.graph.synth import TeacherKeep, make_scene
 from pasco_amd.me.backend import hip_backend
 
 dev = torch.device("cuda", 0)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from devlib import use_dev_library   # noqa: E402
+use_dev_library()      # the hooks below exist only in the development build (-DPH_DEV)
 be = hip_backend()
 net = bench.build_net(3, 283, dev)
 scene = make_scene(0, n_infers=3).to(dev)
@@ -34,7 +37,6 @@ with torch.no_grad():
 be.conv_fwd = inner
 lib = be.lib
 lib.ph_conv_dma_set_ablate.argtypes = [C.c_int]
-lib.ph_conv_win_force.argtypes = [C.c_int]
 for key, rec in want.items():
     if rec is None:
         continue
@@ -42,7 +44,7 @@ for key, rec in want.items():
     print(key, n_out, "window stats", kw["win"]["stats"].tolist(), "tiles", (n_out + 127) // 128,
           "mean cnt", float(kw["win"]["cnt"].float().mean()))
     for force, fname in ((1, "windows"), (-1, "gather")):
-        lib.ph_conv_win_force(force)
+        be.set_route({1: 1, -1: 2, 0: 0}[force])
         for mask, name in ((0, "full"), (1, "no MFMA"), (8, "no fragment reads"), (9, "no MFMA, no frag reads"),
                            (2, "no window reload"), (4, "no weight DMA"), (15, "loop skeleton only")):
             lib.ph_conv_dma_set_ablate(mask)
@@ -56,4 +58,4 @@ for key, rec in want.items():
                 ts.append(e0.elapsed_time(e1) * 1e3)
             print(f"  {fname:8s} {name:26s} {min(ts[1:]):8.1f} us", flush=True)
     lib.ph_conv_dma_set_ablate(0)
-    lib.ph_conv_win_force(0)
+    be.set_route(0)
