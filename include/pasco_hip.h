@@ -38,7 +38,7 @@ extern "C" {
 /* 2: ph_conv_desc grew (split_exp2, out_split, window / axis-table / row-list blocks), ph_map_insert and ph_split_rows gained
  * their `status` argument.  A caller built against another version must be rebuilt: the binding checks the version AND the size
  * of ph_conv_desc before the first call.
- * 3: ph_panop_*.  4: ph_conv_desc.route (was reserved2) replaces the process-global test hooks of rounds 2 - 5. */
+ * 3: ph_panop_*.  4: ph_conv_desc.route (was reserved2) replaces the process-global test hooks of rounds 2 - 5; w_frag. */
 #define PH_ABI_VERSION 4
 #define PH_MAX_KVOL 64 /* largest kernel volume of one nbr_build / pooling call (4x4x4 window); conv_fwd takes tables of up to 4096 offsets (dense bottleneck: 7x7x5 = 245) */
 
@@ -231,6 +231,12 @@ typedef struct ph_conv_desc {
    * exact_if = this word and the same `out`: the exact fp32 result replaces the split one exactly when it has to.  What
    * the plain MinkowskiConvolution modules of pasco_amd.me do (round 5). */
   const int32_t *exact_if;
+  /* mode 2, optional, cout <= 64 and kvol == 27: the rows of w_split once more in FRAGMENT ORDER for the window kernel of the
+   * 64-wide outputs (conv_wop.hip): f16 [kvol][cpad / 16][2][2][64][8] - per (offset, 16-channel chunk c, column block j of 32,
+   * hi / lo) the 64 lanes' 16 bytes back to back: lane l31 + 32 h holds channels 16 c + 8 h .. + 7 of column min(32 j + l31,
+   * cout - 1).  A fragment load then reads 1 KB of whole cache lines instead of 32 bytes of each of 32 rows (round 6: the
+   * weight loads were what saturated the vector-memory path of that kernel).  Same values as w_split; NULL = not given. */
+  const void *w_frag;
 } ph_conv_desc;
 
 int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);

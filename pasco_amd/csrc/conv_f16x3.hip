@@ -642,6 +642,7 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   ConvArgsH a;
   a.in_split = (const _Float16 *)d->in_split;
   a.w_split = (const _Float16 *)d->w_split;
+  a.w_frag = (const _Float16 *)d->w_frag;
   a.cpad = (d->cin + 31) / 32 * 32;
   a.out_split = (_Float16 *)d->out_split;
   a.osp_scale = d->osp_scale;

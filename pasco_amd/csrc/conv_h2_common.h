@@ -36,6 +36,7 @@ struct ConvArgsH {
   // mode 2 (both operands pre-split by ph_split_rows): rows of cpad/32 groups [hi x32 | lo x32]
   const _Float16 *in_split;   // [n_in][cpad/32][2][32]
   const _Float16 *w_split;    // [kvol][cout][cpad/32][2][32]
+  const _Float16 *w_frag;     // optional (ph_conv_desc.w_frag): the same values in fragment order [kvol][cpad/16][2][2][64][8]
   int cpad;
   // optional second output: split operand of act(out * osp_scale + osp_shift) for the next convolution
   _Float16 *out_split;        // [n_out][cout/32][2][32]  (cout % 32 == 0)
@@ -122,6 +123,8 @@ const char *ph_dma_zero_line();
 int ph_dma_ablate_bits();   // 0 in the product library (development build: tools/dma_ablate.py)
 // conv_win.hip
 int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st);
+// conv_wop.hip: the window kernel of the 64-wide outputs (args.n_row_tiles set by the caller)
+int ph_conv_wop2_launch(const ConvArgsH &args, int tiles_per_wg, hipStream_t st);
 
 // conv_f16x3.hip: reduction + epilogue of a split over the kernel offsets (after a launch with args.ksplit > 1)
 int ph_launch_splitk_epilogue(const ConvArgsH &args, hipStream_t st);

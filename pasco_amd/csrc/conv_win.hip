@@ -922,10 +922,14 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st) {
   if (bn == 64) {
     b.win_which = 0 | ph_win_force_bits(b.route);
     static const bool wop = [] { const char *e = PH_DEV_ENV("PASCO_WIN_OFFSET_PARALLEL"); return e == nullptr || atoi(e) != 0; }();
-    if (wop && b.cout <= 64) {       // offset-parallel waves (k_conv_wop); PASCO_WIN_OFFSET_PARALLEL=0: the row-parallel kernel
+    // round 6: k_conv_wop2 (conv_wop.hip: 16-channel chunks in two window buffers, T tiles per workgroup); development build:
+    // PASCO_WOP=0 the round-4 kernel, 1 / 2 tiles per workgroup
+    static const int wop2 = [] { const char *e = PH_DEV_ENV("PASCO_WOP"); return e == nullptr ? 1 : atoi(e); }();
+    if (wop && b.cout <= 64) {       // offset-parallel waves; PASCO_WIN_OFFSET_PARALLEL=0: the row-parallel kernel
       ConvArgsH args = b;
       args.n_row_tiles = (int)((b.n_out + WIN_BM - 1) / WIN_BM);
       args.n_col_tiles = 1;
+      if (wop2 > 0) return ph_conv_wop2_launch(args, wop2 >= 2 ? 2 : 1, st);
       const int grid = ((args.n_row_tiles + 7) / 8) * 8;
       // the phase trace (tools/wop_trace.py) exists only for the non-emitting instantiation: a launch that has to write the next
       // layer's operand is never traced (it would silently leave that operand unwritten)

@@ -69,7 +69,7 @@ class ConvDesc(C.Structure):
         ("win_rows", _vp), ("win_cnt", _vp), ("win_slots", _vp), ("win_stats", _vp),
         ("axis_table", _vp), ("axis_coords", _vp), ("axis_lo", _i32), ("axis_rows", _i32),
         ("rl_in", _vp), ("rl_out", _vp), ("rl_tile_k", _vp), ("rl_rows", _i64), ("rl_tiles", _i32),
-        ("exact_if", _vp),
+        ("exact_if", _vp), ("w_frag", _vp),
     ]
 
 
@@ -541,6 +541,8 @@ class CBackend:
                 if win is not None and kvol == 27 and nbr is not None:
                     d.win_rows, d.win_cnt, d.win_slots, d.win_stats = (_ptr(win["rows"]), _ptr(win["cnt"]),
                                                                        _ptr(win["slots"]), _ptr(win["stats"]))
+                    if 32 < cout <= 64 and self._serves_cuda:       # the window kernel of the 64-wide outputs reads its weights in
+                        d.w_frag = _ptr(self.weight_fragments(w_split, kvol, cout, cpad))     # fragment order (cached on w_split)
             else:                  # (w_hi, w_lo, unscale) from split_weight_f16: mode 1, activations split in-kernel
                 w_hi, w_lo, unscale = split
                 d.mma_mode, d.w_f16_hi, d.w_f16_lo = 1, _ptr(w_hi), _ptr(w_lo)
@@ -723,6 +725,26 @@ class CBackend:
         k, cin, cout = w.shape
         rows = (w * float(2.0 ** e)).transpose(1, 2).contiguous().view(k * cout, cin)   # exact power of two
         return self.split_rows(rows, exp2=0), float(2.0 ** (-e))
+
+    @staticmethod
+    def weight_fragments(w_split: torch.Tensor, kvol: int, cout: int, cpad: int) -> torch.Tensor:
+        """`ph_conv_desc.w_frag`: the rows of `w_split` (f16 [kvol * cout, cpad / 32, 2, 32]) in the fragment order of the 64-wide
+        window kernel - f16 [kvol, cpad / 16, 2 (column block), 2 (hi, lo), 64 (lane = l31 + 32 h), 8]: lane's 8 channels
+        16 c + 8 h .. + 7 of column min(32 j + l31, cout - 1).  A pure permutation, made once per kernel tensor (kept on it)."""
+        hit = getattr(w_split, "_ph_wfrag", None)
+        if hit is not None and hit[0] == (w_split._version, kvol, cout, cpad):
+            return hit[1]
+        g = cpad // 32
+        ws = w_split.view(kvol, cout, g, 2, 2, 2, 8)               # [k, n, group, part, s = chunk parity, h, q]
+        rows = torch.arange(64, device=w_split.device).clamp_(max=cout - 1)
+        ws = ws.index_select(1, rows).view(kvol, 2, 32, g, 2, 2, 2, 8)     # [k, j, l31, group, part, s, h, q]
+        frag = ws.permute(0, 3, 5, 1, 4, 6, 2, 7).contiguous()     # [k, group, s, j, part, h, l31, q]: chunk c = 2 group + s
+        frag = frag.view(kvol, 2 * g, 2, 2, 64, 8)
+        try:
+            w_split._ph_wfrag = ((w_split._version, kvol, cout, cpad), frag)
+        except AttributeError:
+            pass
+        return frag
 
     def split_capable(self) -> bool:
         return self.device_type == "cuda" or self.checker_split

@@ -83,7 +83,7 @@ def _conv_case(hip, nbr, cin, cout, g, emit=False):
     return x, w, kw
 
 
-@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (64, 128), (256, 256)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (64, 128), (256, 256), (128, 64), (32, 64)])
 def test_window_conv_equals_gather_conv(hip, cin, cout):
     """The same launch with and without window tables on the S10 map (windows chosen by the device-side predicate)."""
     nbr = s10_map(hip, n=90112 if cin == 256 else 300032, generative=True)
@@ -124,7 +124,8 @@ def test_window_conv_equals_gather_conv(hip, cin, cout):
     hip.check_status(x.device)
 
 
-@pytest.mark.parametrize("cin,cout,n", [(64, 64, None), (128, 128, None), (64, 64, 129), (256, 256, None), (128, 256, 300)])
+@pytest.mark.parametrize("cin,cout,n", [(64, 64, None), (128, 128, None), (64, 64, 129), (256, 256, None), (128, 256, 300),
+                                       (64, 64, 300), (128, 64, None), (32, 64, 1000), (64, 64, 1)])
 def test_window_conv_multi_pass_and_ragged(hip, oracle, cin, cout, n):
     """A shuffled map has no locality (windows of > 1000 rows): forced onto the window kernel it runs 3 - 5 passes
     per tile; the result must still be the convolution (oracle on fp32 operands).  n = 129: a ragged second tile."""

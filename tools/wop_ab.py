@@ -1,0 +1,115 @@
+"""k_conv_wop2 (conv_wop.hip, round 6) against the round-4 window kernel on the 64-channel 3^3 launches of ONE benchmark step, same
+process, interleaved: [old] = the development library with PASCO_WOP=0 (k_conv_wop, round 4), [T1] = the same with PASCO_WOP=1 (k_conv_wop2, one tile per
+workgroup), [T2] = the product library's default.  Outputs are compared with
+the base library's (another fp32 summation order: max |a - b| / mean |b| printed).
+
+    python tools/wop_ab.py [out.txt]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from pasco_amd.build import build_hip
+from pasco_amd.graph.synth import TeacherKeep, make_scene
+from pasco_amd.me.backend import CBackend, hip_backend
+
+out_path = sys.argv[1] if len(sys.argv) > 1 else None
+dev = torch.device("cuda", 0)
+be = hip_backend()
+net = bench.build_net(3, 283, dev)
+scene = make_scene(0, n_infers=3).to(dev)
+tk = TeacherKeep(scene, dev)
+layers = {}
+inner = be.conv_fwd
+
+
+def spy(x, weight, nbr, n_out, **kw):
+    out = inner(x, weight, nbr, n_out, **kw)
+    cfg = be.conv_last_config()
+    shape = tuple(kw["wshape"]) if weight is None else tuple((weight if weight.dim() == 3 else weight[None]).shape)
+    if cfg["kernel"] == 5 and shape[2] <= 64:
+        key = (shape, n_out, kw.get("emit_split") is not None, kw.get("residual") is not None, kw.get("want_out", True))
+        rec = layers.get(key)
+        if rec is None:
+            layers[key] = [1, (x, weight, nbr, n_out, dict(kw))]
+        else:
+            rec[0] += 1
+    return out
+
+
+with torch.no_grad():
+    bench.run_scene(net, scene, tk)
+    be.conv_fwd = spy
+    bench.run_scene(net, scene, tk)
+    be.conv_fwd = inner
+import shutil
+import tempfile
+dev_lib = build_hip(dev=True, verbose=False)
+tmpd = tempfile.mkdtemp()
+libs = {}
+first = next(iter(layers.values()))[1]
+for name, sel in (("old", "0"), ("T1", "1")):       # one copy of the development library per setting (the switch is read once per load)
+    path = os.path.join(tmpd, f"libpascohip_dev_{name}.so")
+    shutil.copy(dev_lib, path)
+    os.environ["PASCO_WOP"] = sel
+    libs[name] = CBackend(path, "ph_", "cuda")
+    x, weight, nbr, n_out, kw = first
+    kw = {k: v for k, v in kw.items() if k not in ("out", "out_split")}
+    libs[name].conv_fwd(x, weight, nbr, n_out, **kw)      # first launch: the setting is latched
+    torch.cuda.synchronize()
+libs["T2"] = be
+names = list(libs)
+
+
+def run(lib, rec):
+    x, weight, nbr, n_out, kw = rec
+    kw = dict(kw)
+    kw.pop("out", None)               # every library writes its own output
+    kw.pop("out_split", None)
+    return lib.conv_fwd(x, weight, nbr, n_out, **kw)
+
+
+def timed(lib, rec):
+    ts = []
+    for _ in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run(lib, rec)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return min(ts[1:])
+
+
+def flat(o):
+    return [t.float().flatten() for t in (o if isinstance(o, tuple) else (o,)) if t is not None]
+
+
+lines = []
+tot = {n: 0.0 for n in names}
+for key, (cnt, rec) in sorted(layers.items(), key=lambda kv: -kv[0][1] * kv[1][0]):
+    shape, n_out, emit, res, want = key
+    ref = flat(run(libs[names[0]], rec))
+    errs = []
+    for n in names[1:]:
+        got = flat(run(libs[n], rec))
+        errs.append(max(float((g - r).abs().max() / r.abs().mean().clamp_min(1e-30)) for g, r in zip(got, ref)))
+    t = {}
+    for _ in range(2):                       # interleaved, best of two rounds
+        for n in names:
+            v = timed(libs[n], rec)
+            t[n] = min(t.get(n, 1e30), v)
+    for n in names:
+        tot[n] += cnt * t[n]
+    line = f"k{shape[0]} {shape[1]:3d}->{shape[2]:<3d} n={n_out:7d} {'E' if emit else '-'}{'R' if res else '-'}{'o' if want else '-'} x{cnt:2d}  " + \
+        "  ".join(f"[{n}] {t[n]:7.1f}" for n in names) + "   err vs " + names[0] + ": " + " ".join(f"{e:.1e}" for e in errs)
+    print(line, flush=True)
+    lines.append(line)
+line = "us/step: " + "  ".join(f"[{n}] {tot[n]:9.1f}" for n in names)
+print(line)
+lines.append(line)
+if out_path:
+    open(out_path, "w").write("\n".join(lines) + "\n")
