@@ -124,7 +124,7 @@ int ph_dma_ablate_bits();   // 0 in the product library (development build: tool
 // conv_win.hip
 int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st);
 // conv_wop.hip: the window kernel of the 64-wide outputs (args.n_row_tiles set by the caller)
-int ph_conv_wop2_launch(const ConvArgsH &args, int tiles_per_wg, hipStream_t st);
+int ph_conv_wop2_launch(const ConvArgsH &args, hipStream_t st);
 
 // conv_f16x3.hip: reduction + epilogue of a split over the kernel offsets (after a launch with args.ksplit > 1)
 int ph_launch_splitk_epilogue(const ConvArgsH &args, hipStream_t st);

@@ -567,330 +567,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) k_conv_win(ConvArgsH a) {
   h2_store_tile<TM, TN, EMIT>(a, acc, m0, n0, wm, wn, h, l31);
 }
 
-// ---- the 64-wide convolution, OFFSET-PARALLEL waves (round 4) --------------------------------------------------------------
-// What held k_conv_win<4, 4, 1, 1, 2> (the 64-channel 3^3 layers, the largest class of a step) at 0.23 of the matrix peak
-// (profiles/r3u_pmc_window_kernel.txt): a 32 x 64 wave tile needs 12 fragment reads (4 activation + 8 weight, 16 bytes per
-// lane each) per 12 MFMAs, every wave of the workgroup reads the SAME weight tile from LDS, and the weight ring costs one
-// workgroup barrier per 12 MFMAs (28 % of the wave cycles in counter / barrier waits).  Here the four waves split the 27
-// KERNEL OFFSETS instead of the tile's rows: wave w owns offsets w, w + 4, ... and multiplies ALL 128 rows x 64 columns for
-// them (accumulators 4 x 2 x 16 registers).  Then
-//   * a weight fragment is used by one wave only: it is loaded global -> registers (L2-resident, 16 bytes per lane, half a
-//     stage ahead), no LDS ring, NO BARRIER in the offset loop - waves free-run between the window loads;
-//   * per half-stage (one offset, 16 of the chunk's 32 channels) a wave reads 8 activation fragments from the window for
-//     24 MFMAs: a third of the LDS read traffic per MFMA;
-//   * at the end of the tile the four partial accumulators are summed through LDS in a fixed order (own part, then the
-//     other waves' ascending) and wave i stores row block i with the common epilogue.
-// Same products as k_conv_win, another fp32 summation order (per wave: pass, chunk, own offsets; then across waves).
-// The offset loop is scheduled by hand (inline-asm loads with counted waits; left to the compiler the weight loads were sunk
-// behind the MFMAs that precede them and every fragment read was waited for one by one): per half-stage
-//     issue the 4 weight loads of the NEXT half-stage           (vmcnt: waited at the end of this half-stage)
-//     wait for the fragments of row blocks 0, 1 -> 12 MFMAs -> issue their reads for the next half-stage
-//     wait for the fragments of row blocks 2, 3 -> 12 MFMAs -> issue their reads for the next half-stage
-// so LDS and L2 latencies run under the MFMAs of the same wave, and the second wave of the SIMD fills what is left.
-__device__ __forceinline__ f16x8 wop_gld(const char *p) {
-  f16x8 v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-__device__ __forceinline__ f16x8 wop_lds(uint32_t addr) {
-  f16x8 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-__device__ __forceinline__ uint32_t wop_lds16(uint32_t addr) {
-  uint32_t v;
-  asm volatile("ds_read_u16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-struct WopW {
-  f16x8 bh[2], bl[2];
-};
-struct WopA {                 // activation fragments of two row blocks: [block][hi, lo]
-  f16x8 h[2], l[2];
-};
-#define WOP_WAIT_VM0(w) asm volatile("s_waitcnt vmcnt(0)" : "+v"((w).bh[0]), "+v"((w).bh[1]), "+v"((w).bl[0]), "+v"((w).bl[1])::"memory")
-#define WOP_WAIT_LGKM(n, f) \
-  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"((f).h[0]), "+v"((f).h[1]), "+v"((f).l[0]), "+v"((f).l[1])::"memory")
-
-#ifdef PH_DEV
-// development build only (tools/wop_trace.py): shader-clock stamps of the phases of the first 64 workgroups (wave 0), TRACE instantiation
-__device__ unsigned long long g_wop_trace[64 * 16];
-static int g_wop_trace_on = 0;
-extern "C" void ph_wop_trace_enable(int on) { g_wop_trace_on = on; }
-extern "C" int ph_wop_trace_read(unsigned long long *host_out) {
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wop_trace), sizeof(g_wop_trace)) == hipSuccess ? 0 : 2;
-}
-#define WOP_STAMP(i)                                                                                   \
-  do {                                                                                                 \
-    if (TRACE && tid == 0 && blockIdx.x < 64) g_wop_trace[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
-  } while (0)
-#else
-#define WOP_STAMP(i) do { } while (0)
-#endif
-
-template <int WMAX, bool EMIT, bool TRACE = false>
-__global__ void __launch_bounds__(256, 2) k_conv_wop(ConvArgsH a) {
-  constexpr int NT = 256;
-  constexpr int RPP = NT / 8;                       // window rows one DMA pass covers
-  constexpr int BM = WIN_BM;
-  constexpr int W_PASSES = WMAX / RPP;
-  static_assert(WMAX % RPP == 0, "window capacity vs DMA pass");
-  constexpr int WIN_BYTES = (WMAX + 1) * 128;       // + the zero row
-  constexpr int OFF_SLOT = WIN_BYTES;
-  constexpr int OFF_WIDX = OFF_SLOT + WIN_CAP * 2;
-  __shared__ __attribute__((aligned(128))) char lds[OFF_WIDX + WMAX * 4];
-
-  const int nwg = gridDim.x;
-  const int cpx = nwg >> 3;
-  const int bid = blockIdx.x;
-  const int row_tile = (bid & 7) * cpx + (bid >> 3);
-  if (row_tile >= a.n_row_tiles) return;
-  const int64_t m0 = (int64_t)row_tile * BM;
-  // Everything the tile needs from global memory before its first window is requested AT ONCE (the statistics of the
-  // predicate, the slot map, the window's row list, the row count; the dependent chain predicate -> slot map -> row list ->
-  // window cost four round trips = 11 % of a workgroup's life, tools/wop_trace.py): one round trip, then the window DMA.
-  const int32_t st_w = a.win_stats[a.win_which & 1];
-  uint4 slot_raw[2];
-  int32_t widx_raw[2];
-  {
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.win_slots + (int64_t)row_tile * WIN_CAP);
-    const int32_t *wrp = a.win_rows + (int64_t)row_tile * WIN_CAP;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int i = (int)threadIdx.x + q * NT;
-      slot_raw[q] = i < WIN_CAP * 2 / 16 ? src[i] : make_uint4(0, 0, 0, 0);
-      widx_raw[q] = i < WMAX ? wrp[i] : -1;
-    }
-  }
-  const int cnt = a.win_cnt[row_tile];
-  {
-    const int which = a.win_which;       // ph_win_pred on the value loaded above
-    const bool windows = (which & 0x100) ? true : ((which & 0x200) ? false : (int64_t)st_w * 4 <= (int64_t)a.n_row_tiles * 5);
-    if (!windows) return;                // the gather kernel serves this map
-  }
-
-  const int tid = threadIdx.x;
-  WOP_STAMP(0);
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5;
-  const int l31 = lane & 31;
-  const int cout = a.cout;
-  const int nchunks = a.cpad >> 5;
-  const uint32_t rsb = 4u * (uint32_t)a.cpad;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  static_assert(WIN_CAP * 2 / 16 <= 2 * NT && WMAX <= 2 * NT, "two loads per thread cover the slot map and the row list");
-  int *widx = reinterpret_cast<int *>(lds + OFF_WIDX);
-  {   // tile constants: slot map, first pass's row list, zero row -> LDS
-    uint4 *dst = reinterpret_cast<uint4 *>(lds + OFF_SLOT);
-    const int wp0 = cnt < WMAX ? cnt : WMAX;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int i = tid + q * NT;
-      if (i < WIN_CAP * 2 / 16) dst[i] = slot_raw[q];
-      if (i < WMAX) widx[i] = i < wp0 ? widx_raw[q] : -1;
-    }
-    if (tid < 8) reinterpret_cast<uint4 *>(lds + WMAX * 128)[tid] = make_uint4(0, 0, 0, 0);
-  }
-  const int npass = cnt > 0 ? (cnt + WMAX - 1) / WMAX : 1;
-
-  // window DMA geometry (as k_conv_win)
-  const int l_j = tid & 7;
-  const int l_r = tid >> 3;
-  const uint32_t sj16 = (uint32_t)((l_j ^ ((l_r >> 1) & 7)) << 4);
-  const uint64_t in_base = (uint64_t)reinterpret_cast<uintptr_t>(a.in_split) + sj16;
-  const uint64_t zero_src = (uint64_t)reinterpret_cast<uintptr_t>(a.zero) + sj16;
-
-  // weight fragments: lane (column l31 of column block j, k-slots 8 h .. 8 h + 7 of the half-stage) = 16 bytes of row
-  // (k * cout + column) of the weight operand, hi at + 0, lo at + 64 of the chunk's 128-byte group
-  const char *wrow[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int n = j * 32 + l31;
-    n = n < cout ? n : cout - 1;
-    wrow[j] = reinterpret_cast<const char *>(a.w_split) + (uint64_t)n * rsb + h * 16;
-  }
-  const uint64_t wslab = (uint64_t)cout * rsb;
-  auto load_w = [&](int k, int chunk, int ks, WopW &f) {
-    const uint64_t off = (uint64_t)k * wslab + ((uint32_t)chunk << 7) + (uint32_t)(ks * 32);
-    f.bh[0] = wop_gld(wrow[0] + off);
-    f.bl[0] = wop_gld(wrow[0] + off + 64);
-    f.bh[1] = wop_gld(wrow[1] + off);
-    f.bl[1] = wop_gld(wrow[1] + off + 64);
-  };
-  // this wave's offsets: wave, wave + 4, ... (7, 7, 7, 6 of them)
-  const int nk = (WIN_KV - wave + 3) >> 2;
-  const uint32_t slot_rd = lds0 + (uint32_t)OFF_SLOT + (uint32_t)(l31 * 2);      // + (k * 128 + 32 i) * 2
-
-  // fragment reads of two row blocks (i0, i0 + 1) of a half-stage: window rows wr (128-byte rows, 16-byte granules swizzled by
-  // (row >> 1) & 7; hi granules 0..3, lo granules 4..7 of the chunk)
-  auto issue_a = [&](const uint32_t (&wr)[4], int ks, int i0, WopA &f) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const uint32_t r = wr[i0 + u];
-      const uint32_t sw = (r >> 1) & 7u;
-      const uint32_t ab = lds0 + r * 128u;
-      f.h[u] = wop_lds(ab + (((uint32_t)(ks * 2 + h) ^ sw) << 4));
-      f.l[u] = wop_lds(ab + (((uint32_t)(4 + ks * 2 + h) ^ sw) << 4));
-    }
-  };
-  auto mfma12 = [&](const WopW &w, const WopA &f, int i0) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[i0 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bh[j], f.l[u], acc[i0 + u][j], 0, 0, 0);
-        acc[i0 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bl[j], f.h[u], acc[i0 + u][j], 0, 0, 0);
-        acc[i0 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bh[j], f.h[u], acc[i0 + u][j], 0, 0, 0);
-      }
-  };
-
-  WopW w0, w1;
-  load_w(wave, 0, 0, w0);
-  for (int pass = 0; pass < npass; ++pass) {
-    const int base = pass * WMAX;
-    const int wp = cnt - base < WMAX ? cnt - base : WMAX;
-    if (pass > 0) {                                  // further passes (windows beyond the LDS capacity): their row list
-      __syncthreads();                               // the previous pass's window and row list are no longer read
-      const int32_t *wrp = a.win_rows + (int64_t)row_tile * WIN_CAP + base;
-      for (int i = tid; i < WMAX; i += NT) widx[i] = i < wp ? wrp[i] : -1;
-    }
-    __syncthreads();
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-      const uint32_t coff = (uint32_t)chunk << 7;
-      if (chunk > 0) __syncthreads();                // every wave is done reading the previous chunk's window
-#pragma unroll
-      for (int p = 0; p < W_PASSES; ++p) {
-        if (p * RPP < wp) {                          // uniform
-          const int ix = widx[p * RPP + l_r];
-          uint64_t v = in_base + (uint64_t)(uint32_t)(ix < 0 ? 0 : ix) * rsb + coff;
-          asm volatile("" : "+v"(v));
-          const uint64_t src = ix >= 0 ? v : zero_src;
-          char *dst = lds + (p * RPP + wave * 8) * 128;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)src,
-                                           (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        }
-      }
-      WOP_STAMP(1 + 3 * (chunk & 1));
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the window and the prefetched weights w0
-      __builtin_amdgcn_s_barrier();
-      WOP_STAMP(2 + 3 * (chunk & 1));
-      const bool last_chunk = chunk + 1 == nchunks && pass + 1 == npass;
-      const int cnext = last_chunk ? chunk : (chunk + 1 == nchunks ? 0 : chunk + 1);
-      // window rows of the first offset's entries (zero row: no neighbour / a row of another pass)
-      uint32_t wr[4], sl[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sl[i] = wop_lds16(slot_rd + (uint32_t)((wave * BM + i * 32) * 2));
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3])::"memory");
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t local = sl[i] - (uint32_t)base;
-        wr[i] = local < (uint32_t)wp ? local : (uint32_t)WMAX;
-      }
-      for (int t = 0; t < nk; ++t) {
-        const int k = wave + 4 * t;
-        const bool more = t + 1 < nk;                // uniform
-        WopA fa, fb;
-        // ---- half-stage (k, first 16 channels of the chunk): weights w0 (landed)
-        __builtin_amdgcn_sched_barrier(0);
-        issue_a(wr, 0, 0, fa);
-        issue_a(wr, 0, 2, fb);
-        load_w(k, chunk, 1, w1);
-        if (more) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) sl[i] = wop_lds16(slot_rd + (uint32_t)(((k + 4) * BM + i * 32) * 2));
-          WOP_WAIT_LGKM(8, fa);
-        } else {
-          WOP_WAIT_LGKM(4, fa);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma12(w0, fa, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_a(wr, 1, 0, fa);
-        if (more) WOP_WAIT_LGKM(8, fb);
-        else WOP_WAIT_LGKM(4, fb);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma12(w0, fb, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_a(wr, 1, 2, fb);
-        WOP_WAIT_VM0(w1);
-        // ---- half-stage (k, second 16 channels): weights w1; w0 <- the next offset's (or the next chunk's first)
-        __builtin_amdgcn_sched_barrier(0);
-        load_w(more ? k + 4 : wave, more ? chunk : cnext, 0, w0);
-        WOP_WAIT_LGKM(4, fa);                        // the next offset's slots landed before these fragments
-        asm volatile("" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3]));
-        __builtin_amdgcn_sched_barrier(0);
-        mfma12(w1, fa, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        WOP_WAIT_LGKM(0, fb);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma12(w1, fb, 2);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t local = sl[i] - (uint32_t)base;
-          wr[i] = local < (uint32_t)wp ? local : (uint32_t)WMAX;
-        }
-        WOP_WAIT_VM0(w0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      WOP_STAMP(3 + 3 * (chunk & 1));
-    }
-  }
-
-  // ---- sum of the four partial accumulators: wave i ends up with row block i ---------------------------------------------
-  __syncthreads();                                   // the window is free
-  WOP_STAMP(7);
-  // two rounds of two row blocks: in round b the waves write their partial sums of blocks 2 b and 2 b + 1 (the owner keeps its
-  // own), waves 2 b and 2 b + 1 sum them up: own part first, then the other waves' ascending - a fixed order
-  float *red = reinterpret_cast<float *>(lds);       // [block in round][writer: the 3 other waves][j][r][lane]: 2 x 3 x 8 KB
-  static_assert(WIN_BYTES >= 2 * 3 * 2 * 16 * 64 * 4, "the reduction reuses the window");
-  f32x16 fin[1][2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int i = 2 * b + u;
-      if (wave != i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) red[(((u * 3 + (wave < i ? wave : wave - 1)) * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int i = 2 * b + u;
-      if (wave == i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          fin[0][j] = acc[i][j];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            if (s == i) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) fin[0][j][r] += red[(((u * 3 + (s < i ? s : s - 1)) * 2 + j) * 16 + r) * 64 + lane];
-          }
-        }
-      }
-    }
-    if (b == 0) __syncthreads();
-  }
-  WOP_STAMP(8);
-  h2_store_tile<1, 2, EMIT>(a, fin, m0, 0, wave, 0, h, l31);
-  WOP_STAMP(9);
-}
-
 template <int WAVES, int WM, int WN, int TM, int TN, int WMAX>
 static int launch_win(const ConvArgsH &a, hipStream_t st) {
   constexpr int BN = WN * TN * 32;
@@ -921,27 +597,14 @@ int ph_conv_win_launch(const ConvArgsH &a, int bn, hipStream_t st) {
   }
   if (bn == 64) {
     b.win_which = 0 | ph_win_force_bits(b.route);
-    static const bool wop = [] { const char *e = PH_DEV_ENV("PASCO_WIN_OFFSET_PARALLEL"); return e == nullptr || atoi(e) != 0; }();
-    // round 6: k_conv_wop2 (conv_wop.hip: 16-channel chunks in two window buffers, T tiles per workgroup); development build:
-    // PASCO_WOP=0 the round-4 kernel, 1 / 2 tiles per workgroup
-    static const int wop2 = [] { const char *e = PH_DEV_ENV("PASCO_WOP"); return e == nullptr ? 1 : atoi(e); }();
-    if (wop && b.cout <= 64) {       // offset-parallel waves; PASCO_WIN_OFFSET_PARALLEL=0: the row-parallel kernel
+    // 64-wide outputs: offset-parallel waves on 16-channel chunks (conv_wop.hip, round 6) when the caller gave the fragment-order
+    // copy of the kernel; else (and PASCO_WOP=0 in the development build) the row-parallel window kernel below
+    static const bool wop2 = [] { const char *e = PH_DEV_ENV("PASCO_WOP"); return e == nullptr || atoi(e) != 0; }();
+    if (wop2 && b.cout <= 64 && b.w_frag != nullptr) {
       ConvArgsH args = b;
       args.n_row_tiles = (int)((b.n_out + WIN_BM - 1) / WIN_BM);
       args.n_col_tiles = 1;
-      if (wop2 > 0) return ph_conv_wop2_launch(args, wop2 >= 2 ? 2 : 1, st);
-      const int grid = ((args.n_row_tiles + 7) / 8) * 8;
-      // the phase trace (tools/wop_trace.py) exists only for the non-emitting instantiation: a launch that has to write the next
-      // layer's operand is never traced (it would silently leave that operand unwritten)
-#ifdef PH_DEV
-      if (g_wop_trace_on && args.out_split == nullptr)
-        hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, false, true>), dim3(grid), dim3(256), 0, st, args);
-      else
-#endif
-      if (args.out_split != nullptr) hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, true>), dim3(grid), dim3(256), 0, st, args);
-      else hipLaunchKernelGGL((k_conv_wop<WIN_MAX_64, false>), dim3(grid), dim3(256), 0, st, args);
-      PH_LAUNCH_CHECK();
-      return 0;
+      return ph_conv_wop2_launch(args, st);
     }
     return launch_win<4, 4, 1, 1, 2, WIN_MAX_64>(b, st);
   }

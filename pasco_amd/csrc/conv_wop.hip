@@ -1,21 +1,26 @@
 // Sparse 3^3 convolution of the 64-channel levels on LDS-resident input windows, round 6 (`k_conv_wop2`, kernel id 5 like the
 // kernel it replaces: the window side of a window / gather pair).
 //
-// What held k_conv_wop (conv_win.hip, round 4) at 0.25 of the f16 matrix peak (profiles/r4e_wop_trace_v3.txt, r5zz PMC: matrix
-// pipe 50 % busy): 35 % of a workgroup's life lies OUTSIDE its offset loops - the tile's tables (one round trip), the window
-// DMA of each 32-channel chunk (nothing to multiply while it flies), the reduction, the epilogue - and inside the loop a wave
-// alone on its SIMD (its partner workgroup being in one of those phases) stalls at the head of every offset on the LDS reads
-// it has just issued.  Same arithmetic here (offset-parallel waves: wave w owns offsets w, w + 4, ..., every weight fragment
-// global -> registers, 128 rows x 64 columns of accumulators per wave, partial sums added through LDS in a fixed order), but:
+// What held k_conv_wop (conv_win.hip, round 4) at 0.25 of the f16 matrix peak, measured this round with shader-clock stamps
+// on workgroups from the middle of the grid (tools/wop2_trace.py) and with parts of the kernel switched off
+// (tools/wop_ablate.py): a workgroup lives ~85 k clocks for 21.5 k clocks of matrix work per wave; 28 % of that life is outside
+// the offset loops (tables + first window 7 k, reduction 5.5 k, an epilogue of 11 k that serialised its four column groups on
+// the in-order vmcnt of loads behind stores), and inside the loops a wave ALONE on its SIMD (its partner workgroup being in
+// one of those phases) needs ~1 800 clocks per offset for 768 clocks of products: its own ~60 address instructions, 13 LDS /
+// memory instructions and their waits sit BETWEEN its groups of 12 MFMAs instead of under them.
+// Same arithmetic here (offset-parallel waves: wave w owns offsets w, w + 4, ..., every weight fragment global -> registers,
+// 128 rows x 64 columns of accumulators per wave, partial sums added through LDS in a fixed order), but:
 //   * 16-CHANNEL window chunks in TWO LDS buffers: the window of chunk c + 1 (64 bytes per row: 16 hi | 16 lo values) is
-//     DMA'd while chunk c multiplies - one DMA instruction per wave at the head of each of the 7 offsets, every one of them
-//     issued unconditionally (rows beyond the window read the zero line) so that the counted vmcnt waits are constants;
-//   * the offsets of a chunk are straight-line code (7 x 24 MFMAs, no branch, no loop-carried fragment copies): the
-//     fragments of offset t + 1 are requested under the products of offset t - rows 0..63 before the second group of 12
-//     MFMAs, rows 64..127 after it -, the slots of offset t + 1 at its head, the weights one whole offset ahead;
-//   * T tiles per workgroup: the next tile's slot map and row list are DMA'd into a second table buffer during the
-//     current tile, its first window during the current tile's last chunk - the set-up round trips are paid once per
-//     workgroup, and the next tile's window lands under the reduction and the epilogue's stores.
+//     DMA'd while chunk c multiplies - one DMA instruction per wave and offset, every one of them issued unconditionally
+//     (rows beyond the window read the zero line) so that the counted vmcnt waits are constants;
+//   * the slot map is turned into LDS BYTE OFFSETS once per tile and pass (in place, under the first window's DMA): slot ->
+//     row * 64 + swizzle, "no neighbour / other pass" -> the zero row: 3 address instructions per fragment pair instead of 15;
+//   * the offsets of a chunk are straight-line code (7 x 24 MFMAs) and every other instruction of an offset is placed in a gap
+//     BETWEEN two MFMAs: the next offset's addresses, the window DMA, the next offset's weights (one contiguous kilobyte per
+//     load instruction from the fragment-order copy of the kernel, ph_conv_desc.w_frag) under the first 12, the slot reads of
+//     the offset after next under the second 12; fragment reads between the groups, each a group of products ahead;
+//   * two rounds of reduction through both (by then free) window buffers, and the epilogue with every load ahead of its first
+//     store (h2_store_tile_staged).
 // Wave 3 owns 6 offsets; its seventh (k = 27) multiplies the zero row: no branch in the body.
 //
 // Summation order per accumulator: pass, 16-channel chunk, own offsets ascending; then across waves (own part first, the other
@@ -29,16 +34,14 @@ constexpr int W2_CAP = W2_BM * W2_KV;              // entries of a tile's slot m
 constexpr int W2_MAX = 448;                        // window rows per pass: 7 DMA passes of 64 rows
 constexpr int W2_ROWB = 64;                        // bytes of a window row
 constexpr int W2_WIN = (W2_MAX + 1) * W2_ROWB;     // + the zero row (index W2_MAX)
+constexpr int W2_ZOFS = W2_MAX * W2_ROWB;          // byte offset of the zero row (its swizzle is 0)
 constexpr int W2_TAB_SLOT = W2_CAP * 2;            // u16 slot map
 constexpr int W2_TAB = W2_TAB_SLOT + W2_MAX * 4;   // + the first W2_MAX entries of the row list
-constexpr int W2_PIECES = W2_TAB / 16;             // 16-byte pieces of a table buffer (544)
+constexpr int W2_PIECES = W2_TAB / 16;             // 16-byte pieces of the table buffer (544)
+constexpr int OFF_TAB = 2 * W2_WIN;
 static_assert(W2_TAB % 16 == 0 && W2_WIN % 64 == 0 && W2_TAB_SLOT % 16 == 0, "alignment of the LDS regions");
+static_assert(W2_ZOFS + 48 < 65536, "row offsets fit the u16 entries of the slot map");
 
-__device__ __forceinline__ f16x8 w2_gld(const char *p) {
-  f16x8 v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
 __device__ __forceinline__ f16x8 w2_lds(uint32_t addr) {
   f16x8 v;
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
@@ -62,11 +65,12 @@ struct W2A {                 // activation fragments of two row blocks
 };
 #define W2_PIN_W(w) "+v"((w).bh[0]), "+v"((w).bh[1]), "+v"((w).bl[0]), "+v"((w).bl[1])
 #define W2_PIN_A(f) "+v"((f).h[0]), "+v"((f).h[1]), "+v"((f).l[0]), "+v"((f).l[1])
+#define W2_SB() __builtin_amdgcn_sched_barrier(0)
 
 #ifdef PH_DEV
-// development build only (tools/wop_trace.py): shader-clock stamps of waves 0 and 3 of 64 workgroups from the middle of the grid -
+// development build only (tools/wop2_trace.py): shader-clock stamps of waves 0 and 3 of 64 workgroups from the middle of the grid -
 // per step: start, the middle of each of the 7 offsets, before / after the step's barrier; then reduction and epilogue.  A stamp is a
-// scalar memory read (it shares lgkmcnt with the counted LDS waits): only placed where the kernel waits for lgkmcnt(0) anyway.
+// scalar memory read (it shares lgkmcnt with the counted LDS waits): each is followed by a wait for lgkmcnt(0).
 constexpr int W2_TRACE_N = 64;
 __device__ unsigned long long g_w2_trace[64 * 2 * W2_TRACE_N];
 static int g_w2_trace_on = 0;
@@ -77,25 +81,26 @@ extern "C" int ph_wop2_trace_read(unsigned long long *host_out) {
 #define W2_STAMP(i)                                                                                                        \
   do {                                                                                                                     \
     const int i_ = (i);                                                                                                    \
-    if (TRACE && trace_wg >= 0 && lane == 0 && (wave == 0 || wave == 3) && i_ < W2_TRACE_N)                                \
-      reinterpret_cast<unsigned long long *>(lds + OFF_TAB + NTAB * W2_TAB)[(wave == 3 ? W2_TRACE_N : 0) + i_] =           \
-          __builtin_readcyclecounter();                                                                                    \
+    if (TRACE && trace_wg >= 0) {                                                                                          \
+      if (lane == 0 && (wave == 0 || wave == 3) && i_ < W2_TRACE_N)                                                        \
+        reinterpret_cast<unsigned long long *>(lds + OFF_TAB + W2_TAB)[(wave == 3 ? W2_TRACE_N : 0) + i_] =                \
+            __builtin_readcyclecounter();                                                                                  \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
+    }                                                                                                                      \
   } while (0)
 #else
 #define W2_STAMP(i) do { } while (0)
 #endif
 
-template <bool EMIT, int T, bool TRACE = false>
+template <bool EMIT, bool TRACE = false>
 __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
-  constexpr int NTAB = T > 1 ? 2 : 1;
-  constexpr int OFF_TAB = 2 * W2_WIN;
-  __shared__ __attribute__((aligned(128))) char lds[OFF_TAB + NTAB * W2_TAB + (TRACE ? 2 * 64 * 8 : 0)];
+  __shared__ __attribute__((aligned(128))) char lds[OFF_TAB + W2_TAB + (TRACE ? 2 * 64 * 8 : 0)];
 
   const int nwg = gridDim.x;
   const int cpx = nwg >> 3;
   const int bid = blockIdx.x;
-  const int tile0 = ((bid & 7) * cpx + (bid >> 3)) * T;
-  if (tile0 >= a.n_row_tiles) return;
+  const int tile = (bid & 7) * cpx + (bid >> 3);
+  if (tile >= a.n_row_tiles) return;
   {
     const int which = a.win_which;       // ph_win_pred
     const int32_t st_w = a.win_stats[which & 1];
@@ -106,6 +111,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < 4);
   const int trace_wg = (TRACE && (int)blockIdx.x >= (int)gridDim.x / 2 && (int)blockIdx.x < (int)gridDim.x / 2 + 64) ? (int)blockIdx.x - (int)gridDim.x / 2 : -1;
   (void)trace_wg;
   int stamp = 0;
@@ -113,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
   W2_STAMP(stamp++);
   const int h = lane >> 5;
   const int l31 = lane & 31;
-  const int cout = a.cout;
+  const uint32_t hx = (uint32_t)(h << 4);
   const uint32_t rsb = 4u * (uint32_t)a.cpad;
   const int nch = a.cpad >> 4;
 #ifdef PH_DEV
@@ -137,8 +143,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
   const uint64_t zero_src = (uint64_t)reinterpret_cast<uintptr_t>(a.zero) + (uint32_t)(l_j << 4);
   auto chunk_off = [](int c) -> uint32_t { return (uint32_t)((c >> 1) * 128 + (c & 1) * 32); };
 
-  // one table buffer <- slot map + head of the row list of `tile` (3 DMA instructions per wave at most)
-  auto tab_dma = [&](int tile, int tb) {
+  // the table buffer <- slot map + head of the row list of the tile (3 DMA instructions per wave at most)
+  auto tab_dma = [&]() {
     const char *sl = reinterpret_cast<const char *>(a.win_slots + (int64_t)tile * W2_CAP);
     const char *rw = reinterpret_cast<const char *>(a.win_rows + (int64_t)tile * W2_CAP);
 #pragma unroll
@@ -146,335 +152,304 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
       const int i = q * 256 + tid;
       if (i < W2_PIECES) {
         const char *src = i < W2_TAB_SLOT / 16 ? sl + i * 16 : rw + (i - W2_TAB_SLOT / 16) * 16;
-        char *dst = lds + OFF_TAB + tb * W2_TAB + (q * 256 + wave * 64) * 16;
+        char *dst = lds + OFF_TAB + (q * 256 + wave * 64) * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
       }
     }
   };
-  // pass p (64 rows) of a window: row list in LDS at `rows_lds` (byte address), `wp` rows valid, channels at byte `coff` of the operand row
-  auto win_dma_ix = [&](int ix, int p, int wp, uint32_t coff, int buf) {
-    if (W2_ABL(0x8)) return;       // ... without the window DMA
+  // source address of this thread's 16 bytes of DMA pass p (64 rows) of a window: row `ix` of the operand, `wp` rows valid
+  auto dma_src = [&](int ix, int p, int wp, uint32_t coff) -> uint64_t {
     const bool ok = (p * 64 + l_r) < wp;
     uint64_t v = in_base + (uint64_t)(uint32_t)(ok ? ix : 0) * rsb + coff;
     asm volatile("" : "+v"(v));
-    const uint64_t src = ok ? v : zero_src;
+    return ok ? v : zero_src;
+  };
+  auto dma_go = [&](uint64_t src, int p, int buf) {
     char *dst = lds + buf * W2_WIN + (p * 64 + wave * 16) * W2_ROWB;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)src,
                                      (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
   };
-
-  // weight fragments: lane (column l31 of column block j, k-slots 8 h .. 8 h + 7 of the chunk) = 16 bytes of row (k * cout + column)
-  // with the fragment-order copy (a.w_frag): lane's 16 bytes of fragment (k, c, j, hi / lo) at ((k nch + c) 4 + 2 j + part) 1024 + 16 lane -
-  // every load instruction reads one contiguous kilobyte
-  const bool frag = a.w_frag != nullptr;
-  const char *wrow[2];
+  // slot map -> byte offsets inside a window buffer, in place: entry (k, r) = window row * 64 + (swizzle << 4) for a row of this pass,
+  // the zero row for "no neighbour" / a row of another pass.  Two entries per 32-bit word.
+  auto tab_transform = [&](int base, int wp) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(lds + OFF_TAB);
+    for (int i = tid; i < W2_CAP / 2; i += 256) {
+      const uint32_t v = w[i];
+      uint32_t o = 0;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int n = j * 32 + l31;
-    n = n < cout ? n : cout - 1;
-    wrow[j] = frag ? reinterpret_cast<const char *>(a.w_frag) + j * 2048 + lane * 16
-                   : reinterpret_cast<const char *>(a.w_split) + (uint64_t)n * rsb + h * 16;
-  }
-  const uint64_t wslab = (uint64_t)cout * rsb;
-  const uint32_t lo_delta = frag ? 1024u : 64u;
-  auto load_w = [&](int k, int c, W2W &f) {
-    if (W2_ABL(0x4)) return;       // ... without the weight loads
-    const int kc = k < W2_KV ? k : W2_KV - 1;
-    const uint64_t off = frag ? (uint64_t)(uint32_t)((kc * nch + c) << 12) : (uint64_t)kc * wslab + chunk_off(c);
-    f.bh[0] = w2_gld(wrow[0] + off);
-    f.bl[0] = w2_gld(wrow[0] + off + lo_delta);
-    f.bh[1] = w2_gld(wrow[1] + off);
-    f.bl[1] = w2_gld(wrow[1] + off + lo_delta);
-  };
-
-  f32x16 acc[4][2];
-  // fragment reads of row blocks i0, i0 + 1: wofs = window row * 64 + ((h ^ swizzle) << 4), lo granule = hi granule ^ 2
-  auto issue_a = [&](const uint32_t (&wofs)[4], uint32_t bufbase, int i0, W2A &f) {
-    if (W2_ABL(0x2)) return;       // development build: timing without the fragment reads
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const uint32_t ad = bufbase + wofs[i0 + u];
-      f.h[u] = w2_lds(ad);
-      f.l[u] = w2_lds(ad ^ 32u);
+      for (int e = 0; e < 2; ++e) {
+        const uint32_t local = ((v >> (16 * e)) & 0xFFFFu) - (uint32_t)base;
+        const uint32_t ofs = local < (uint32_t)wp ? local * (uint32_t)W2_ROWB + (((local >> 2) & 3u) << 4) : (uint32_t)W2_ZOFS;
+        o |= ofs << (16 * e);
+      }
+      w[i] = o;
     }
   };
-  auto mfma12 = [&](const W2W &w, const W2A &f, int i0) {
-    if (W2_ABL(0x1)) return;       // ... without the products
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[i0 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bh[j], f.l[u], acc[i0 + u][j], 0, 0, 0);
-        acc[i0 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bl[j], f.h[u], acc[i0 + u][j], 0, 0, 0);
-        acc[i0 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bh[j], f.h[u], acc[i0 + u][j], 0, 0, 0);
-      }
+
+  // weight fragments in fragment order: lane's 16 bytes of fragment (k, c, j, hi / lo) at ((k nch + c) 4 + 2 j + part) 1024 + 16 lane
+  const char *wbase = reinterpret_cast<const char *>(a.w_frag) + lane * 16;
+  auto w_addr = [&](int k, int c) -> const char * {
+    const int kc = k < W2_KV ? k : W2_KV - 1;
+    return wbase + (uint64_t)(uint32_t)((kc * nch + c) << 12);
   };
-  // slot -> byte offset of the window row inside a buffer (+ this lane's hi granule)
-  auto row_ofs = [&](uint32_t slot, int base, int wp, bool kvalid) -> uint32_t {
-    const uint32_t local = slot - (uint32_t)base;
-    const uint32_t r = (kvalid && local < (uint32_t)wp) ? local : (uint32_t)W2_MAX;
-    return r * (uint32_t)W2_ROWB + ((((r >> 2) & 3u) ^ (uint32_t)h) << 4);
+#define W2_GLD(dst, ptr, OFFS) asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFFS : "=v"(dst) : "v"(ptr) : "memory")
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // the n-th of the 12 products of row blocks i0, i0 + 1 with one weight set: per accumulator the smallest terms first (hi x lo,
+  // lo x hi, hi x hi), its three products four issues apart
+  auto mf = [&](const W2W &w, const W2A &f, int i0, int n) {
+    if (W2_ABL(0x1)) return;
+    const int p = n >> 2, u = (n >> 1) & 1, j = n & 1;
+    if (p == 0) acc[i0 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bh[j], f.l[u], acc[i0 + u][j], 0, 0, 0);
+    else if (p == 1) acc[i0 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bl[j], f.h[u], acc[i0 + u][j], 0, 0, 0);
+    else acc[i0 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bh[j], f.h[u], acc[i0 + u][j], 0, 0, 0);
   };
 
-  // ---- first tile: tables, then its first window (the only exposed round trips of the workgroup) -----------------------------
-  tab_dma(tile0, 0);
-  int cnt = __builtin_amdgcn_readfirstlane(a.win_cnt[tile0]);
-  if (tid < 4) reinterpret_cast<uint4 *>(lds + W2_MAX * W2_ROWB)[tid] = make_uint4(0, 0, 0, 0);                 // zero rows of both buffers
-  else if (tid < 8) reinterpret_cast<uint4 *>(lds + W2_WIN + W2_MAX * W2_ROWB)[tid - 4] = make_uint4(0, 0, 0, 0);
+  // ---- tables, then the first window (the exposed round trips of the workgroup); the slot map is rewritten under the window's DMA ----
+  tab_dma();
+  const int cnt = __builtin_amdgcn_readfirstlane(a.win_cnt[tile]);
+  if (tid < 4) reinterpret_cast<uint4 *>(lds + W2_ZOFS)[tid] = make_uint4(0, 0, 0, 0);                 // zero rows of both buffers
+  else if (tid < 8) reinterpret_cast<uint4 *>(lds + W2_WIN + W2_ZOFS)[tid - 4] = make_uint4(0, 0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  const int npass = cnt > 0 ? (cnt + W2_MAX - 1) / W2_MAX : 1;
+  const int nsteps = nch * npass;
+  const uint32_t tab_slots = lds0 + (uint32_t)OFF_TAB + (uint32_t)(l31 * 2);                          // + (k * 128 + 32 i) * 2
+  const uint32_t tab_rows = lds0 + (uint32_t)(OFF_TAB + W2_TAB_SLOT) + (uint32_t)(l_r * 4);           // + 64 p * 4
   {
     const int wp = cnt < W2_MAX ? cnt : W2_MAX;
 #pragma unroll
     for (int p = 0; p < 7; ++p) {
       const int ix = *reinterpret_cast<const int *>(lds + OFF_TAB + W2_TAB_SLOT + (p * 64 + l_r) * 4);
-      win_dma_ix(ix, p, wp, chunk_off(0), 0);
+      dma_go(dma_src(ix, p, wp, chunk_off(0)), p, 0);
     }
+    tab_transform(0, wp);
   }
   W2W w0, w1;
-  load_w(wave, 0, w0);
+  {
+    const char *wp0 = w_addr(wave, 0);
+    W2_GLD(w0.bh[0], wp0, 0);
+    W2_GLD(w0.bl[0], wp0, 1024);
+    W2_GLD(w0.bh[1], wp0, 2048);
+    W2_GLD(w0.bl[1], wp0, 3072);
+  }
   int par = 0;                                         // window buffer of the step about to run
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : W2_PIN_W(w0)::"memory");
   __builtin_amdgcn_s_barrier();
+  const int64_t m0 = (int64_t)tile * W2_BM;
 
+  for (int s = 0, pass = 0, c = 0; s < nsteps; ++s, c = (c + 1 == nch ? 0 : c + 1), pass += (c == 0 ? 1 : 0)) {
+    const int base = pass * W2_MAX;
+    const int wp = cnt - base < W2_MAX ? cnt - base : W2_MAX;
+    // the window this step's DMAs fetch: the next chunk of this pass, or nothing (zero line: the last chunk of a pass)
+    const bool same = c + 1 < nch;
+    const int n_wp = same ? wp : 0;
+    const uint32_t n_coff = same ? chunk_off(c + 1) : chunk_off(0);
+    const int cn = same ? c + 1 : 0;                 // chunk of the weights prefetched at the last offset
+    const uint32_t bufbase = lds0 + (uint32_t)(par * W2_WIN);
+    const int nbuf = par ^ 1;
+
+    // ---- step prologue: the state every offset starts from - in flight, in this order: fa(0) + ixn(0), sl(1), fb(0) -----------
+    uint32_t sl[4], ad[4];
+    int ixn;
+    W2A fa, fb;
+    W2_STAMP(stamp++);
 #pragma unroll
-  for (int ti = 0; ti < T; ++ti) {
-    const int tile = tile0 + ti;
-    if (tile >= a.n_row_tiles) break;                  // uniform
-    const int tb = ti & (NTAB - 1);
-    const bool has_next = (ti + 1 < T) && (tile + 1 < a.n_row_tiles);
-    int cnt_next = 0;
-    if (has_next) {
-      tab_dma(tile + 1, (ti + 1) & (NTAB - 1));        // lands during this tile's first chunk (the chunk boundary certifies it)
-      // the load completes HERE (a scalar load shares lgkmcnt with the counted LDS waits below)
-      cnt_next = __builtin_amdgcn_readfirstlane(a.win_cnt[tile + 1]);
+    for (int i = 0; i < 4; ++i) sl[i] = w2_lds16(tab_slots + (uint32_t)((wave * W2_BM + i * 32) * 2));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3])::"memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ad[i] = bufbase + (sl[i] ^ hx);
+    W2_SB();
+    if (!W2_ABL(0x2)) {
+      fa.h[0] = w2_lds(ad[0]); fa.l[0] = w2_lds(ad[0] ^ 32u); fa.h[1] = w2_lds(ad[1]); fa.l[1] = w2_lds(ad[1] ^ 32u);
     }
-    const int64_t m0 = (int64_t)tile * W2_BM;
-    const int npass = cnt > 0 ? (cnt + W2_MAX - 1) / W2_MAX : 1;
-    const int nsteps = nch * npass;                    // nch = 16-channel chunks of the input rows
-    const uint32_t tab_slots = lds0 + (uint32_t)(OFF_TAB + tb * W2_TAB) + (uint32_t)(l31 * 2);        // + (k * 128 + 32 i) * 2
-    const uint32_t tab_rows = lds0 + (uint32_t)(OFF_TAB + tb * W2_TAB + W2_TAB_SLOT) + (uint32_t)(l_r * 4);
-    const uint32_t nxt_rows = lds0 + (uint32_t)(OFF_TAB + ((ti + 1) & (NTAB - 1)) * W2_TAB + W2_TAB_SLOT) + (uint32_t)(l_r * 4);
+    ixn = w2_lds32(tab_rows);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int i = 0; i < 4; ++i) sl[i] = w2_lds16(tab_slots + (uint32_t)(((wave + 4) * W2_BM + i * 32) * 2));
+    if (!W2_ABL(0x2)) {
+      fb.h[0] = w2_lds(ad[2]); fb.l[0] = w2_lds(ad[2] ^ 32u); fb.h[1] = w2_lds(ad[3]); fb.l[1] = w2_lds(ad[3] ^ 32u);
+    }
+    W2_SB();
 
-    for (int s = 0, pass = 0, c = 0; s < nsteps; ++s, c = (c + 1 == nch ? 0 : c + 1), pass += (c == 0 ? 1 : 0)) {
-      const int base = pass * W2_MAX;
-      const int wp = cnt - base < W2_MAX ? cnt - base : W2_MAX;
-      // the window this step's DMAs fetch: the next chunk of this pass, the first chunk of the next tile, or nothing (zero line)
-      const bool same = c + 1 < nch;
-      const bool nxt_tile = !same && s + 1 == nsteps && has_next;
-      const uint32_t n_rows = same ? tab_rows : nxt_rows;
-      const int n_wp = same ? wp : (nxt_tile ? (cnt_next < W2_MAX ? cnt_next : W2_MAX) : 0);
-      const uint32_t n_coff = same ? chunk_off(c + 1) : chunk_off(0);
-      const int cn = same ? c + 1 : 0;                 // chunk of the weights prefetched at the last offset
-      const uint32_t bufbase = lds0 + (uint32_t)(par * W2_WIN);
-      const int nbuf = par ^ 1;
-
-      // the window of this step has landed (every wave waited for its DMAs before the barrier that ended the previous step)
-      uint32_t sl[4], wofs[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sl[i] = w2_lds16(tab_slots + (uint32_t)((wave * W2_BM + i * 32) * 2));
-      int ixn = w2_lds32(n_rows);                      // row of DMA pass 0
-      W2_STAMP(stamp++);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3]), "+v"(ixn)::"memory");
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wofs[i] = row_ofs(sl[i], base, wp, true);
-      W2A fa, fb;
-      __builtin_amdgcn_sched_barrier(0);
-      issue_a(wofs, bufbase, 0, fa);
-      issue_a(wofs, bufbase, 2, fb);
-      __builtin_amdgcn_sched_barrier(0);
-
+    // One offset.  G1 = the 12 products of row blocks 0, 1 (fa), G2 = those of row blocks 2, 3 (fb); everything else in their gaps:
+    //   G1: [wait fa, ixn (, this offset's weights)] mf, [wait sl] mf, next offset's weights (address + 4 loads) between the next
+    //       four, the window DMA of this offset, the next offset's four fragment addresses, one per gap;
+    //   between: the reads of fa(t + 1) and of the row of the next DMA pass;
+    //   G2: [wait fb] the slot reads of offset t + 2 in the first four gaps;
+    //   after: the reads of fb(t + 1).
+    // LDS queue at the head of an offset (oldest first): fa(t) 4, ixn(t) 1, sl(t + 1) 4, fb(t) 4.
 #define W2_OFFSET(t, WC, WN)                                                                                                  \
   do {                                                                                                                        \
     const int kn = wave + 4 * ((t) + 1);                                                                                      \
-    /* head: this offset's first fragments and the row of its DMA pass have landed (the second group of reads may fly); */  \
-    /* then the slots of the next offset, the window DMA, the next offset's (chunk's) weights */                            \
-    asm volatile("s_waitcnt lgkmcnt(4)" : W2_PIN_A(fa), "+v"(ixn)::"memory");                                                 \
-    if (W2_ABL(0x2)) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ixn)::"memory");   /* ablated reads: the counts above do not hold */ \
+    const int k2 = wave + 4 * ((t) + 2) < W2_KV ? wave + 4 * ((t) + 2) : W2_KV - 1;                                           \
+    const char *wpn = (t) < 6 ? w_addr(kn, c) : w_addr(wave, cn);                                                             \
+    if ((t) < 6) asm volatile("s_waitcnt lgkmcnt(8)" : W2_PIN_A(fa), "+v"(ixn)::"memory");                                    \
+    else asm volatile("s_waitcnt lgkmcnt(4)" : W2_PIN_A(fa), "+v"(ixn)::"memory");                                            \
+    if (W2_ABL(0x2)) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ixn)::"memory");   /* ablated reads: the counts do not hold */   \
+    if ((t) > 0) asm volatile("s_waitcnt vmcnt(1)" : W2_PIN_W(WC)::"memory");      /* this offset's weights (the DMA behind them may fly) */ \
+    W2_SB(); mf(WC, fa, 0, 0); W2_SB();                                                                                       \
+    if ((t) < 6) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3])::"memory");         \
+    W2_SB(); mf(WC, fa, 0, 1); W2_SB();                                                                                       \
+    if (!W2_ABL(0x4)) W2_GLD(WN.bh[0], wpn, 0);                                                                               \
+    W2_SB(); mf(WC, fa, 0, 2); W2_SB();                                                                                       \
+    if (!W2_ABL(0x4)) W2_GLD(WN.bl[0], wpn, 1024);                                                                            \
+    W2_SB(); mf(WC, fa, 0, 3); W2_SB();                                                                                       \
+    if (!W2_ABL(0x4)) W2_GLD(WN.bh[1], wpn, 2048);                                                                            \
+    W2_SB(); mf(WC, fa, 0, 4); W2_SB();                                                                                       \
+    if (!W2_ABL(0x4)) W2_GLD(WN.bl[1], wpn, 3072);                                                                            \
+    W2_SB(); mf(WC, fa, 0, 5); W2_SB();                                                                                       \
+    const uint64_t dsrc = dma_src(ixn, (t), n_wp, n_coff);                                                                    \
+    W2_SB(); mf(WC, fa, 0, 6); W2_SB();                                                                                       \
+    if (!W2_ABL(0x8)) dma_go(dsrc, (t), nbuf);                                                                                \
+    W2_SB(); mf(WC, fa, 0, 7); W2_SB();                                                                                       \
     if ((t) < 6) {                                                                                                            \
-      const int ks = kn < W2_KV ? kn : W2_KV - 1;                                                                             \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) sl[i] = w2_lds16(tab_slots + (uint32_t)((ks * W2_BM + i * 32) * 2));     \
-    }                                                                                                                         \
-    win_dma_ix(ixn, (t), n_wp, n_coff, nbuf);                                                                                 \
-    if ((t) < 6) load_w(kn, c, WN);                                                                                           \
-    else load_w(wave, cn, WN);                                                                                                \
-    /* this offset's weights (requested one offset ahead; at t = 0 they were waited for before the step's barrier) */      \
-    if ((t) > 0 && !W2_ABL(0x20)) asm volatile("s_waitcnt vmcnt(5)" : W2_PIN_W(WC)::"memory");   /* 0x20: weights not waited for */ \
-    __builtin_amdgcn_sched_barrier(0);                                                                                        \
-    mfma12(WC, fa, 0);                                                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                                        \
-    W2_STAMP(stamp++);                                                                                                        \
-    if ((t) < 6) {                                                                                                            \
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3]), W2_PIN_A(fb)::"memory");      \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) wofs[i] = row_ofs(sl[i], base, wp, kn < W2_KV);                           \
-      __builtin_amdgcn_sched_barrier(0);                                                                                      \
-      issue_a(wofs, bufbase, 0, fa);                                                                                          \
-      ixn = w2_lds32(n_rows + (uint32_t)(((t) + 1) * 64 * 4));                                                                \
+      const bool kv = kn < W2_KV;                                                                                             \
+      ad[0] = bufbase + (kv ? sl[0] ^ hx : (uint32_t)W2_ZOFS + hx);                                                           \
+      W2_SB(); mf(WC, fa, 0, 8); W2_SB();                                                                                     \
+      ad[1] = bufbase + (kv ? sl[1] ^ hx : (uint32_t)W2_ZOFS + hx);                                                           \
+      W2_SB(); mf(WC, fa, 0, 9); W2_SB();                                                                                     \
+      ad[2] = bufbase + (kv ? sl[2] ^ hx : (uint32_t)W2_ZOFS + hx);                                                           \
+      W2_SB(); mf(WC, fa, 0, 10); W2_SB();                                                                                    \
+      ad[3] = bufbase + (kv ? sl[3] ^ hx : (uint32_t)W2_ZOFS + hx);                                                           \
+      W2_SB(); mf(WC, fa, 0, 11); W2_SB();                                                                                    \
+      if (!W2_ABL(0x2)) {                                                                                                     \
+        fa.h[0] = w2_lds(ad[0]); fa.l[0] = w2_lds(ad[0] ^ 32u); fa.h[1] = w2_lds(ad[1]); fa.l[1] = w2_lds(ad[1] ^ 32u);       \
+      }                                                                                                                       \
+      ixn = w2_lds32(tab_rows + (uint32_t)(((t) + 1) * 64 * 4));                                                              \
     } else {                                                                                                                  \
-      asm volatile("s_waitcnt lgkmcnt(0)" : W2_PIN_A(fb)::"memory");                                                          \
+      W2_SB(); mf(WC, fa, 0, 8); W2_SB(); mf(WC, fa, 0, 9); W2_SB(); mf(WC, fa, 0, 10); W2_SB(); mf(WC, fa, 0, 11); W2_SB();   \
     }                                                                                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                                                        \
-    mfma12(WC, fb, 2);                                                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                                        \
-    if ((t) < 6) issue_a(wofs, bufbase, 2, fb);                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                                        \
+    W2_STAMP(stamp++);                                                                                                        \
+    if ((t) < 6) asm volatile("s_waitcnt lgkmcnt(5)" : W2_PIN_A(fb)::"memory");                                               \
+    else asm volatile("s_waitcnt lgkmcnt(0)" : W2_PIN_A(fb)::"memory");                                                       \
+    W2_SB(); mf(WC, fb, 2, 0); W2_SB();                                                                                       \
+    if ((t) < 5) sl[0] = w2_lds16(tab_slots + (uint32_t)((k2 * W2_BM + 0) * 2));                                              \
+    W2_SB(); mf(WC, fb, 2, 1); W2_SB();                                                                                       \
+    if ((t) < 5) sl[1] = w2_lds16(tab_slots + (uint32_t)((k2 * W2_BM + 32) * 2));                                             \
+    W2_SB(); mf(WC, fb, 2, 2); W2_SB();                                                                                       \
+    if ((t) < 5) sl[2] = w2_lds16(tab_slots + (uint32_t)((k2 * W2_BM + 64) * 2));                                             \
+    W2_SB(); mf(WC, fb, 2, 3); W2_SB();                                                                                       \
+    if ((t) < 5) sl[3] = w2_lds16(tab_slots + (uint32_t)((k2 * W2_BM + 96) * 2));                                             \
+    W2_SB(); mf(WC, fb, 2, 4); W2_SB(); mf(WC, fb, 2, 5); W2_SB(); mf(WC, fb, 2, 6); W2_SB(); mf(WC, fb, 2, 7); W2_SB();      \
+    mf(WC, fb, 2, 8); W2_SB(); mf(WC, fb, 2, 9); W2_SB(); mf(WC, fb, 2, 10); W2_SB(); mf(WC, fb, 2, 11); W2_SB();             \
+    if ((t) < 6 && !W2_ABL(0x2)) {                                                                                            \
+      fb.h[0] = w2_lds(ad[2]); fb.l[0] = w2_lds(ad[2] ^ 32u); fb.h[1] = w2_lds(ad[3]); fb.l[1] = w2_lds(ad[3] ^ 32u);         \
+    }                                                                                                                         \
+    W2_SB();                                                                                                                  \
   } while (0)
 
-      W2_OFFSET(0, w0, w1);
-      W2_OFFSET(1, w1, w0);
-      W2_OFFSET(2, w0, w1);
-      W2_OFFSET(3, w1, w0);
-      W2_OFFSET(4, w0, w1);
-      W2_OFFSET(5, w1, w0);
-      W2_OFFSET(6, w0, w1);
+    W2_OFFSET(0, w0, w1);
+    W2_OFFSET(1, w1, w0);
+    W2_OFFSET(2, w0, w1);
+    W2_OFFSET(3, w1, w0);
+    W2_OFFSET(4, w0, w1);
+    W2_OFFSET(5, w1, w0);
+    W2_OFFSET(6, w0, w1);
 #undef W2_OFFSET
-      // this wave's DMAs of the next window and the weights prefetched at the last offset have landed, its reads of this window
-      // are done; the next step starts with w0
-      W2_STAMP(stamp++);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : W2_PIN_W(w1)::"memory");
-      W2_STAMP(stamp++);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      w0 = w1;
-      __builtin_amdgcn_s_barrier();
-      par ^= 1;
-      if (!same && s + 1 < nsteps) {
-        // a further pass of a window beyond the LDS capacity (rare: maps the predicate lets through have <= 1.25 passes per
-        // tile on average): its row list segment and first window, synchronously
-        const int nb = (pass + 1) * W2_MAX;
-        const int nwp = cnt - nb < W2_MAX ? cnt - nb : W2_MAX;
-        const int32_t *wrp = a.win_rows + (int64_t)tile * W2_CAP + nb;
-        int *rows = reinterpret_cast<int *>(lds + OFF_TAB + tb * W2_TAB + W2_TAB_SLOT);
-        for (int i = tid; i < W2_MAX; i += 256) rows[i] = i < nwp ? wrp[i] : 0;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int p = 0; p < 7; ++p) {
-          const int ix = rows[p * 64 + l_r];
-          win_dma_ix(ix, p, nwp, chunk_off(0), par);
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-    }
-
-    // ---- sum of the four partial accumulators through the window buffer that is NOT receiving the next tile's window: four
-    // rounds, one row block each: the three other waves write their part, the owner adds: own part, then the others ascending
-    if (W2_ABL(0x10)) continue;    // ... without reduction and epilogue
+    // this wave's DMAs of the next window and the weights prefetched at the last offset have landed, its reads of this window
+    // are done; the next step starts with w0
     W2_STAMP(stamp++);
-    f32x16 fin[1][2];
-    if constexpr (T == 1) {
-      // one tile per workgroup: both window buffers are free - two rounds of two row blocks (48 KB): in round b the waves write
-      // their partial sums of blocks 2 b and 2 b + 1 (the owner keeps its own), waves 2 b and 2 b + 1 add: own part, then the others'
-      float *red = reinterpret_cast<float *>(lds);       // [block in round][writer: the 3 other waves][j][r][lane]
-      static_assert(2 * W2_WIN >= 2 * 3 * 2 * 16 * 64 * 4, "two row blocks of partial sums fit the window buffers");
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int i = 2 * b + u;
-          if (wave != i) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) red[(((u * 3 + (wave < i ? wave : wave - 1)) * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int i = 2 * b + u;
-          if (wave == i) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              fin[0][j] = acc[i][j];
-#pragma unroll
-              for (int sw = 0; sw < 3; ++sw)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) fin[0][j][r] += red[(((u * 3 + sw) * 2 + j) * 16 + r) * 64 + lane];
-            }
-          }
-        }
-        if (b == 0) __syncthreads();
-      }
-    } else {
-    // four rounds of one row block through the window buffer that is NOT receiving the next tile's window
-    float *red = reinterpret_cast<float *>(lds + (par ^ 1) * W2_WIN);      // [writer: the 3 other waves][j][r][lane]: 24 KB
-    static_assert(W2_WIN >= 3 * 2 * 16 * 64 * 4, "one round of the reduction fits a window buffer");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (wave != i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) red[(((wave < i ? wave : wave - 1) * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
-      }
-      __syncthreads();
-      if (wave == i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          fin[0][j] = acc[i][j];
-#pragma unroll
-          for (int sw = 0; sw < 3; ++sw)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) fin[0][j][r] += red[((sw * 2 + j) * 16 + r) * 64 + lane];
-        }
-      }
-      if (i < 3) __syncthreads();
-    }
-    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : W2_PIN_W(w1)::"memory");
     W2_STAMP(stamp++);
-    // the epilogue with every load ahead of its first store (conv_h2_common.h: the plain form serialises its four column groups
-    // on the vmcnt order of loads behind stores: 10.9 k of a workgroup's 85 k clocks, tools/wop2_trace.py): per-channel vectors
-    // and each lane's residual values staged in the window buffers, which nothing reads any more
-    if constexpr (T == 1) h2_store_tile_staged<1, 2, EMIT, 256, 64, 2 * W2_WIN>(a, fin, m0, 0, wave, 0, h, l31, tid, lds);
-    else h2_store_tile<1, 2, EMIT>(a, fin, m0, 0, wave, 0, h, l31);
-    W2_STAMP(stamp++);
-#ifdef PH_DEV
-    if (TRACE && trace_wg >= 0) {
+    w0 = w1;
+    __builtin_amdgcn_s_barrier();
+    par ^= 1;
+    if (!same && s + 1 < nsteps) {
+      // a further pass of a window beyond the LDS capacity (rare: maps the predicate lets through have <= 1.25 passes per tile
+      // on average): the tables again, the next segment of the row list, the slot map for that pass, its first window - synchronously
+      const int nb = (pass + 1) * W2_MAX;
+      const int nwp = cnt - nb < W2_MAX ? cnt - nb : W2_MAX;
+      tab_dma();
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      W2_STAMP(stamp++);                 // the epilogue's stores have completed
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid < 2 * W2_TRACE_N)
-        g_w2_trace[trace_wg * 2 * W2_TRACE_N + tid] = reinterpret_cast<unsigned long long *>(lds + OFF_TAB + NTAB * W2_TAB)[tid];
-    }
-#endif
-    cnt = cnt_next;
-    if (has_next) {
-      // every owner is done reading the reduction buffer before the next tile's DMAs write it (its first window landed before the
-      // last step's barrier); the epilogue's stores stay in flight
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int32_t *wrp = a.win_rows + (int64_t)tile * W2_CAP + nb;
+      int *rows = reinterpret_cast<int *>(lds + OFF_TAB + W2_TAB_SLOT);
+      for (int i = tid; i < W2_MAX; i += 256) rows[i] = i < nwp ? wrp[i] : 0;
+      tab_transform(nb, nwp);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int p = 0; p < 7; ++p) dma_go(dma_src(rows[p * 64 + l_r], p, nwp, chunk_off(0)), p, par);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
+  if (W2_ABL(0x10)) return;            // development build: timing without reduction and epilogue
+
+  // ---- sum of the four partial accumulators through both window buffers (free now): two rounds of two row blocks (48 KB): in
+  // round b the waves write their partial sums of blocks 2 b and 2 b + 1 (the owner keeps its own), waves 2 b and 2 b + 1 add:
+  // own part first, then the other waves' ascending - a fixed order
+  W2_STAMP(stamp++);
+  f32x16 fin[1][2];
+  {
+    float *red = reinterpret_cast<float *>(lds);       // [block in round][writer: the 3 other waves][j][r][lane]
+    static_assert(2 * W2_WIN >= 2 * 3 * 2 * 16 * 64 * 4, "two row blocks of partial sums fit the window buffers");
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = 2 * b + u;
+        if (wave != i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((u * 3 + (wave < i ? wave : wave - 1)) * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = 2 * b + u;
+        if (wave == i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            fin[0][j] = acc[i][j];
+#pragma unroll
+            for (int sw = 0; sw < 3; ++sw)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) fin[0][j][r] += red[(((u * 3 + sw) * 2 + j) * 16 + r) * 64 + lane];
+          }
+        }
+      }
+      if (b == 0) __syncthreads();
+    }
+  }
+  W2_STAMP(stamp++);
+  // the epilogue with every load ahead of its first store (conv_h2_common.h: the plain form serialises its four column groups on
+  // the vmcnt order of loads behind stores): per-channel vectors and each lane's residual values staged in the window buffers
+  h2_store_tile_staged<1, 2, EMIT, 256, 64, 2 * W2_WIN>(a, fin, m0, 0, wave, 0, h, l31, tid, lds);
+  W2_STAMP(stamp++);
+#ifdef PH_DEV
+  if (TRACE && trace_wg >= 0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    W2_STAMP(stamp++);                 // the epilogue's stores have completed
+    __syncthreads();
+    if (tid < 2 * W2_TRACE_N)
+      g_w2_trace[trace_wg * 2 * W2_TRACE_N + tid] = reinterpret_cast<unsigned long long *>(lds + OFF_TAB + W2_TAB)[tid];
+  }
+#endif
 }
 
-// Launches the window side of a pair for 64-wide outputs (conv_win.hip: ph_conv_win_launch).  tiles_per_wg: 1 or 2.
-int ph_conv_wop2_launch(const ConvArgsH &args, int tiles_per_wg, hipStream_t st) {
-  const int nwg = (args.n_row_tiles + tiles_per_wg - 1) / tiles_per_wg;
-  const int grid = ((nwg + 7) / 8) * 8;
+// Launches the window side of a pair for 64-wide outputs (conv_win.hip: ph_conv_win_launch); needs args.w_frag.
+int ph_conv_wop2_launch(const ConvArgsH &args, hipStream_t st) {
+  const int grid = ((args.n_row_tiles + 7) / 8) * 8;
   const bool emit = args.out_split != nullptr;
 #ifdef PH_DEV
-  if (g_w2_trace_on && !emit && tiles_per_wg == 1) {      // never on a launch that has to write the next layer's operand
-    hipLaunchKernelGGL((k_conv_wop2<false, 1, true>), dim3(grid), dim3(256), 0, st, args);
+  if (g_w2_trace_on && !emit) {        // never on a launch that has to write the next layer's operand
+    hipLaunchKernelGGL((k_conv_wop2<false, true>), dim3(grid), dim3(256), 0, st, args);
     PH_LAUNCH_CHECK();
     return 0;
   }
 #endif
-  if (tiles_per_wg == 2) {
-    if (emit) hipLaunchKernelGGL((k_conv_wop2<true, 2>), dim3(grid), dim3(256), 0, st, args);
-    else hipLaunchKernelGGL((k_conv_wop2<false, 2>), dim3(grid), dim3(256), 0, st, args);
-  } else {
-    if (emit) hipLaunchKernelGGL((k_conv_wop2<true, 1>), dim3(grid), dim3(256), 0, st, args);
-    else hipLaunchKernelGGL((k_conv_wop2<false, 1>), dim3(grid), dim3(256), 0, st, args);
-  }
+  if (emit) hipLaunchKernelGGL((k_conv_wop2<true>), dim3(grid), dim3(256), 0, st, args);
+  else hipLaunchKernelGGL((k_conv_wop2<false>), dim3(grid), dim3(256), 0, st, args);
   PH_LAUNCH_CHECK();
   return 0;
 }
