@@ -222,6 +222,45 @@ struct TailLds {
     return make_float4(v[0], v[1], v[2], v[3]);
   }
 };
+// ... or in REGISTERS of the lane (a kernel whose accumulators die before its epilogue and that has something to do between the loads
+// and the stores: conv_wop.hip issues them ahead of its reduction): slot numbers are compile-time constants after unrolling
+template <int NSLOT>
+struct TailRegs {
+  static constexpr bool staged = true;
+  float4 v[NSLOT];
+  __device__ __forceinline__ float4 get(int slot) const { return v[slot]; }
+};
+// h2_stage_tail's loads into a TailRegs (all TN column blocks; slot = ((i * TN + j) * 2 + m) * 2 + u)
+template <int TM, int TN>
+__device__ __forceinline__ void h2_load_tail_regs(const ConvArgsH &a, int64_t m0, int n0, int wm, int wn, int h, int l31,
+                                                  TailRegs<TM * TN * 4> &t) {
+  const int cout = a.cout;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t r = m0 + (wm * TM + i) * 32 + l31;
+    const int64_t orow = r < a.n_out ? (a.out_rows ? (int64_t)a.out_rows[r] : r) : -1;
+    int64_t axis_off[3] = {0, 0, 0};
+    if (a.axis_table && orow >= 0) {
+      if (ph_axis_offsets(a, orow, axis_off) && a.status != nullptr) atomicOr(a.status, 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int col = n0 + (wn * TN + j) * 32 + 16 * m + 8 * u + 4 * h;
+          const bool ok = orow >= 0 && col < cout;
+          float4 rs = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.residual && ok) rs = *reinterpret_cast<const float4 *>(a.residual + orow * cout + col);
+          if (a.axis_table && ok) {
+            const float4 tb = ph_axis_residual4(a, axis_off, col);
+            rs = make_float4(tb.x + rs.x, tb.y + rs.y, tb.z + rs.z, tb.w + rs.w);
+          }
+          t.v[((i * TN + j) * 2 + m) * 2 + u] = rs;
+        }
+  }
+}
 // slot of (i, j, m, u) within passes of JB column blocks: ((i * JB + (j - j0)) * 2 + m) * 2 + u
 template <int TM, int TN, int JB>
 __device__ __forceinline__ void h2_stage_tail(const ConvArgsH &a, int64_t m0, int n0, int wm, int wn, int h, int l31, int j0,

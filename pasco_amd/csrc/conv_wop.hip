@@ -101,13 +101,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
   const int bid = blockIdx.x;
   const int tile = (bid & 7) * cpx + (bid >> 3);
   if (tile >= a.n_row_tiles) return;
-  {
-    const int which = a.win_which;       // ph_win_pred
-    const int32_t st_w = a.win_stats[which & 1];
-    const bool windows = (which & 0x100) ? true : ((which & 0x200) ? false : (int64_t)st_w * 4 <= (int64_t)a.n_row_tiles * 5);
-    if (!windows) return;                // the gather kernel serves this map
-  }
-
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -212,12 +205,28 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
     else acc[i0 + u][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w.bh[j], f.h[u], acc[i0 + u][j], 0, 0, 0);
   };
 
-  // ---- tables, then the first window (the exposed round trips of the workgroup); the slot map is rewritten under the window's DMA ----
+  // ---- tables, then the first window (the exposed round trips of the workgroup): the table DMA goes out FIRST, the predicate of the
+  // pair, the tile's row count and the first weights are fetched under it; the slot map is rewritten under the window's DMA -------
   tab_dma();
+  W2W w0, w1;
+  {
+    const char *wp0 = w_addr(wave, 0);
+    W2_GLD(w0.bh[0], wp0, 0);
+    W2_GLD(w0.bl[0], wp0, 1024);
+    W2_GLD(w0.bh[1], wp0, 2048);
+    W2_GLD(w0.bl[1], wp0, 3072);
+  }
   const int cnt = __builtin_amdgcn_readfirstlane(a.win_cnt[tile]);
+  bool windows;
+  {
+    const int which = a.win_which;       // ph_win_pred
+    const int32_t st_w = a.win_stats[which & 1];
+    windows = (which & 0x100) ? true : ((which & 0x200) ? false : (int64_t)st_w * 4 <= (int64_t)a.n_row_tiles * 5);
+  }
   if (tid < 4) reinterpret_cast<uint4 *>(lds + W2_ZOFS)[tid] = make_uint4(0, 0, 0, 0);                 // zero rows of both buffers
   else if (tid < 8) reinterpret_cast<uint4 *>(lds + W2_WIN + W2_ZOFS)[tid - 4] = make_uint4(0, 0, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : W2_PIN_W(w0)::"memory");
+  if (!windows) return;                  // the gather kernel serves this map (nothing of this workgroup is in flight any more)
   __builtin_amdgcn_s_barrier();
   const int npass = cnt > 0 ? (cnt + W2_MAX - 1) / W2_MAX : 1;
   const int nsteps = nch * npass;
@@ -232,18 +241,21 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
     }
     tab_transform(0, wp);
   }
-  W2W w0, w1;
-  {
-    const char *wp0 = w_addr(wave, 0);
-    W2_GLD(w0.bh[0], wp0, 0);
-    W2_GLD(w0.bl[0], wp0, 1024);
-    W2_GLD(w0.bh[1], wp0, 2048);
-    W2_GLD(w0.bl[1], wp0, 3072);
-  }
   int par = 0;                                         // window buffer of the step about to run
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : W2_PIN_W(w0)::"memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   const int64_t m0 = (int64_t)tile * W2_BM;
+  // row offsets of this wave's first two offsets: the same for every chunk of a pass - read once, not at the head of every step
+  uint32_t s0[4], s1[4];
+  auto first_slots = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s0[i] = w2_lds16(tab_slots + (uint32_t)((wave * W2_BM + i * 32) * 2));
+      s1[i] = w2_lds16(tab_slots + (uint32_t)(((wave + 4) * W2_BM + i * 32) * 2));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s0[0]), "+v"(s0[1]), "+v"(s0[2]), "+v"(s0[3]), "+v"(s1[0]), "+v"(s1[1]), "+v"(s1[2]), "+v"(s1[3])::"memory");
+  };
+  first_slots();
 
   for (int s = 0, pass = 0, c = 0; s < nsteps; ++s, c = (c + 1 == nch ? 0 : c + 1), pass += (c == 0 ? 1 : 0)) {
     const int base = pass * W2_MAX;
@@ -256,23 +268,21 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
     const uint32_t bufbase = lds0 + (uint32_t)(par * W2_WIN);
     const int nbuf = par ^ 1;
 
-    // ---- step prologue: the state every offset starts from - in flight, in this order: fa(0) + ixn(0), sl(1), fb(0) -----------
+    // ---- step prologue: the first fragments (addresses from the pass's first slots) - in flight, in this order: fa(0) + ixn(0), fb(0)
     uint32_t sl[4], ad[4];
     int ixn;
     W2A fa, fb;
     W2_STAMP(stamp++);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sl[i] = w2_lds16(tab_slots + (uint32_t)((wave * W2_BM + i * 32) * 2));
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3])::"memory");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ad[i] = bufbase + (sl[i] ^ hx);
+    for (int i = 0; i < 4; ++i) {
+      ad[i] = bufbase + (s0[i] ^ hx);
+      sl[i] = s1[i];
+    }
     W2_SB();
     if (!W2_ABL(0x2)) {
       fa.h[0] = w2_lds(ad[0]); fa.l[0] = w2_lds(ad[0] ^ 32u); fa.h[1] = w2_lds(ad[1]); fa.l[1] = w2_lds(ad[1] ^ 32u);
     }
     ixn = w2_lds32(tab_rows);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sl[i] = w2_lds16(tab_slots + (uint32_t)(((wave + 4) * W2_BM + i * 32) * 2));
     if (!W2_ABL(0x2)) {
       fb.h[0] = w2_lds(ad[2]); fb.l[0] = w2_lds(ad[2] ^ 32u); fb.h[1] = w2_lds(ad[3]); fb.l[1] = w2_lds(ad[3] ^ 32u);
     }
@@ -284,18 +294,18 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
     //   between: the reads of fa(t + 1) and of the row of the next DMA pass;
     //   G2: [wait fb] the slot reads of offset t + 2 in the first four gaps;
     //   after: the reads of fb(t + 1).
-    // LDS queue at the head of an offset (oldest first): fa(t) 4, ixn(t) 1, sl(t + 1) 4, fb(t) 4.
+    // LDS queue at the head of an offset (oldest first): fa(t) 4, ixn(t) 1, sl(t + 1) 4, fb(t) 4 (t = 0: the slots are in registers).
 #define W2_OFFSET(t, WC, WN)                                                                                                  \
   do {                                                                                                                        \
     const int kn = wave + 4 * ((t) + 1);                                                                                      \
     const int k2 = wave + 4 * ((t) + 2) < W2_KV ? wave + 4 * ((t) + 2) : W2_KV - 1;                                           \
     const char *wpn = (t) < 6 ? w_addr(kn, c) : w_addr(wave, cn);                                                             \
-    if ((t) < 6) asm volatile("s_waitcnt lgkmcnt(8)" : W2_PIN_A(fa), "+v"(ixn)::"memory");                                    \
+    if ((t) > 0 && (t) < 6) asm volatile("s_waitcnt lgkmcnt(8)" : W2_PIN_A(fa), "+v"(ixn)::"memory");                         \
     else asm volatile("s_waitcnt lgkmcnt(4)" : W2_PIN_A(fa), "+v"(ixn)::"memory");                                            \
     if (W2_ABL(0x2)) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ixn)::"memory");   /* ablated reads: the counts do not hold */   \
     if ((t) > 0) asm volatile("s_waitcnt vmcnt(1)" : W2_PIN_W(WC)::"memory");      /* this offset's weights (the DMA behind them may fly) */ \
     W2_SB(); mf(WC, fa, 0, 0); W2_SB();                                                                                       \
-    if ((t) < 6) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3])::"memory");         \
+    if ((t) > 0 && (t) < 6) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3])::"memory"); \
     W2_SB(); mf(WC, fa, 0, 1); W2_SB();                                                                                       \
     if (!W2_ABL(0x4)) W2_GLD(WN.bh[0], wpn, 0);                                                                               \
     W2_SB(); mf(WC, fa, 0, 2); W2_SB();                                                                                       \
@@ -377,19 +387,28 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
       __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int p = 0; p < 7; ++p) dma_go(dma_src(rows[p * 64 + l_r], p, nwp, chunk_off(0)), p, par);
+      first_slots();
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
   if (W2_ABL(0x10)) return;            // development build: timing without reduction and epilogue
 
+  // ---- the epilogue's loads FIRST: the per-channel vectors into the (free) table buffer, this lane's residual values into
+  // registers - they fly under the reduction, and no load of the epilogue waits behind one of its stores (the plain form
+  // serialises its four column groups on the in-order vmcnt of loads behind stores: 11 k of a workgroup's 85 k clocks) ----------
+  W2_STAMP(stamp++);
+  lds_float *epar = (lds_float *)(lds + OFF_TAB);
+  h2_stage_params(a, 0, 64, tid, epar);
+  TailRegs<8> tail;
+  if (a.has_tail) h2_load_tail_regs<1, 2>(a, m0, 0, wave, 0, h, l31, tail);
   // ---- sum of the four partial accumulators through both window buffers (free now): two rounds of two row blocks (48 KB): in
   // round b the waves write their partial sums of blocks 2 b and 2 b + 1 (the owner keeps its own), waves 2 b and 2 b + 1 add:
-  // own part first, then the other waves' ascending - a fixed order
-  W2_STAMP(stamp++);
+  // own part first, then the other waves' ascending - a fixed order.  16 bytes per lane and LDS instruction.
   f32x16 fin[1][2];
   {
-    float *red = reinterpret_cast<float *>(lds);       // [block in round][writer: the 3 other waves][j][r][lane]
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v *red = reinterpret_cast<f32x4v *>(lds);       // [block in round][writer: the 3 other waves][j][r / 4][lane] x 4 floats
     static_assert(2 * W2_WIN >= 2 * 3 * 2 * 16 * 64 * 4, "two row blocks of partial sums fit the window buffers");
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -400,7 +419,11 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
 #pragma unroll
           for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[(((u * 3 + (wave < i ? wave : wave - 1)) * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+            for (int r4 = 0; r4 < 4; ++r4) {
+              f32x4v v;
+              v[0] = acc[i][j][4 * r4]; v[1] = acc[i][j][4 * r4 + 1]; v[2] = acc[i][j][4 * r4 + 2]; v[3] = acc[i][j][4 * r4 + 3];
+              red[(((u * 3 + (wave < i ? wave : wave - 1)) * 2 + j) * 4 + r4) * 64 + lane] = v;
+            }
         }
       }
       __syncthreads();
@@ -414,7 +437,11 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
 #pragma unroll
             for (int sw = 0; sw < 3; ++sw)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) fin[0][j][r] += red[(((u * 3 + sw) * 2 + j) * 16 + r) * 64 + lane];
+              for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4v v = red[(((u * 3 + sw) * 2 + j) * 4 + r4) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fin[0][j][4 * r4 + q] += v[q];
+              }
           }
         }
       }
@@ -422,9 +449,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
     }
   }
   W2_STAMP(stamp++);
-  // the epilogue with every load ahead of its first store (conv_h2_common.h: the plain form serialises its four column groups on
-  // the vmcnt order of loads behind stores): per-channel vectors and each lane's residual values staged in the window buffers
-  h2_store_tile_staged<1, 2, EMIT, 256, 64, 2 * W2_WIN>(a, fin, m0, 0, wave, 0, h, l31, tid, lds);
+  h2_store_tile<1, 2, EMIT, ParLds, TailRegs<8>>(a, fin, m0, 0, wave, 0, h, l31, ParLds{epar, 0, 64}, tail);
   W2_STAMP(stamp++);
 #ifdef PH_DEV
   if (TRACE && trace_wg >= 0) {
