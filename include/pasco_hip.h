@@ -49,6 +49,13 @@ extern "C" {
 #define PH_ROUTE_WIDE_NEVER 0x8
 #define PH_ROUTE_LIN_NEVER 0x10  /* k = 1 products: not the row-stream kernel */
 
+/* status word bit 6, written by ph_split_rows only: the operand holds at least one value with |x * 2^exp2| >= PH_SPLIT_FULL_PRECISION,
+ * i.e. one whose hi / lo split carries the full 22 bits.  Informational in a stream's status word; in the word of a GUARDED
+ * convolution (ph_conv_desc.exact_if) its ABSENCE - a tensor of tiny values only: 2^-19 relative error at |x| = 2^-9 growing to
+ * 2^-11 at 2^-19, unscaled with exp2 = 5 - sends the launch to the exact fp32 kernel like an overflow does. */
+#define PH_STATUS_MAGNITUDE 0x40
+#define PH_SPLIT_FULL_PRECISION 0.0625f
+
 /* activation codes for fused prologue / epilogue */
 #define PH_ACT_NONE 0
 #define PH_ACT_RELU 1
@@ -225,7 +232,8 @@ typedef struct ph_conv_desc {
   const int32_t *rl_in, *rl_out, *rl_tile_k;
   int64_t rl_rows;
   int32_t rl_tiles;       /* entries of rl_tile_k (an upper bound of the used tiles) */
-  /* mode 0 only, optional: a device word that GUARDS the launch - it does its work only when (*exact_if & 1) != 0 and
+  /* mode 0 only, optional: a device word that GUARDS the launch - it does its work only when (*exact_if & 1) != 0 (an operand
+   * left the f16 range) or (*exact_if & PH_STATUS_MAGNITUDE) == 0 (the operand holds tiny values only: round 6) and
    * returns at once otherwise.  The guarded form of the split path, no host read: ph_split_rows and the mode-2 launch get
    * `status` = this word (bit 0 = an operand left the f16 range), then the same convolution is launched in mode 0 with
    * exact_if = this word and the same `out`: the exact fp32 result replaces the split one exactly when it has to.  What

@@ -277,8 +277,8 @@ int pho_split_rows(const float *in, int64_t n, int32_t c, const float *pro_scale
   const int cpad = (c + 31) / 32 * 32;
   uint16_t *out = (uint16_t *)out_split;
   const int has_pro = pro_scale || pro_shift || pro_act != PH_ACT_NONE;
-  int bad = 0;
-#pragma omp parallel for schedule(static) reduction(| : bad)
+  int bad = 0, big = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad, big)
   for (int64_t r = 0; r < n; ++r) {
     uint16_t *row = out + r * 2 * cpad;
     for (int ch = 0; ch < cpad; ++ch) {
@@ -291,6 +291,7 @@ int pho_split_rows(const float *in, int64_t n, int32_t c, const float *pro_scale
         }
         v *= pow2;
         if (!(fabsf(v) <= 65504.f)) bad = 1;
+        if (fabsf(v) >= PH_SPLIT_FULL_PRECISION) big = 1;
         hi = f32_to_f16_bits(v);
         lo = f32_to_f16_bits(v - f16_bits_to_f32(hi));
       }
@@ -299,6 +300,7 @@ int pho_split_rows(const float *in, int64_t n, int32_t c, const float *pro_scale
     }
   }
   if (bad && status) *status |= 1;
+  if (big && status) *status |= PH_STATUS_MAGNITUDE;      /* include/pasco_hip.h: the operand holds a full-precision value */
   return 0;
 }
 
@@ -325,7 +327,8 @@ int pho_conv_fwd(const ph_conv_desc *d, ph_stream_t stream) {
   if (!d) return fail("conv_fwd: null desc");
   if (d->cin <= 0 || d->cout <= 0 || d->kvol < 1 || d->kvol > 4096) return fail("conv_fwd: bad shape");
   if (d->n_out == 0) return 0;
-  if (d->mma_mode == 0 && d->exact_if && (*d->exact_if & 1) == 0) return 0;   /* guarded launch: nothing to redo */
+  if (d->mma_mode == 0 && d->exact_if && (*d->exact_if & 1) == 0 && (*d->exact_if & PH_STATUS_MAGNITUDE) != 0)
+    return 0;   /* guarded launch: nothing to redo (no overflow, and the operand was not all tiny) */
   /* mma_mode 0 / 1: plain fp32 on in / weight (how the device forms the products does not change the values
    * beyond rounding).  mma_mode 2 follows the device's data flow (include/pasco_hip.h): the operands are
    * in_split / w_split, read back as hi + lo, with the prologue already inside in_split; in / weight may be NULL. */

@@ -40,7 +40,7 @@ struct ConvArgs {
   int epi_act, res_act;
   float slope;
   int n_row_tiles, n_col_tiles;
-  const int32_t *pred;     // ph_conv_desc.exact_if: work only when (*pred & 1) != 0
+  const int32_t *pred;     // ph_conv_desc.exact_if: work only when (*pred & 1) != 0 or (*pred & PH_STATUS_MAGNITUDE) == 0
 };
 
 // activations: neg = 1 (none), 0 (ReLU), slope (leaky); NaN-preserving select (ph_common.h)
@@ -74,7 +74,10 @@ __global__ void __launch_bounds__(CV_THREADS) k_conv_mfma(ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float As[BM * A_LD];
   __shared__ __attribute__((aligned(16))) float Bs[BKC * B_LD];
 
-  if (a.pred != nullptr && (*a.pred & 1) == 0) return;      // guarded launch (ph_conv_desc.exact_if): nothing to redo
+  if (a.pred != nullptr) {      // guarded launch (ph_conv_desc.exact_if): nothing to redo unless the split operand overflowed or was all tiny
+    const int w = *a.pred;
+    if ((w & 1) == 0 && (w & PH_STATUS_MAGNITUDE) != 0) return;
+  }
 
   // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of
   // tiles so that neighbouring row tiles (shared gathered rows) meet in one L2.

@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ in
     const float4 v0 = *reinterpret_cast<const float4 *>(in + row * c + c0);
     const float4 v1 = *reinterpret_cast<const float4 *>(in + row * c + c0 + 4);
     float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    bool bad = false;
+    bool bad = false, big = false;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = x[j];
@@ -459,11 +459,18 @@ __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ in
       }
       v *= pow2;
       bad |= h_out_of_range(v);
+      big |= fabsf(v) >= PH_SPLIT_FULL_PRECISION;
       const _Float16 vh = (_Float16)v;
       hi[j] = vh;
       lo[j] = (_Float16)(v - (float)vh);
     }
     if (status != nullptr && bad) atomicOr(status, 1);   // |v| > 65504 or NaN
+    // bit 6: the operand holds a value whose lo half is a normal f16 (full 22-bit split).  A tensor WITHOUT one is all tiny (or
+    // all zero): its hi / lo pairs carry fewer and fewer bits (lo is subnormal below 2^-3 scaled, hi itself below 2^-14) - the guarded
+    // module path (ph_conv_desc.exact_if) sends such a tensor to the exact kernel.  One atomic per wave, and only until the bit shows.
+    if (status != nullptr && __builtin_amdgcn_ballot_w64(big) != 0 && (threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(big))) {
+      if ((__atomic_load_n(status, __ATOMIC_RELAXED) & PH_STATUS_MAGNITUDE) == 0) atomicOr(status, PH_STATUS_MAGNITUDE);
+    }
   }
   _Float16 *dst = out + (row * (cpad >> 5) + (c0 >> 5)) * 64 + (c0 & 31);
   *reinterpret_cast<f16x8 *>(dst) = hi;

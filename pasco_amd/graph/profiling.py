@@ -72,7 +72,7 @@ class ConvProfiler:
                         pass
             name = KERNEL_NAMES.get(kid, f"kernel{kid}")
             if kid == 5 and cout <= 64:          # the 64-wide window launches run the offset-parallel kernel
-                name = "k_conv_wop"
+                name = "k_conv_wop2"
             prof.records.append(dict(e0=e0, e1=e1, pairs=pairs, n_in=n_in, n_out=n_out, cin=cin,
                                      cout=cout, kvol=kvol, kernel=name))
             return out

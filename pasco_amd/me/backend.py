@@ -142,6 +142,7 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+STATUS_MAGNITUDE = 0x40    # PH_STATUS_MAGNITUDE
 ROUTE_WIN_ALWAYS, ROUTE_WIN_NEVER, ROUTE_WIDE_ALWAYS, ROUTE_WIDE_NEVER, ROUTE_LIN_NEVER = 0x1, 0x2, 0x4, 0x8, 0x10   # PH_ROUTE_*
 
 
@@ -658,6 +659,7 @@ class CBackend:
         snap = t.clone()          # stream-ordered: after every kernel of this stream that could raise a flag ...
         t.zero_()                 # ... and before any later one
         v, opt = snap.tolist()
+        v &= ~STATUS_MAGNITUDE        # informational (ph_split_rows: the operand holds a full-precision value): not an error
         if opt != 0:
             v |= 16
         if v == 0:

@@ -86,3 +86,17 @@ def test_printed_line_stays_parseable():
     fat["exchange"] = {"x": "y" * 5000}
     slim = bench.compact_line(fat)
     assert len(json.dumps(slim)) <= bench.LINE_LIMIT and "roofline" in slim and "cpu_baseline" in slim
+
+
+def test_window_kernel_headline_sits_under_the_matrix_roof():
+    """The LDS-window kernels serve SURVEY 8(d)'s algorithmic gather bytes on chip: algorithmic bytes / time can exceed the HBM
+    peak, so the headline roof of such a class is the f16 matrix peak and the algorithmic figure is kept beside it."""
+    classes = {("k3 C=64", "k_conv_wop2"): dict(launches=18, time_s=18 * 210e-6, flops=18 * 54.5e9, bytes_alg=18 * 1.847e9,
+                                                bytes_min=18 * 0.234e9)}
+    per_kernel = {"k_conv_wop2": dict(_rec(18, 18 * 210e-6, 18 * 54.5e9, 18 * 1.847e9), bytes_min=18 * 0.234e9)}
+    r = bench.roofline_object(per_kernel, steps=1, classes=classes)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - 3 * 54.5e9 / 210e-6 / 1e12 / 2500.0) < 1e-3
+    assert r["alg_roof"]["bound"] == "hbm" and r["alg_roof"]["frac"] > 1.0          # the quotient that is not an HBM number
+    line = bench.compact_line({"metric": "m", "value": 1.0, "roofline": r, "config": {"workload": "w"}})
+    assert line["roofline"]["bound"] == "mfma" and "alg_roof" in line["roofline"]

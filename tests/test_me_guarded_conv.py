@@ -9,21 +9,21 @@ import pasco_amd.me as ME
 from pasco_amd.me import modules as M
 
 
-def _scene(n=4000, extent=(24, 24, 10), c=64, seed=0, big=None):
+def _scene(n=4000, extent=(24, 24, 10), c=64, seed=0, big=None, gain=1.0):
     g = torch.Generator().manual_seed(seed)
     X, Y, Z = extent
     site = torch.randperm(X * Y * Z, generator=g)[:n]
     coords = torch.stack([torch.zeros_like(site), site // (Y * Z), (site // Z) % Y, site % Z], 1).int()
-    feats = torch.randn(n, c, generator=g)
+    feats = torch.randn(n, c, generator=g) * gain
     if big is not None:
         feats[17, 3] = big                       # one activation beyond the f16 range of the scaled operand (|x| > 2047)
     return coords, feats
 
 
-def _run(device, big, mode, n=4000, extent=(24, 24, 10)):
+def _run(device, big, mode, n=4000, extent=(24, 24, 10), gain=1.0):
     torch.manual_seed(3)
     conv = ME.MinkowskiConvolution(64, 64, kernel_size=3, bias=True, dimension=3).to(device).eval()
-    coords, feats = _scene(n=n, extent=extent, big=big)
+    coords, feats = _scene(n=n, extent=extent, big=big, gain=gain)
     x = ME.SparseTensor(feats.to(device), coords.to(device))
     M.set_me_conv(mode)
     try:
@@ -43,6 +43,18 @@ def _check(device, be, **kw):
     exact_big = _run(device, 5000.0, "exact", **kw)
     guarded_big = _run(device, 5000.0, "guarded", **kw)
     assert torch.isfinite(guarded_big).all() and torch.equal(guarded_big, exact_big)
+    # a tensor of TINY activations only (the fixed 2^5 operand scale leaves |x| ~ 1e-6 with 2^-11-class hi / lo pairs,
+    # 5e-4 relative error at 1e-6 and 6e-2 at 1e-8): no value reaches the full-precision range, the magnitude bit of the guard
+    # word stays clear and the exact kernel's result comes back, bit for bit
+    for gain in (1e-6, 1e-8):
+        exact_tiny = _run(device, None, "exact", gain=gain, **kw)
+        guarded_tiny = _run(device, None, "guarded", gain=gain, **kw)
+        assert torch.equal(guarded_tiny, exact_tiny), gain
+    # small but not tiny (|x| ~ 1e-2: values above 2^-9 exist): the split kernel keeps the work, at fp32-class accuracy
+    exact_small = _run(device, None, "exact", gain=1e-2, **kw)
+    guarded_small = _run(device, None, "guarded", gain=1e-2, **kw)
+    bias_free = float((exact_small - exact_small.mean(0)).abs().mean())
+    assert float((guarded_small - exact_small).abs().max()) <= 1e-4 * bias_free
     be.check_status(torch.device(device))                                  # and the stream's own status pair stayed clean
 
 
@@ -61,12 +73,15 @@ def test_exact_if_guards_an_exact_launch(oracle):
     nbr = oracle.nbr_build(coords, tk, tv, kernel_offsets(3, 1))
     w = torch.randn(27, 16, 8, generator=torch.Generator().manual_seed(1))
     out = torch.full((500, 8), 7.0)
-    flag = torch.zeros(1, dtype=torch.int32)
+    from pasco_amd.me.backend import STATUS_MAGNITUDE
+    flag = torch.full((1,), STATUS_MAGNITUDE, dtype=torch.int32)      # what a healthy operand split leaves: no overflow, magnitude present
     oracle.conv_fwd(feats, w, nbr, 500, out=out, exact_if=flag)
-    assert bool((out == 7.0).all()), "flag clear: the guarded launch must not touch the output"
-    flag.fill_(1)
-    oracle.conv_fwd(feats, w, nbr, 500, out=out, exact_if=flag)
-    assert torch.equal(out, oracle.conv_fwd(feats, w, nbr, 500))
+    assert bool((out == 7.0).all()), "no overflow, magnitude present: the guarded launch must not touch the output"
+    for word in (STATUS_MAGNITUDE | 1, 0):                             # an overflow / a tensor of tiny values only: the exact kernel works
+        out.fill_(7.0)
+        flag.fill_(word)
+        oracle.conv_fwd(feats, w, nbr, 500, out=out, exact_if=flag)
+        assert torch.equal(out, oracle.conv_fwd(feats, w, nbr, 500)), word
     with pytest.raises(ValueError):
         oracle.conv_fwd(feats, w, nbr, 500, exact_if=flag, split=(w, 1.0))
 
@@ -85,12 +100,20 @@ def test_exact_if_guards_an_exact_launch_gpu(hip):
     nbr = mgr.kernel_map(x.coordinate_map_key, x.coordinate_map_key, 3)
     w = torch.randn(27, 64, 64, generator=torch.Generator().manual_seed(1)).cuda() * 0.05
     out = torch.full((20000, 64), 7.0, device="cuda")
-    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    from pasco_amd.me.backend import STATUS_MAGNITUDE
+    flag = torch.full((1,), STATUS_MAGNITUDE, dtype=torch.int32, device="cuda")
     hip.conv_fwd(x.F, w, nbr, 20000, out=out, exact_if=flag)
     assert bool((out == 7.0).all())
-    flag.fill_(1)
-    hip.conv_fwd(x.F, w, nbr, 20000, out=out, exact_if=flag)
-    assert torch.equal(out, hip.conv_fwd(x.F, w, nbr, 20000))
+    for word in (STATUS_MAGNITUDE | 1, 0):
+        out.fill_(7.0)
+        flag.fill_(word)
+        hip.conv_fwd(x.F, w, nbr, 20000, out=out, exact_if=flag)
+        assert torch.equal(out, hip.conv_fwd(x.F, w, nbr, 20000)), word
+    # ph_split_rows raises the magnitude bit exactly when a value reaches the full-precision range of the scaled operand
+    for gain, want in ((1.0, STATUS_MAGNITUDE), (1e-5, 0)):
+        word = torch.zeros(1, dtype=torch.int32, device="cuda")
+        hip.split_rows((feats * gain).cuda(), status=word)
+        assert int(word) == want, (gain, int(word))
 
 
 # ---- deferred BatchNorm / activation on the plain modules -----------------------------------------------------------------
