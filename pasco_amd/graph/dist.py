@@ -282,15 +282,22 @@ _SLAB_BUFFERS: Dict[tuple, torch.Tensor] = {}
 
 
 def _persistent(key: tuple, shape, dtype, device) -> torch.Tensor:
-    """One exchange buffer per (purpose, shape, dtype, device), reused from step to step (no allocation in the timed step)."""
-    k = key + (tuple(shape), dtype, str(device))
+    """One exchange buffer per (purpose, dtype, device), reused from step to step (no allocation in the timed step): a flat buffer
+    GROWN to the largest size asked for so far (capacity rounded up to 1 / 8 of a power of two; the previous buffer is dropped
+    when it grows) and viewed in the asked shape - a scene's slab row count differs from the last scene's nearly always, and a
+    buffer per exact shape kept up to 64 dead arenas of 100 - 400 MB each."""
+    k = key + (dtype, str(device))
+    need = 1
+    for v in shape:
+        need *= int(v)
     t = _SLAB_BUFFERS.get(k)
-    if t is None:
-        if len(_SLAB_BUFFERS) > 64:
-            _SLAB_BUFFERS.clear()
-        t = torch.empty(shape, dtype=dtype, device=device)
+    if t is None or t.numel() < need:
+        step = max(1 << max(need.bit_length() - 4, 0), 1)
+        cap = (need + step - 1) // step * step
+        _SLAB_BUFFERS.pop(k, None)
+        t = torch.empty(cap, dtype=dtype, device=device)
         _SLAB_BUFFERS[k] = t
-    return t
+    return t[:need].view(*shape)
 
 
 def slab_owner(k: int, world: int, slabs: int) -> int:

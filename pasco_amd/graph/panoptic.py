@@ -70,6 +70,40 @@ class PanopticResult(dict):
         self[key] = val
         return val
 
+    # the lazy keys behave like the real ones of the dict the reference returns (helper.py:291-303): membership, get, iteration
+    def _lazy_keys(self):
+        return () if self._lazy is None else tuple(k for k in DENSE_KEYS + ("vox_all_mask_probs_denses",) if not dict.__contains__(self, k))
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy_keys()
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def materialize(self) -> "PanopticResult":
+        """Build every dense map now (what the reference's function always does)."""
+        for k in self._lazy_keys():
+            self[k]
+        return self
+
+    def keys(self):
+        return list(dict.keys(self)) + list(self._lazy_keys())
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._lazy_keys())
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def __reduce__(self):          # pickling / copying: a plain dict with everything built
+        return (dict, (dict(self.materialize().items()),))
+
 
 def _device_backend(t: torch.Tensor):
     import os

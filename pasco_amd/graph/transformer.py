@@ -168,6 +168,9 @@ class SelfAttentionLayer(nn.Module):
         own forward dispatches to scaled_dot_product_attention, which on this ROCm build is an AOTriton flash kernel
         (`attn_fwd`): a Triton kernel on the path, and one whose fp32 products are not fp32-exact."""
         mha = self.self_attn
+        # the written-out attention below has no dropout on the softmax weights (nn.MultiheadAttention applies it in training mode):
+        # the reference builds these layers with dropout = 0.0 (transformer_predictor_v2.py:72-82); anything else must not pass silently
+        assert mha.dropout == 0.0 or not self.training, "SelfAttentionLayer: attention dropout > 0 in training mode is not served"
         B, Q, D = x.shape
         H = mha.num_heads
         dh = D // H

@@ -45,6 +45,9 @@ def run_both(device, coords, masks, qp, extent):
 
 
 def compare(got, exp):
+    # the dense maps are built on first access, but the result behaves like the reference's dict before that too
+    assert "semantic_seg_denses" in got and "vox_all_mask_probs_denses" in got and "nonsense" not in got
+    assert set(exp.keys()) <= set(got.keys()) and got.get("nonsense", 5) == 5
     info = lambda r: [(s["id"], s["isthing"], s["category_id"], s["query_id"]) for s in r["segments_infos"][0]]
     assert info(got) == info(exp)
     for a, b in zip(got["segments_infos"][0], exp["segments_infos"][0]):
@@ -58,6 +61,7 @@ def compare(got, exp):
         assert torch.allclose(a, b, rtol=2e-6, atol=1e-7, equal_nan=True), (k, float((a - b).abs().max()))
     a, b = got["vox_all_mask_probs_denses"][0].cpu(), exp["vox_all_mask_probs_denses"][0].cpu()
     assert a.shape == b.shape and torch.equal(a, b)
+    assert got.get("semantic_seg_denses") is got["semantic_seg_denses"] and len(got) == len(got.keys()) == len(list(got.items()))
 
 
 CASES = [dict(seed=1, n=5000, q=100), dict(seed=2, n=3000, q=100, quantize=True), dict(seed=3, n=700, q=6),
