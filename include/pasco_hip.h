@@ -52,7 +52,9 @@ extern "C" {
 /* status word bit 6, written by ph_split_rows only: the operand holds at least one value with |x * 2^exp2| >= PH_SPLIT_FULL_PRECISION,
  * i.e. one whose hi / lo split carries the full 22 bits.  Informational in a stream's status word; in the word of a GUARDED
  * convolution (ph_conv_desc.exact_if) its ABSENCE - a tensor of tiny values only: 2^-19 relative error at |x| = 2^-9 growing to
- * 2^-11 at 2^-19, unscaled with exp2 = 5 - sends the launch to the exact fp32 kernel like an overflow does. */
+ * 2^-11 at 2^-19, unscaled with exp2 = 5 - sends the launch to the exact fp32 kernel like an overflow does.  The device library
+ * looks for such a value among the first 65 536 eight-channel segments of the tensor only (a miss costs a launch of the exact
+ * kernel, never a wrong result); the checker looks at every value. */
 #define PH_STATUS_MAGNITUDE 0x40
 #define PH_SPLIT_FULL_PRECISION 0.0625f
 

@@ -434,6 +434,7 @@ __global__ void __launch_bounds__(HV_THREADS) k_conv_h2(ConvArgsH a) {
 }
 
 // fp32 rows -> [hi x32 | lo x32] groups; one thread per 8 channels.  Channels >= c (pad to 32) are zero.
+constexpr unsigned PH_MAGNITUDE_BLOCKS = 256;
 __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ in, int64_t n, int c, int cpad,
                                                      const float *__restrict__ ps, const float *__restrict__ pb,
                                                      int has_pro, float neg, float pow2, _Float16 *__restrict__ out,
@@ -467,9 +468,14 @@ __global__ void __launch_bounds__(256) k_split_rows(const float *__restrict__ in
     if (status != nullptr && bad) atomicOr(status, 1);   // |v| > 65504 or NaN
     // bit 6: the operand holds a value whose lo half is a normal f16 (full 22-bit split).  A tensor WITHOUT one is all tiny (or
     // all zero): its hi / lo pairs carry fewer and fewer bits (lo is subnormal below 2^-3 scaled, hi itself below 2^-14) - the guarded
-    // module path (ph_conv_desc.exact_if) sends such a tensor to the exact kernel.  One atomic per wave, and only until the bit shows.
-    if (status != nullptr && __builtin_amdgcn_ballot_w64(big) != 0 && (threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(big))) {
-      if ((__atomic_load_n(status, __ATOMIC_RELAXED) & PH_STATUS_MAGNITUDE) == 0) atomicOr(status, PH_STATUS_MAGNITUDE);
+    // module path (ph_conv_desc.exact_if) sends such a tensor to the exact kernel.  Looked for in the first PH_MAGNITUDE_BLOCKS
+    // workgroups only (the first ~8 k rows of a 64-channel tensor): a miss there costs a launch of the exact kernel, never a wrong
+    // result, and the rest of the grid pays nothing (a read-before-atomic in every wave measured +20 % on this HBM-bound pass).
+    if (status != nullptr && blockIdx.x < PH_MAGNITUDE_BLOCKS) {
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(big);
+      if (m != 0 && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m) &&
+          (__atomic_load_n(status, __ATOMIC_RELAXED) & PH_STATUS_MAGNITUDE) == 0)
+        atomicOr(status, PH_STATUS_MAGNITUDE);
     }
   }
   _Float16 *dst = out + (row * (cpad >> 5) + (c0 >> 5)) * 64 + (c0 & 31);
