@@ -19,8 +19,12 @@
 //     BETWEEN two MFMAs: the next offset's addresses, the window DMA, the next offset's weights (one contiguous kilobyte per
 //     load instruction from the fragment-order copy of the kernel, ph_conv_desc.w_frag) under the first 12, the slot reads of
 //     the offset after next under the second 12; fragment reads between the groups, each a group of products ahead;
-//   * two rounds of reduction through both (by then free) window buffers, and the epilogue with every load ahead of its first
-//     store (h2_store_tile_staged).
+//   * two rounds of reduction through both (by then free) window buffers, and the epilogue's loads (per-channel vectors to LDS,
+//     residual values to registers) issued ahead of the reduction: no load of the epilogue waits behind one of its stores.
+// PERSISTENT workgroups (tiles drawn from per-XCD queues by atomics, the next tile's ticket / tables / first window fetched under
+// the current tile) were built this round and give bit-identical results, but the compiler spills 250 registers around the
+// tile loop and reloads two of them inside the offsets (each reload drains vmcnt): 31 % SLOWER (profiles/
+// r6m_wop2_persistent_rejected.txt) - removed; the ~8 k clocks at the head of every tile (10 % of its life) stay exposed.
 // Wave 3 owns 6 offsets; its seventh (k = 27) multiplies the zero row: no branch in the body.
 //
 // Summation order per accumulator: pass, 16-channel chunk, own offsets ascending; then across waves (own part first, the other
@@ -57,6 +61,10 @@ __device__ __forceinline__ int w2_lds32(uint32_t addr) {
   asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
+// ... with the constant part of the address in the instruction (a register per constant address is hoisted out of every loop and
+// spilled: the slot of (offset k, row block i) sits at k * 256 + i * 64 behind the wave's base)
+#define W2_LDS16_IMM(dst, addr, IMM) asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM) : "memory")
+#define W2_LDS32_IMM(dst, addr, IMM) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM) : "memory")
 struct W2W {                 // weight fragments of one (offset, chunk): [column block][hi, lo]
   f16x8 bh[2], bl[2];
 };
@@ -133,7 +141,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
   const int gf = l_j ^ ((l_r >> 2) & 3);
   const uint32_t gofs = (uint32_t)((gf >> 1) * 64 + (gf & 1) * 16);
   const uint64_t in_base = (uint64_t)reinterpret_cast<uintptr_t>(a.in_split) + gofs;
-  const uint64_t zero_src = (uint64_t)reinterpret_cast<uintptr_t>(a.zero) + (uint32_t)(l_j << 4);
   auto chunk_off = [](int c) -> uint32_t { return (uint32_t)((c >> 1) * 128 + (c & 1) * 32); };
 
   // the table buffer <- slot map + head of the row list of the tile (3 DMA instructions per wave at most)
@@ -152,11 +159,13 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
     }
   };
   // source address of this thread's 16 bytes of DMA pass p (64 rows) of a window: row `ix` of the operand, `wp` rows valid
+  // (a window row beyond `wp` is never named by a slot - absent neighbours go to the zero row -, so what lands in it does not matter:
+  // such a lane fetches row 0 of the operand instead of selecting a second base pointer)
   auto dma_src = [&](int ix, int p, int wp, uint32_t coff) -> uint64_t {
     const bool ok = (p * 64 + l_r) < wp;
     uint64_t v = in_base + (uint64_t)(uint32_t)(ok ? ix : 0) * rsb + coff;
     asm volatile("" : "+v"(v));
-    return ok ? v : zero_src;
+    return v;
   };
   auto dma_go = [&](uint64_t src, int p, int buf) {
     char *dst = lds + buf * W2_WIN + (p * 64 + wave * 16) * W2_ROWB;
@@ -232,6 +241,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
   const int nsteps = nch * npass;
   const uint32_t tab_slots = lds0 + (uint32_t)OFF_TAB + (uint32_t)(l31 * 2);                          // + (k * 128 + 32 i) * 2
   const uint32_t tab_rows = lds0 + (uint32_t)(OFF_TAB + W2_TAB_SLOT) + (uint32_t)(l_r * 4);           // + 64 p * 4
+  const uint32_t slot_w = tab_slots + (uint32_t)(wave * W2_BM * 2);      // this wave's first offset; its offset wave + 4 t: + 4 t * 256
   {
     const int wp = cnt < W2_MAX ? cnt : W2_MAX;
 #pragma unroll
@@ -248,11 +258,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
   // row offsets of this wave's first two offsets: the same for every chunk of a pass - read once, not at the head of every step
   uint32_t s0[4], s1[4];
   auto first_slots = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      s0[i] = w2_lds16(tab_slots + (uint32_t)((wave * W2_BM + i * 32) * 2));
-      s1[i] = w2_lds16(tab_slots + (uint32_t)(((wave + 4) * W2_BM + i * 32) * 2));
-    }
+    W2_LDS16_IMM(s0[0], slot_w, 0); W2_LDS16_IMM(s0[1], slot_w, 64); W2_LDS16_IMM(s0[2], slot_w, 128); W2_LDS16_IMM(s0[3], slot_w, 192);
+    W2_LDS16_IMM(s1[0], slot_w, 1024); W2_LDS16_IMM(s1[1], slot_w, 1088); W2_LDS16_IMM(s1[2], slot_w, 1152); W2_LDS16_IMM(s1[3], slot_w, 1216);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s0[0]), "+v"(s0[1]), "+v"(s0[2]), "+v"(s0[3]), "+v"(s1[0]), "+v"(s1[1]), "+v"(s1[2]), "+v"(s1[3])::"memory");
   };
   first_slots();
@@ -298,7 +305,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
 #define W2_OFFSET(t, WC, WN)                                                                                                  \
   do {                                                                                                                        \
     const int kn = wave + 4 * ((t) + 1);                                                                                      \
-    const int k2 = wave + 4 * ((t) + 2) < W2_KV ? wave + 4 * ((t) + 2) : W2_KV - 1;                                           \
     const char *wpn = (t) < 6 ? w_addr(kn, c) : w_addr(wave, cn);                                                             \
     if ((t) > 0 && (t) < 6) asm volatile("s_waitcnt lgkmcnt(8)" : W2_PIN_A(fa), "+v"(ixn)::"memory");                         \
     else asm volatile("s_waitcnt lgkmcnt(4)" : W2_PIN_A(fa), "+v"(ixn)::"memory");                                            \
@@ -332,7 +338,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
       if (!W2_ABL(0x2)) {                                                                                                     \
         fa.h[0] = w2_lds(ad[0]); fa.l[0] = w2_lds(ad[0] ^ 32u); fa.h[1] = w2_lds(ad[1]); fa.l[1] = w2_lds(ad[1] ^ 32u);       \
       }                                                                                                                       \
-      ixn = w2_lds32(tab_rows + (uint32_t)(((t) + 1) * 64 * 4));                                                              \
+      W2_LDS32_IMM(ixn, tab_rows, ((t) + 1) * 64 * 4);                                                                        \
     } else {                                                                                                                  \
       W2_SB(); mf(WC, fa, 0, 8); W2_SB(); mf(WC, fa, 0, 9); W2_SB(); mf(WC, fa, 0, 10); W2_SB(); mf(WC, fa, 0, 11); W2_SB();   \
     }                                                                                                                         \
@@ -340,13 +346,14 @@ __global__ void __launch_bounds__(256, 2) k_conv_wop2(ConvArgsH a) {
     if ((t) < 6) asm volatile("s_waitcnt lgkmcnt(5)" : W2_PIN_A(fb)::"memory");                                               \
     else asm volatile("s_waitcnt lgkmcnt(0)" : W2_PIN_A(fb)::"memory");                                                       \
     W2_SB(); mf(WC, fb, 2, 0); W2_SB();                                                                                       \
-    if ((t) < 5) sl[0] = w2_lds16(tab_slots + (uint32_t)((k2 * W2_BM + 0) * 2));                                              \
+    /* offset t + 2 of this wave: k = wave + 4 (t + 2); wave 3's k = 27 reads the head of the row list - its entries are not used (kv) */ \
+    if ((t) < 5) W2_LDS16_IMM(sl[0], slot_w, (4 * ((t) + 2) * W2_BM + 0) * 2);                                                \
     W2_SB(); mf(WC, fb, 2, 1); W2_SB();                                                                                       \
-    if ((t) < 5) sl[1] = w2_lds16(tab_slots + (uint32_t)((k2 * W2_BM + 32) * 2));                                             \
+    if ((t) < 5) W2_LDS16_IMM(sl[1], slot_w, (4 * ((t) + 2) * W2_BM + 32) * 2);                                               \
     W2_SB(); mf(WC, fb, 2, 2); W2_SB();                                                                                       \
-    if ((t) < 5) sl[2] = w2_lds16(tab_slots + (uint32_t)((k2 * W2_BM + 64) * 2));                                             \
+    if ((t) < 5) W2_LDS16_IMM(sl[2], slot_w, (4 * ((t) + 2) * W2_BM + 64) * 2);                                               \
     W2_SB(); mf(WC, fb, 2, 3); W2_SB();                                                                                       \
-    if ((t) < 5) sl[3] = w2_lds16(tab_slots + (uint32_t)((k2 * W2_BM + 96) * 2));                                             \
+    if ((t) < 5) W2_LDS16_IMM(sl[3], slot_w, (4 * ((t) + 2) * W2_BM + 96) * 2);                                               \
     W2_SB(); mf(WC, fb, 2, 4); W2_SB(); mf(WC, fb, 2, 5); W2_SB(); mf(WC, fb, 2, 6); W2_SB(); mf(WC, fb, 2, 7); W2_SB();      \
     mf(WC, fb, 2, 8); W2_SB(); mf(WC, fb, 2, 9); W2_SB(); mf(WC, fb, 2, 10); W2_SB(); mf(WC, fb, 2, 11); W2_SB();             \
     if ((t) < 6 && !W2_ABL(0x2)) {                                                                                            \

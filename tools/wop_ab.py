@@ -1,6 +1,6 @@
 """k_conv_wop2 (conv_wop.hip, round 6) against the round-4 window kernel on the 64-channel 3^3 launches of ONE benchmark step, same
-process, interleaved: [old] = the development library with PASCO_WOP=0 (k_conv_wop, round 4), [T1] = the same with PASCO_WOP=1 (k_conv_wop2, one tile per
-workgroup), [T2] = the product library's default.  Outputs are compared with
+process, interleaved: [rows] = the development library with PASCO_WOP=0 (k_conv_win, row-parallel waves), [dev] = the same with PASCO_WOP=1
+(k_conv_wop2 with the development switches compiled in), [product] = the product library.  Outputs are compared with
 the base library's (another fp32 summation order: max |a - b| / mean |b| printed).
 
     python tools/wop_ab.py [out.txt]"""
@@ -51,7 +51,7 @@ dev_lib = build_hip(dev=True, verbose=False)
 tmpd = tempfile.mkdtemp()
 libs = {}
 first = next(iter(layers.values()))[1]
-for name, sel in (("old", "0"), ("T1", "1")):       # one copy of the development library per setting (the switch is read once per load)
+for name, sel in (("rows", "0"), ("dev", "1")):       # one copy of the development library per setting (the switch is read once per load)
     path = os.path.join(tmpd, f"libpascohip_dev_{name}.so")
     shutil.copy(dev_lib, path)
     os.environ["PASCO_WOP"] = sel
@@ -60,7 +60,7 @@ for name, sel in (("old", "0"), ("T1", "1")):       # one copy of the developmen
     kw = {k: v for k, v in kw.items() if k not in ("out", "out_split")}
     libs[name].conv_fwd(x, weight, nbr, n_out, **kw)      # first launch: the setting is latched
     torch.cuda.synchronize()
-libs["T2"] = be
+libs["product"] = be
 names = list(libs)
 
 
