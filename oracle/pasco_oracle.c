@@ -922,11 +922,11 @@ int pho_pos_aug(const int32_t *coords, int64_t n, const float *eps, int32_t tab_
 int pho_keep_mask(const void *const *srcs, int32_t n_src, int32_t kind, const int32_t *coords, int64_t n, const int32_t *lo,
                   const int32_t *hi, int64_t fallback_rows, uint8_t *out, int32_t *any_word, ph_stream_t stream) {
   (void)stream; (void)any_word;
-  if (n_src < 1 || n_src > 8 || (kind != 0 && kind != 1) || n < 0 || fallback_rows < 0) return fail("keep_mask: bad arguments");
+  if (n_src < 0 || n_src > 8 || (kind != 0 && kind != 1) || n < 0 || fallback_rows < 0) return fail("keep_mask: bad arguments");
   if ((lo == NULL) != (hi == NULL) || (lo != NULL && coords == NULL)) return fail("keep_mask: bounds need lo, hi and coords");
   int any = 0;
   for (int64_t r = 0; r < n; ++r) {
-    int k = 0;
+    int k = n_src == 0;            /* no source: the box test alone */
     for (int i = 0; i < n_src; ++i)
       k = k || (kind == 1 ? ((const int32_t *)srcs[i])[r] >= 0 : ((const uint8_t *)srcs[i])[r] != 0);
     out[r] = (uint8_t)k;

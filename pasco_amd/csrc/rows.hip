@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256)
     k_keep_mask(KeepSrcs srcs, int n_src, int kind, const int4 *__restrict__ coords, int64_t n, const int32_t *__restrict__ lo,
                 const int32_t *__restrict__ hi, uint8_t *__restrict__ out, int32_t *__restrict__ any) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool k = false;
+  bool k = n_src == 0;             // no source: the box test alone (decoder_v3.py:151-158 on generated children)
   if (r < n) {
     for (int i = 0; i < n_src; ++i)
       k = k || (kind == 1 ? reinterpret_cast<const int32_t *>(srcs.p[i])[r] >= 0 : reinterpret_cast<const uint8_t *>(srcs.p[i])[r] != 0);
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256)
 extern "C" int ph_keep_mask(const void *const *srcs, int32_t n_src, int32_t kind, const int32_t *coords, int64_t n,
                             const int32_t *lo, const int32_t *hi, int64_t fallback_rows, uint8_t *out, int32_t *any_word,
                             ph_stream_t stream) {
-  PH_REQUIRE(n_src >= 1 && n_src <= 8 && (kind == 0 || kind == 1) && n >= 0 && fallback_rows >= 0, "keep_mask: bad arguments");
+  PH_REQUIRE(n_src >= 0 && n_src <= 8 && (kind == 0 || kind == 1) && n >= 0 && fallback_rows >= 0, "keep_mask: bad arguments");
   PH_REQUIRE((lo == nullptr) == (hi == nullptr) && (lo == nullptr || coords != nullptr), "keep_mask: bounds need lo, hi and coords");
   PH_REQUIRE(fallback_rows == 0 || any_word != nullptr, "keep_mask: the fallback needs the scratch word");
   if (n == 0) return 0;

@@ -123,7 +123,10 @@ class SPCDense3Dv2(nn.Module):
 
         in_splits = {}     # operand split of each intermediate, shared by the three branches that read it
 
-        def cbr(name, x):
+        def cbr(name, x, add=None):
+            """conv - BatchNorm - ReLU of one branch; `add`: a tensor added to the result by the launch's epilogue (after the ReLU)
+            - the sums of the block's branches (layers.py:700-726) ride on the convolutions instead of ten element-wise passes.
+            fp32 addition is commutative: each sum below is the reference's, term by term, in its order of association."""
             ks = self._KERNELS[name]
             scale, shift = fold_bn(getattr(self, self._BNS[name]))
             w = self._row_weight(name)
@@ -139,14 +142,13 @@ class SPCDense3Dv2(nn.Module):
                         in_splits[id(x)] = (x, be.split_rows(x))
                     in_split = in_splits[id(x)][1]
             return be.conv_fwd(x, w, tables.get(ks), n, epi_scale=scale, epi_shift=shift, epi_act=ACT_RELU,
-                               split=split, in_split=in_split)
+                               split=split, in_split=in_split, residual=add)
 
         x = rows.index_select(0, perm)                     # z-major inside the block (see _grid_tables), lexicographic outside
         x1 = cbr("a_conv1", x)
-        x2, x3, x4 = cbr("a_conv2", x1), cbr("a_conv3", x1), cbr("a_conv4", x1)
-        t1 = x2 + x3 + x4
-        x5, x6, x7 = cbr("a_conv5", t1), cbr("a_conv6", t1), cbr("a_conv7", t1)
-        s = x1 + t1 + x5 + x6 + x7
-        y0 = cbr("ch_conv1", s)
-        y1, y2, y3 = cbr("res_1", x), cbr("res_2", x), cbr("res_3", x)
-        return (x1 + y0 + y1 + y2 + y3).index_select(0, inv)
+        x2 = cbr("a_conv2", x1)
+        t1 = cbr("a_conv4", x1, add=cbr("a_conv3", x1, add=x2))                      # (x2 + x3) + x4
+        s = cbr("a_conv7", t1, add=cbr("a_conv6", t1, add=cbr("a_conv5", t1, add=x1 + t1)))      # (((x1 + t1) + x5) + x6) + x7
+        y = cbr("ch_conv1", s, add=x1)                                                # x1 + y0
+        y = cbr("res_3", x, add=cbr("res_2", x, add=cbr("res_1", x, add=y)))          # ((. + y1) + y2) + y3
+        return y.index_select(0, inv)

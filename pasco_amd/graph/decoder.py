@@ -60,6 +60,20 @@ def inside_bounds(coords: torch.Tensor, lo, hi) -> torch.Tensor:
     return ((xyz >= lo) & (xyz <= hi)).all(dim=1)
 
 
+def box_mask(mgr, coords: torch.Tensor, lo, hi) -> torch.Tensor:
+    """`inside_bounds` in one launch where the library serves it (ph_keep_mask without a source = the box test alone) instead of
+    four element-wise torch kernels per level."""
+    if fused.fusion() and coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4:
+        try:
+            be = mgr.backend()
+        except Exception:
+            be = None
+        if be is not None and be.has("keep_mask") and os.environ.get("PASCO_KEEP_FUSED", "1") != "0":
+            lo_t, hi_t = _corner(lo, coords).reshape(3).contiguous(), _corner(hi, coords).reshape(3).contiguous()
+            return be.keep_mask([], coords.contiguous(), lo_t, hi_t)
+    return inside_bounds(coords, lo, hi)
+
+
 _FIRST_ROWS = {}
 
 
@@ -119,7 +133,7 @@ class DecoderBlock(nn.Module):
         mgr = x.coordinate_manager
         up = self.upsample.net[0]
         # children -> bounds prune -> features only for surviving children
-        out_key = mgr.expand_pruned(x.coordinate_map_key, up.stride, lambda kids: inside_bounds(kids, global_min, global_max))
+        out_key = mgr.expand_pruned(x.coordinate_map_key, up.stride, lambda kids: box_mask(mgr, kids, global_min, global_max))
         nbr = mgr.kernel_map(x.coordinate_map_key, out_key, up.kernel_size, up.dilation, transposed=True)
         # `dec + shortcut` (decoder_v3.py:163) lists the rows of `dec` first: when the absorbed `resize` applies, its launch
         # writes them straight into the union's feature tensor (round 5) - the up-sampled features are never copied (the
@@ -320,13 +334,23 @@ class DecoderGenerativeSepConvV2(nn.Module):
             n_max = max([n_rows[(i, scale)] for i in infer_ids] + ([pad_to[scale]] if pad_to[scale] is not None else []))
             batch_f[scale] = x.F.new_empty((len(infer_ids), n_max, x.F.shape[1]))
             batch_c[scale] = x.C.new_empty((len(infer_ids), n_max, x.C.shape[1]))
+        # the pruned semantic logits are gathered straight into THEIR zero-padded batch (batch_sparse_tensor's layout, utils.py:
+        # 659-670); its coordinate batch is the stride-1 feature batch's (same maps, same pad length): no second copy
+        sem_F = None
+        if 1 in xs:
+            l0 = sem_logits_at_scales[1][infer_ids[0]].F
+            sem_F = l0.new_empty((len(infer_ids), batch_f[1].shape[1], l0.shape[1]))
         for (i, scale, x, keep), (out_key, rows) in zip(todo, pruned):
             mgr = x.coordinate_manager
             be = mgr.backend()
             if scale == 1:      # logits and features of one map, same mask: one map event (decoder_v3.py:421-427)
                 logits = sem_logits_at_scales[scale][i]
-                sem_logits_pruneds.append(ME.SparseTensor(be.gather_rows(logits.F.contiguous(), rows), coordinate_map_key=out_key,
-                                                          coordinate_manager=mgr))
+                slot1, n1_ = infer_ids.index(i), n_rows[(i, scale)]
+                dst = sem_F[slot1, :n1_]
+                be.gather_rows(logits.F.contiguous(), rows, out=dst)
+                if n1_ < sem_F.shape[1]:
+                    sem_F[slot1, n1_:].zero_()
+                sem_logits_pruneds.append(ME.SparseTensor(dst, coordinate_map_key=out_key, coordinate_manager=mgr))
             # the subnet's rows of the level, as the first convolution's operand (the level is split once for all subnets)
             xi = fused.gathered_split(x, rows, out_key)
             if xi is None:
@@ -346,8 +370,13 @@ class DecoderGenerativeSepConvV2(nn.Module):
         # rows of every subnet at every scale, for the transformer's host-side "is there a padded row" decisions
         batched["_meta"] = {"lens": {"fine": [int(t.F.shape[0]) for t in xs_infers[1]],
                                      "level": {s: [int(t.F.shape[0]) for t in v] for s, v in xs_infers.items()}}}
-        sem_F, sem_C = batch_sparse_tensor(sem_logits_pruneds, pad_to[1])
-        keep_pad = ((sem_F != 0).sum(-1) + (sem_C != 0).sum(-1)) != 0
+        if sem_F is None:
+            sem_F, sem_C = batch_sparse_tensor(sem_logits_pruneds, pad_to[1])
+        else:
+            sem_C = batch_c[1]
+        # a row counts as padding iff its logits AND its coordinates are all zero (transformer_predictor_v2.py:194-205 through
+        # decoder_v3.py:443-446): two reductions instead of six element-wise / reduce launches
+        keep_pad = (sem_F != 0).any(-1) | (sem_C != 0).any(-1)
         panop = self.transformer_predictor(batched, (sem_F, sem_C), min_Cs, max_Cs, keep_pad, subnets=subnets,
                                            sem_tensors=sem_logits_pruneds)
         return panop, sem_logits_pruneds

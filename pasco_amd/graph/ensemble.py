@@ -114,19 +114,26 @@ def match_partials(anchor_mask: torch.Tensor, aux_mask: torch.Tensor) -> torch.T
 def match_from_partials(partials: Sequence[torch.Tensor], q: int, iou_threshold: float):
     """Slab contributions (in slab order) -> the Hungarian matching: (a_idx, b_idx on the partials' device, matched IoUs
     on the host) (utils.py:153-198)."""
-    tot = partials[0].clone()
-    for p in partials[1:]:
-        tot += p                                                             # fixed order: slab 0, 1, 2, ...
-    inter = tot[:q * q].reshape(q, q)
-    union = tot[q * q:q * q + q][:, None] + tot[q * q + q:][None, :] - inter
-    iou = torch.where(union != 0, inter / union, torch.zeros_like(inter))
-    iou = iou * (iou > iou_threshold)
-    iou_h = iou.cpu()                                                        # the one host read of the matching step
-    a_idx, b_idx = linear_sum_assignment((1.0 - iou_h).numpy())
-    matched_h = iou_h[a_idx, b_idx]                                          # host copy: the query filter is decided there too
+    if len(partials) == 1:
+        tot = partials[0]
+    else:
+        tot = partials[0].clone()
+        for p in partials[1:]:
+            tot += p                                                         # fixed order: slab 0, 1, 2, ...
+    dev = tot.device
+    # the one host read of the matching step brings the SUMS down (Q Q + 2 Q floats); the Q x Q soft IoUs are formed on the host:
+    # fp32 +, -, / are correctly rounded on either side - the same matrix as the device's, bit for bit, without nine small launches
+    tot_h = tot.cpu().numpy()
+    inter = tot_h[:q * q].reshape(q, q)
+    union = (tot_h[q * q:q * q + q][:, None] + tot_h[q * q + q:][None, :]) - inter
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iou = np.where(union != 0, inter / union, np.float32(0.0)).astype(np.float32)
+    iou = iou * (iou > np.float32(iou_threshold))
+    a_idx, b_idx = linear_sum_assignment(np.float32(1.0) - iou)
+    matched_h = torch.from_numpy(iou[a_idx, b_idx])                          # host copy: the query filter is decided there too
     ab = torch.as_tensor(np.stack([a_idx, b_idx]))
-    if iou.is_cuda:                                                          # pinned staging: the upload does not synchronise
-        ab = ab.pin_memory().to(iou.device, non_blocking=True)
+    if dev.type == "cuda":                                                   # pinned staging: the upload does not synchronise
+        ab = ab.pin_memory().to(dev, non_blocking=True)
     return ab[0], ab[1], matched_h
 
 
@@ -233,13 +240,18 @@ class Ensembler(torch.nn.Module):
         sites = self.sites(dev)
         cache = {} if cache is None else cache
         rows_per_subnet, query_probs = [], []
-        occupied = None
         for i in range(n_sub):
             vl = panop_predictions[i]["voxel_logits"]
-            rows = _lookup_rows(vl, self.projected(Ts[i], dev, cache))
-            rows_per_subnet.append(rows)
-            occupied = (rows >= 0) if occupied is None else (occupied | (rows >= 0))
+            rows_per_subnet.append(_lookup_rows(vl, self.projected(Ts[i], dev, cache)))
             query_probs.append(F.softmax(panop_predictions[i]["query_logits"], dim=-1))
+        # a canonical site is occupied where some subnet has a row for it (row >= 0): one pass over the lookups where the library
+        # serves it (ph_keep_mask on int32 sources), else the element-wise form
+        if be.has("keep_mask") and n_sub <= 8:
+            occupied = be.keep_mask([r.contiguous() for r in rows_per_subnet])
+        else:
+            occupied = None
+            for rows in rows_per_subnet:
+                occupied = (rows >= 0) if occupied is None else (occupied | (rows >= 0))
         union_sites = be.mask_compact(occupied.contiguous())                # canonical site ids (int32), lexicographic
         union_long = union_sites.long()
         site_coords = sites.index_select(0, union_long)                     # [U, 3]

@@ -155,6 +155,22 @@ def _attention_math(q, k, v, bias=None):
     return torch.matmul(torch.softmax(att, dim=-1), v)
 
 
+_LEAD_PATTERNS = {}
+
+
+def _lead_pattern(lead: tuple, p: int, device) -> torch.Tensor:
+    """bool [B, P]: row r of subnet b is one of its leading lead[b] rows."""
+    stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+    key = (lead, p, str(device), stream)       # per stream: made on another scene thread's stream it may not be written yet
+    hit = _LEAD_PATTERNS.get(key)
+    if hit is None:
+        if len(_LEAD_PATTERNS) > 64:
+            _LEAD_PATTERNS.clear()
+        hit = torch.arange(p, device=device)[None, :] < torch.tensor(lead, device=device)[:, None]
+        _LEAD_PATTERNS[key] = hit
+    return hit
+
+
 class SelfAttentionLayer(nn.Module):
     def __init__(self, d_model, nhead, dropout=0.0):
         super().__init__()
@@ -819,10 +835,9 @@ class TransformerPredictorV2(nn.Module):
         opt = fused_mod.optimistic_word(keep_pad.device) if sem_tensors is not None else None
         if opt is not None and all(t is not None and t.F.shape[0] <= voxel_coord.shape[1] for t in sem_tensors):
             lead = [int(t.F.shape[0]) for t in sem_tensors]
-            bad = None
-            for b, n_b in enumerate(lead):      # leading n_b rows kept, nothing behind them (host ints: no copy)
-                v = ~keep_pad[b, :n_b].all() | keep_pad[b, n_b:].any()
-                bad = v if bad is None else (bad | v)
+            # leading n_b rows kept, nothing behind them: ONE comparison with the expected pattern (a function of the row counts -
+            # host ints - kept per (counts, pad length, device, stream)) instead of four small launches per subnet
+            bad = (keep_pad != _lead_pattern(tuple(lead), keep_pad.shape[1], keep_pad.device)).any()
             opt.bitwise_or_(bad.to(torch.int32))
         for b in range(B):
             if lead is not None:

@@ -853,15 +853,19 @@ class CBackend:
             keeps.append(keep)
         return [k[:c] for k, c in zip(keeps, cnts.tolist())]
 
-    def gather_rows(self, src: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
-        """src [N,C] (4-byte dtype), rows int32 [M] -> [M,C]; rows == -1 give zeros."""
+    def gather_rows(self, src: torch.Tensor, rows: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """src [N,C] (4-byte dtype), rows int32 [M] -> [M,C]; rows == -1 give zeros.  `out`: caller-owned contiguous [M, C] rows
+        (a slice of a batch buffer: no copy afterwards)."""
         if src.element_size() != 4:
             raise TypeError("gather_rows serves 4-byte element types")
         if not src.is_contiguous():
             raise ValueError("gather_rows: src must be contiguous")
         self._chk(rows, torch.int32, "rows")
         c = src.shape[1]
-        out = torch.empty((rows.shape[0], c), dtype=src.dtype, device=src.device)
+        if out is None:
+            out = torch.empty((rows.shape[0], c), dtype=src.dtype, device=src.device)
+        elif out.shape != (rows.shape[0], c) or out.dtype != src.dtype or not out.is_contiguous() or out.device != src.device:
+            raise ValueError("gather_rows: out must be contiguous [M, C] of src's dtype")
         rc = self.fn["gather_rows"](_ptr(src), c, _ptr(rows), rows.shape[0], _ptr(out),
                                     self.stream(src.device))
         self._check(rc, "gather_rows")
@@ -953,9 +957,14 @@ class CBackend:
         fallback_rows > 0: when nothing is kept at all, the first `fallback_rows` rows count as kept instead (decided on the
         device).  One pass (include/pasco_hip.h keep_mask) instead of a dozen element-wise torch kernels per mask."""
         srcs = list(srcs)
-        kind = 1 if srcs[0].dtype == torch.int32 else 0
-        n = srcs[0].shape[0]
-        dev = srcs[0].device
+        if not srcs:                 # the box test alone
+            if coords is None or lo is None:
+                raise ValueError("keep_mask: no source and no box")
+            kind, n, dev = 0, coords.shape[0], coords.device
+        else:
+            kind = 1 if srcs[0].dtype == torch.int32 else 0
+            n = srcs[0].shape[0]
+            dev = srcs[0].device
         for t in srcs:
             if t.shape != (n,) or not t.is_contiguous() or (t.dtype == torch.int32) != (kind == 1) or \
                     (kind == 0 and t.dtype not in (torch.bool, torch.uint8)):
