@@ -333,7 +333,7 @@ class DecoderGenerativeSepConvV2(nn.Module):
         for scale, x in xs.items():
             n_max = max([n_rows[(i, scale)] for i in infer_ids] + ([pad_to[scale]] if pad_to[scale] is not None else []))
             batch_f[scale] = x.F.new_empty((len(infer_ids), n_max, x.F.shape[1]))
-            batch_c[scale] = x.C.new_empty((len(infer_ids), n_max, x.C.shape[1]))
+            batch_c[scale] = x.C.new_zeros((len(infer_ids), n_max, x.C.shape[1]))      # one fill per scale instead of one per slot
         # the pruned semantic logits are gathered straight into THEIR zero-padded batch (batch_sparse_tensor's layout, utils.py:
         # 659-670); its coordinate batch is the stride-1 feature batch's (same maps, same pad length): no second copy
         sem_F = None
@@ -364,7 +364,6 @@ class DecoderGenerativeSepConvV2(nn.Module):
             batch_c[scale][slot, :n] = y.C
             if n < batch_f[scale].shape[1]:
                 batch_f[scale][slot, n:].zero_()
-                batch_c[scale][slot, n:].zero_()
             xs_infers[scale].append(y)
         batched = {s: (batch_f[s], batch_c[s]) for s in xs_infers}
         # rows of every subnet at every scale, for the transformer's host-side "is there a padded row" decisions
