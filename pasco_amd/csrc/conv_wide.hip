@@ -284,6 +284,35 @@ int ph_conv_wide_try(const ConvArgsH &a_in, hipStream_t st) {
     if (a_in.cout == 256 && trow < 48) return -1;
     if (a_in.cout == 128) {      // whole rounds only: the last round at least ~60 % full, no split over the offsets
       const int64_t rest = trow % 256;
+      if (trow >= 256 && rest != 0 && rest < 150 && a_in.ksplit == 1 && a_in.partial == nullptr && a_in.tail_ws != nullptr) {
+        // whole rounds + a few row tiles (the encoder's 71.5 k-row level: 280 tiles): the whole rounds here (0.35 of the matrix peak
+        // against k_conv_dma's 0.24), the left-over rows on k_conv_dma, split over the offsets so that they fill the chip
+        const int64_t r0 = (trow - rest) * 256, tail_rows = a_in.n_out - r0;
+        int ks = (int)(512 / ((tail_rows + 127) / 128));
+        if (ks > a_in.kvol / 3) ks = a_in.kvol / 3;
+        if (ks > 12) ks = 12;
+        while (ks > 1 && (a_in.kvol + (a_in.kvol + ks - 1) / ks - 1) / ((a_in.kvol + ks - 1) / ks) != ks) --ks;      // no empty slice
+        const char *zero0 = ph_dma_zero_line();
+        if (ks >= 2 && zero0 != nullptr && (int64_t)ks * tail_rows * a_in.cout * 4 <= a_in.tail_ws_bytes) {
+          ConvArgsH head = a_in;
+          head.zero = zero0;
+          head.ablate = 0;
+          head.n_out = r0;
+          head.ksplit = 1;
+          head.partial = nullptr;
+          if (int rc = launch_wide<2>(head, st)) return rc;
+          ConvArgsH tail = a_in;
+          tail.n_out = tail_rows;
+          tail.nbr = a_in.nbr + r0;
+          if (tail.out) tail.out = a_in.out + r0 * a_in.cout;
+          if (tail.out_split) tail.out_split = a_in.out_split + r0 * a_in.cout * 2;
+          if (tail.residual) tail.residual = a_in.residual + r0 * a_in.cout;
+          if (tail.axis_coords) tail.axis_coords = a_in.axis_coords + r0 * 4;
+          tail.ksplit = ks;
+          tail.partial = (float *)a_in.tail_ws;
+          return ph_conv_dma_try(tail, 128, st);
+        }
+      }
       if (trow < 150 || (rest != 0 && rest < 150)) return -1;
     }
   }

