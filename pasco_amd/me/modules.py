@@ -165,6 +165,22 @@ def _same_map(x: SparseTensor, feats: torch.Tensor) -> SparseTensor:
     return SparseTensor(feats, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
 
 
+_GRAD_MODE_WARNED = False
+
+
+def _warn_grad_mode_once() -> None:
+    """An eval-mode module called with autograd ENABLED takes the module-by-module route (separate BatchNorm / activation passes,
+    exact fp32 products where a parameter requires grad): the results are the same, the speed is not ('a caller who
+    forgets torch.no_grad() silently gets the slow route').  Said once per process."""
+    global _GRAD_MODE_WARNED
+    if not _GRAD_MODE_WARNED:
+        _GRAD_MODE_WARNED = True
+        import warnings
+        warnings.warn("pasco_amd.me: eval-mode modules called with autograd enabled - the fused inference route (deferred BatchNorm / "
+                      "activations, split-precision convolutions) needs torch.no_grad() / torch.inference_mode(); running the "
+                      "module-by-module route", RuntimeWarning, stacklevel=3)
+
+
 class MinkowskiBatchNorm(nn.Module):
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
         super().__init__()
@@ -192,6 +208,8 @@ class MinkowskiBatchNorm(nn.Module):
 
     def forward(self, x: SparseTensor) -> SparseTensor:
         m = self.bn
+        if _ME_DEFER and not m.training and torch.is_grad_enabled():
+            _warn_grad_mode_once()
         if _ME_DEFER and not m.training and m.track_running_stats and m._buffers.get("running_mean") is not None \
                 and not torch.is_grad_enabled() and x._F.dtype == torch.float32:
             if x._pending is not None:
