@@ -129,7 +129,7 @@ class _ConvBase(MinkowskiModuleBase):
         win = None
         if mgr is not None and nbr is not None and nbr.shape[0] == 27 and 33 <= self.out_channels <= 64 and \
                 n_out >= ME_MIN_ROWS_WINDOWS and be.device_type == "cuda":
-            win = mgr.kernel_windows(nbr)       # LDS-window tables of the map (cached by the manager): k_conv_wop
+            win = mgr.kernel_windows(nbr)       # LDS-window tables of the map (cached by the manager): k_conv_wop2
         out = be.conv_fwd(feats, kernel, nbr, n_out, bias=bias, split=hit[1], in_split=xs, status=flag, win=win)
         be.conv_fwd(feats, kernel, nbr, n_out, bias=bias, out=out, exact_if=flag, **pro)
         return out

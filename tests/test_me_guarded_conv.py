@@ -89,7 +89,7 @@ def test_exact_if_guards_an_exact_launch(oracle):
 @pytest.mark.gpu
 def test_guarded_module_conv_on_the_gpu(hip):
     _check("cuda", hip)
-    _check("cuda", hip, n=60000, extent=(96, 96, 16))       # >= 16 384 rows: window tables, the k_conv_wop / gather pair
+    _check("cuda", hip, n=60000, extent=(96, 96, 16))       # >= 16 384 rows: window tables, the k_conv_wop2 / gather pair
 
 
 @pytest.mark.gpu
