@@ -38,8 +38,9 @@ extern "C" {
 /* 2: ph_conv_desc grew (split_exp2, out_split, window / axis-table / row-list blocks), ph_map_insert and ph_split_rows gained
  * their `status` argument.  A caller built against another version must be rebuilt: the binding checks the version AND the size
  * of ph_conv_desc before the first call.
- * 3: ph_panop_*.  4: ph_conv_desc.route (was reserved2) replaces the process-global test hooks of rounds 2 - 5; w_frag. */
-#define PH_ABI_VERSION 4
+ * 3: ph_panop_*.  4: ph_conv_desc.route (was reserved2) replaces the process-global test hooks of rounds 2 - 5; w_frag.
+ * 5: ph_conv_desc.grid_dims / grid_kernel (the dense-grid promise). */
+#define PH_ABI_VERSION 5
 #define PH_MAX_KVOL 64 /* largest kernel volume of one nbr_build / pooling call (4x4x4 window); conv_fwd takes tables of up to 4096 offsets (dense bottleneck: 7x7x5 = 245) */
 
 /* ph_conv_desc.route bits */
@@ -48,6 +49,7 @@ extern "C" {
 #define PH_ROUTE_WIDE_ALWAYS 0x4 /* 128 / 256 output channels, >= 8 offsets: the 256-row tile kernel at any size */
 #define PH_ROUTE_WIDE_NEVER 0x8
 #define PH_ROUTE_LIN_NEVER 0x10  /* k = 1 products: not the row-stream kernel */
+#define PH_ROUTE_GRID_NEVER 0x20 /* dense-grid promise (grid_dims): ignored, the gather kernels read nbr */
 
 /* status word bit 6, written by ph_split_rows only: the operand holds at least one value with |x * 2^exp2| >= PH_SPLIT_FULL_PRECISION,
  * i.e. one whose hi / lo split carries the full 22 bits.  Informational in a stream's status word; in the word of a GUARDED
@@ -247,6 +249,16 @@ typedef struct ph_conv_desc {
    * cout - 1).  A fragment load then reads 1 KB of whole cache lines instead of 32 bytes of each of 32 rows (round 6: the
    * weight loads were what saturated the vector-memory path of that kernel).  Same values as w_split; NULL = not given. */
   const void *w_frag;
+  /* mode 2, optional PROMISE about the map (round 6; all zero = none): `nbr` is the stride-1 kernel map of a (kx, ky, kz) box - odd
+   * sizes, dilation 1 - on the FULL dense grid [B, X, Y, Z] (n_in == n_out == B * X * Y * Z) with the sites enumerated (b, z, x, y),
+   * y running fastest, and the offsets enumerated k = iy + ky * (ix + kx * iz), offset = (ix - kx / 2, iy - ky / 2, iz - kz / 2).
+   * grid_dims = {B, X, Y, Z}, grid_kernel = {kx, ky, kz}.  The library may then form neighbour rows by arithmetic and serve the ky
+   * offsets of one (dx, dz) from one LDS window of the input (conv_grid.hip) - the dense bottleneck, whose torch Conv3d stages
+   * (layers.py:656-726) such a launch stands for.  `nbr` must still be given and BE that map: the checker build and the other
+   * kernels read it, and a promise the map does not keep gives wrong sums without a flag. */
+  int32_t grid_dims[4];
+  int32_t grid_kernel[3];
+  int32_t reserved3;
 } ph_conv_desc;
 
 int PH_FN(conv_fwd)(const ph_conv_desc *desc, ph_stream_t stream);

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libpascohip.so")
-SOURCES = ["coords.hip", "conv.hip", "conv_f16x3.hip", "conv_dma.hip", "conv_lin.hip", "conv_wide.hip", "conv_win.hip", "conv_wop.hip", "rows.hip", "attn.hip", "input.hip", "panop.hip"]
+SOURCES = ["coords.hip", "conv.hip", "conv_f16x3.hip", "conv_dma.hip", "conv_lin.hip", "conv_wide.hip", "conv_grid.hip", "conv_win.hip", "conv_wop.hip", "rows.hip", "attn.hip", "input.hip", "panop.hip"]
 HEADERS = ["ph_common.h", "conv_h2_common.h", os.path.join("..", "..", "include", "pasco_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

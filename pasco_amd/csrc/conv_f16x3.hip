@@ -717,6 +717,8 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.out_rows = nullptr;
   a.tile_k = nullptr;
   a.nbr_stride = d->n_out;
+  for (int q = 0; q < 4; ++q) a.gdim[q] = d->grid_dims[q];
+  for (int q = 0; q < 3; ++q) a.gker[q] = d->grid_kernel[q];
   a.tail_ws = d->splitk_ws;
   a.tail_ws_bytes = d->splitk_ws_bytes;
   a.win_rows = d->win_rows;
@@ -790,6 +792,11 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
       a.ksplit = want;
       a.partial = (float *)d->splitk_ws;
     }
+  }
+  // the dense-grid promise (the bottleneck's implicit GEMMs): windows of the input instead of gathers, its own split over the units
+  if (pre && !env && d->grid_dims[0] > 0 && d->nbr != nullptr) {
+    const int rc = ph_conv_grid_try(a, st);
+    if (rc >= 0) return rc;
   }
   // one-pair-per-row maps with row lists (generative transposed convolutions): every 128-position tile of the list is the
   // k = 1 product of one kernel offset; outputs go to the rows the list names

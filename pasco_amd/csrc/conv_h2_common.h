@@ -62,6 +62,7 @@ struct ConvArgsH {
   int par_vec;                // every per-channel vector (bias, epi*, osp*) is 16-byte aligned: the epilogue loads them as float4
   void *tail_ws;              // host-side only: the caller's split scratch (ph_conv_desc.splitk_ws) for ph_conv_dma_try's tail split
   int64_t tail_ws_bytes;
+  int gdim[4], gker[3];       // ph_conv_desc.grid_dims / grid_kernel (all zero: no dense-grid promise); conv_grid.hip
   int64_t nbr_stride;         // k_conv_dma: rows of one offset's segment of `nbr` (= the map's n_out; a launch over a row range of
                               // the map has its own, smaller n_out and row-shifted pointers - ph_conv_dma_try's tail split)
 };
@@ -134,6 +135,8 @@ int ph_conv_dma_try(const ConvArgsH &a, int bn, hipStream_t st);
 int ph_conv_lin_try(const ConvArgsH &a, hipStream_t st);
 // conv_wide.hip: 256 x 256 tiles, 8 waves, one workgroup per CU (256 output channels); -1 = shape not served
 int ph_conv_wide_try(const ConvArgsH &a, hipStream_t st);
+// conv_grid.hip: launches with the dense-grid promise (a.gdim), activations from LDS windows; -1 = shape not served
+int ph_conv_grid_try(const ConvArgsH &a, hipStream_t st);
 
 // hi / lo halves of four values -> the [hi x32 | lo x32] group layout (dst points at the run's hi slot)
 __device__ __forceinline__ bool emit_split4(const float v[4], const float *sc, const float *sh, int has, float neg,

@@ -16,7 +16,6 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..me.backend import ACT_RELU, MAX_KVOL, backend_for
-from ..me.core import kernel_offsets
 from .fused import fold_bn
 
 
@@ -69,13 +68,14 @@ class SPCDense3Dv2(nn.Module):
             "res_2": "bn_res_2", "res_3": "bn_res_3"}
 
     def _row_weight(self, name):
-        """Conv3d weight [Cout, Cin, kx, ky, kz] -> [K, Cin, Cout] with K enumerated x fastest."""
+        """Conv3d weight [Cout, Cin, kx, ky, kz] -> [K, Cin, Cout] with K enumerated y fastest, then x, then z - the order of the
+        grid's kernel maps (`CBackend.grid_offsets`: the direction in which consecutive sites are consecutive rows)."""
         w = getattr(self, name)[0].weight
         hit = getattr(self, "_roww_" + name, None)
         ver = (w._version, w.device)
         if hit is None or hit[0] != ver:
             k = w.shape[2] * w.shape[3] * w.shape[4]
-            rw = w.detach().permute(4, 3, 2, 1, 0).reshape(k, w.shape[1], w.shape[0]).contiguous()
+            rw = w.detach().permute(4, 2, 3, 1, 0).reshape(k, w.shape[1], w.shape[0]).contiguous()
             if k == 1:
                 rw = rw.reshape(w.shape[1], w.shape[0])
             hit = (ver, rw)
@@ -105,7 +105,7 @@ class SPCDense3Dv2(nn.Module):
         tk, tv, _, _, _ = be.map_insert(coords, dedup=False)
         tables = {}
         for ks in {(3, 3, 1), (5, 5, 3), (7, 7, 5)}:
-            offs = kernel_offsets(ks, 1)
+            offs = be.grid_offsets(ks)
             parts = [be.nbr_build(coords, tk, tv, offs[i:i + MAX_KVOL]) for i in range(0, len(offs), MAX_KVOL)]
             tables[ks] = torch.cat(parts, dim=0).contiguous()
         cache[key] = (coords, tables, perm, inv, lex_coords)
@@ -142,7 +142,8 @@ class SPCDense3Dv2(nn.Module):
                         in_splits[id(x)] = (x, be.split_rows(x))
                     in_split = in_splits[id(x)][1]
             return be.conv_fwd(x, w, tables.get(ks), n, epi_scale=scale, epi_shift=shift, epi_act=ACT_RELU,
-                               split=split, in_split=in_split, residual=add)
+                               split=split, in_split=in_split, residual=add,
+                               grid=(tuple(int(v) for v in dims), ks) if split is not None and ks != (1, 1, 1) else None)
 
         x = rows.index_select(0, perm)                     # z-major inside the block (see _grid_tables), lexicographic outside
         x1 = cbr("a_conv1", x)

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpascohip.so")
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
-ABI_VERSION = 4          # include/pasco_hip.h PH_ABI_VERSION this binding was written against
+ABI_VERSION = 5          # include/pasco_hip.h PH_ABI_VERSION this binding was written against
 
 
 class StatusError(RuntimeError):
@@ -70,6 +70,7 @@ class ConvDesc(C.Structure):
         ("axis_table", _vp), ("axis_coords", _vp), ("axis_lo", _i32), ("axis_rows", _i32),
         ("rl_in", _vp), ("rl_out", _vp), ("rl_tile_k", _vp), ("rl_rows", _i64), ("rl_tiles", _i32),
         ("exact_if", _vp), ("w_frag", _vp),
+        ("grid_dims", _i32 * 4), ("grid_kernel", _i32 * 3), ("reserved3", _i32),
     ]
 
 
@@ -143,7 +144,7 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 STATUS_MAGNITUDE = 0x40    # PH_STATUS_MAGNITUDE
-ROUTE_WIN_ALWAYS, ROUTE_WIN_NEVER, ROUTE_WIDE_ALWAYS, ROUTE_WIDE_NEVER, ROUTE_LIN_NEVER = 0x1, 0x2, 0x4, 0x8, 0x10   # PH_ROUTE_*
+ROUTE_WIN_ALWAYS, ROUTE_WIN_NEVER, ROUTE_WIDE_ALWAYS, ROUTE_WIDE_NEVER, ROUTE_LIN_NEVER, ROUTE_GRID_NEVER = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20   # PH_ROUTE_*
 
 
 class CBackend:
@@ -428,7 +429,7 @@ class CBackend:
                  emit_split=None, want_out: bool = True,
                  out: Optional[torch.Tensor] = None, win=None, in_split_has_prologue: bool = False, axis=None,
                  rowlist=None, out_split: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None,
-                 exact_if: Optional[torch.Tensor] = None):
+                 exact_if: Optional[torch.Tensor] = None, grid=None):
         """out = epilogue(sum_k gather(prologue(x))[k] @ W[k]) - one `ph_conv_fwd` launch (include/pasco_hip.h).
 
         `split` selects the split-precision products: (w_hi, w_lo, unscale) from `split_weight_f16` = mode 1
@@ -442,6 +443,8 @@ class CBackend:
         where the map is local enough (decided on the device).
         `axis` = (table fp32 [3, T, cout], coords int32 [n_out, 4], lo) (mode 2): the per-axis table residual
         table[0][x - lo] + table[1][y - lo] + table[2][z - lo] is added where `residual` is added.
+        `grid` = ((B, X, Y, Z), (kx, ky, kz)) (mode 2): the PROMISE that `nbr` is the stride-1 box kernel map of the full dense
+        grid with sites (b, z, x, y) and offsets y-fastest (`grid_offsets`; ph_conv_desc.grid_dims): served from LDS windows.
         `status` (int32 [1] device word): the launch reports its flags there instead of into the stream's status pair;
         `exact_if` (exact fp32 launches only): the launch does its work only when bit 0 of that word is set - the guarded
         form of the split path (include/pasco_hip.h ph_conv_desc.exact_if; `pasco_amd.me.modules`)."""
@@ -536,6 +539,15 @@ class CBackend:
                 if w_split.numel() != kvol * cout * 2 * cpad:
                     raise ValueError("conv: w_split does not match the kernel")
                 d.mma_mode, d.in_split, d.w_split = 2, _ptr(in_split), _ptr(w_split)
+                if grid is not None and nbr is not None:
+                    gd, gk = grid
+                    if len(gd) != 4 or len(gk) != 3 or gd[0] * gd[1] * gd[2] * gd[3] != n_out or x.shape[0] != n_out or \
+                            gk[0] * gk[1] * gk[2] != kvol or any(k % 2 == 0 for k in gk):
+                        raise ValueError("conv: grid = ((B, X, Y, Z), (kx, ky, kz)) must describe the whole map (odd kernel sizes)")
+                    for q in range(4):
+                        d.grid_dims[q] = int(gd[q])
+                    for q in range(3):
+                        d.grid_kernel[q] = int(gk[q])
                 if rowlist is not None and nbr is not None:     # one-pair-per-row map: k = 1 products per list tile
                     d.rl_in, d.rl_out, d.rl_tile_k = _ptr(rowlist["in"]), _ptr(rowlist["out"]), _ptr(rowlist["tile_k"])
                     d.rl_rows, d.rl_tiles = int(rowlist["in"].numel()), int(rowlist["tile_k"].numel())
@@ -568,6 +580,14 @@ class CBackend:
         rc = self.fn["conv_fwd"](C.byref(d), self.stream(dev))
         self._check(rc, "conv_fwd")
         return (out, out_split) if emit else out
+
+    @staticmethod
+    def grid_offsets(kernel_size) -> list:
+        """Offsets of a (kx, ky, kz) box in the enumeration the dense-grid promise of `conv_fwd(grid=...)` names: k = iy + ky * (ix + kx * iz)
+        - y fastest, like the sites (b, z, x, y) of the grid (include/pasco_hip.h ph_conv_desc.grid_kernel)."""
+        kx, ky, kz = (int(k) for k in kernel_size)
+        return [(x, y, z) for z in range(-(kz // 2), kz // 2 + 1) for x in range(-(kx // 2), kx // 2 + 1)
+                for y in range(-(ky // 2), ky // 2 + 1)]
 
     def conv_last_config(self) -> dict:
         """Which kernel instantiation the last `conv_fwd` of this thread launched (include/pasco_hip.h

@@ -33,7 +33,7 @@ def test_hip_library_exports_every_symbol():
         assert hasattr(lib, "ph_" + n), f"libpascohip.so lacks ph_{n}"
     lib.ph_abi_version.restype = ctypes.c_int
     from pasco_amd.me.backend import ABI_VERSION
-    assert lib.ph_abi_version() == ABI_VERSION == 4
+    assert lib.ph_abi_version() == ABI_VERSION == 5
     from pasco_amd.me.backend import ConvDesc
     assert lib.ph_conv_desc_size() == ctypes.sizeof(ConvDesc)
 
