@@ -380,13 +380,21 @@ __global__ void __launch_bounds__(512, 2) k_conv_grid(ConvArgsH a) {
 }
 
 #ifdef PH_DEV
-// development build only (tools/grid_ab.py): phase ablation - 1 window DMA, 2 weight DMA, 4 MFMAs, 8 fragment reads, 16 no vmcnt wait,
-// 32 no barrier, 64 no fragment-address update.  Wrong sums, right instruction stream otherwise.
+// development build only (tools/grid_ab.py): phase ablation of k_conv_grid - 1 window DMA, 2 weight DMA, 4 MFMAs, 8 fragment reads,
+// 16 no vmcnt wait, 32 no barrier, 64 no fragment-address update.  Wrong sums, right instruction stream otherwise.
 static int g_grid_ablate = 0;
 extern "C" void ph_conv_grid_set_ablate(int mask) { g_grid_ablate = mask; }
 #else
 constexpr int g_grid_ablate = 0;
 #endif
+
+// reachable (dx, dz) groups of an average tile: all dx, the dz that stay inside the grid
+static double grid_groups(const int *gd, const int *gk) {
+  double zavg = 0.0;
+  for (int z = 0; z < gd[3]; ++z)
+    for (int iz = 0; iz < gk[2]; ++iz) zavg += (z + iz - gk[2] / 2 >= 0 && z + iz - gk[2] / 2 < gd[3]) ? 1.0 : 0.0;
+  return gk[0] * zavg / gd[3];
+}
 
 // Serves mode-2 launches that carry the dense-grid promise (ph_conv_desc.grid_dims / grid_kernel) with 128 k output channels and whole
 // 32-channel chunks; -1 = not served (the caller goes on to the gather kernels, which read `nbr`).  The split over the units comes
@@ -406,12 +414,7 @@ int ph_conv_grid_try(const ConvArgsH &a_in, hipStream_t st) {
   a.n_col_tiles = a.cout / 128;
   const int64_t tiles = (int64_t)a.n_row_tiles * a.n_col_tiles;
   const int nchunks = a.cpad >> 5;
-  // reachable groups of an average tile: all dx, the dz that stay inside the grid
-  double zavg = 0.0;
-  for (int z = 0; z < gd[3]; ++z)
-    for (int iz = 0; iz < kz; ++iz) zavg += (z + iz - kz / 2 >= 0 && z + iz - kz / 2 < gd[3]) ? 1.0 : 0.0;
-  zavg /= gd[3];
-  const double units = kx * zavg * nchunks;
+  const double units = grid_groups(gd, gk) * nchunks;
   const double stage_us = 1.0, fixed_us = 8.0;
   int best = 1;
   double best_us = 1e30;

@@ -13,7 +13,7 @@ import torch
 
 # 5: a window / gather pair (k_conv_win and k_conv_dma both launched, the device-side predicate lets one of them work)
 KERNEL_NAMES = {0: "k_conv_mfma", 1: "k_conv_f16x3", 2: "k_conv_h2", 3: "k_conv_rl", 4: "k_conv_dma",
-                5: "k_conv_win", 6: "k_conv_wide", 7: "k_conv_lin"}
+                5: "k_conv_win", 6: "k_conv_wide", 7: "k_conv_lin", 8: "k_conv_grid"}
 
 
 def layer_class(kvol: int, cin: int, cout: int) -> str:
