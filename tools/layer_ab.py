@@ -8,7 +8,7 @@ last line is the variant's convolution time per step.
 
 LAYER_AB_BASE=<other libpascohip .so> (tools/build_base_lib.sh builds one from a git revision): every launch is also replayed
 through that library in the same process, interleaved - column [base]; run-to-run differences between GPU boxes (several %)
-do not enter the comparison."""
+do not enter the comparison.  LAYER_AB_PRODUCT=1: the working tree's PRODUCT library (no development hooks, mask 0) against the base."""
 import ctypes as C
 import os
 import sys
@@ -27,7 +27,11 @@ n_infers = int(os.environ.get("LAYER_AB_M", "3"))
 dev = torch.device("cuda", 0)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from devlib import use_dev_library   # noqa: E402
-use_dev_library()      # the hooks below exist only in the development build (-DPH_DEV)
+PRODUCT = os.environ.get("LAYER_AB_PRODUCT", "0") != "0"     # the working tree's PRODUCT library against LAYER_AB_BASE (mask 0 only)
+if PRODUCT:
+    masks = [0]
+else:
+    use_dev_library()      # the ablation hooks exist only in the development build (-DPH_DEV)
 be = hip_backend()
 net = bench.build_net(n_infers, 283, dev)
 scene = make_scene(0, n_infers=n_infers).to(dev)
@@ -60,12 +64,19 @@ with torch.no_grad():
     bench.run_scene(net, scene, tk)
     be.conv_fwd = inner
 lib = be.lib
-lib.ph_conv_dma_set_ablate.argtypes = [C.c_int]
+if PRODUCT:
+    class _NoHooks:
+        @staticmethod
+        def ph_conv_dma_set_ablate(mask):
+            pass
+    lib = _NoHooks
+else:
+    lib.ph_conv_dma_set_ablate.argtypes = [C.c_int]
 base = None
 if os.environ.get("LAYER_AB_BASE"):
     base = CBackend(os.path.abspath(os.environ["LAYER_AB_BASE"]), "ph_", "cuda")
     masks = ["base"] + masks
-KN = {0: "mfma", 1: "f16x3", 2: "h2", 3: "rl", 4: "dma", 5: "win|dma", 6: "wide", 7: "lin"}
+KN = {0: "mfma", 1: "f16x3", 2: "h2", 3: "rl", 4: "dma", 5: "win|dma", 6: "wide", 7: "lin", 8: "grid"}
 
 
 def timed(rec, mask):
