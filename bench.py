@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (matrix) = vector rate
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA peak
 HBM_PEAK_GBS = 8000.0
-SPLIT_KERNELS = ("k_conv_dma", "k_conv_h2", "k_conv_f16x3", "k_conv_rl", "k_conv_win", "k_conv_wop", "k_conv_wop2", "k_conv_wide", "k_conv_lin")   # 3 f16 MFMAs per product
+SPLIT_KERNELS = ("k_conv_dma", "k_conv_h2", "k_conv_f16x3", "k_conv_rl", "k_conv_win", "k_conv_wop", "k_conv_wop2", "k_conv_wide", "k_conv_grid", "k_conv_lin")   # 3 f16 MFMAs per product
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@ def per_kernel(path, counter):
             per[key] += float(r["Counter_Value"])
             names[key] = r.get("Kernel_Name", "")
     out = {}
-    for kern in ("k_conv_dma", "k_conv_lin", "k_conv_wide", "k_conv_wop2", "k_conv_wop", "k_conv_win", "k_attn_feat", "k_attn_split", "k_conv_h2", "k_conv_f16x3", "k_conv_mfma", "k_conv_rl", "k_split_rows", "k_win_build"):
+    for kern in ("k_conv_dma", "k_conv_lin", "k_conv_wide", "k_conv_grid", "k_conv_wop2", "k_conv_wop", "k_conv_win", "k_attn_feat", "k_attn_split", "k_conv_h2", "k_conv_f16x3", "k_conv_mfma", "k_conv_rl", "k_split_rows", "k_win_build"):
         vals = [v for k, v in per.items() if kern + "<" in names[k] or kern + "(" in names[k] or names[k].startswith("_Z") and kern in names[k]]
         if vals:
             out[kern] = (sum(vals) / len(vals), len(vals))
