@@ -719,6 +719,7 @@ int ph_conv_fwd_f16x3(const ph_conv_desc *d, hipStream_t st) {
   a.nbr_stride = d->n_out;
   for (int q = 0; q < 4; ++q) a.gdim[q] = d->grid_dims[q];
   for (int q = 0; q < 3; ++q) a.gker[q] = d->grid_kernel[q];
+  a.grid_upw = 0;
   a.tail_ws = d->splitk_ws;
   a.tail_ws_bytes = d->splitk_ws_bytes;
   a.win_rows = d->win_rows;

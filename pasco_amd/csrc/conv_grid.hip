@@ -44,10 +44,12 @@ __global__ void __launch_bounds__(512, 2) k_conv_grid(ConvArgsH a) {
   constexpr int NRH = (TM + TN) * 2;         // fragment reads per wave and half stage (8)
   __shared__ __attribute__((aligned(128))) char lds[GR_LDS];
 
-  const int nwg = gridDim.x;
-  const int cpx = nwg >> 3;
-  const int bid = blockIdx.x;
-  const int tile = (bid & 7) * cpx + (bid >> 3);
+  // workgroup -> tile WITHOUT the XCD grouping of the other kernels: consecutive workgroups go to consecutive XCDs, so each XCD's
+  // 32 CUs get tiles from every z plane of the grid (tiles of the inner planes carry a third more work than the outer ones; eight
+  // neighbouring tiles on one XCD put 35 workgroups on the inner planes' 32 CUs).  What neighbouring tiles share - the weights -
+  // all tiles share
+  int tile = blockIdx.x;
+  if (PH_ABLATE(a, 0x200)) tile = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);   // development build: the XCD grouping
   if (tile >= a.n_row_tiles * a.n_col_tiles) return;
   const int row_tile = tile / a.n_col_tiles;
   const int col_tile = tile - row_tile * a.n_col_tiles;
@@ -101,7 +103,15 @@ __global__ void __launch_bounds__(512, 2) k_conv_grid(ConvArgsH a) {
       ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(gmask[1]) << 32);
   const int nvalid = __builtin_popcountll(gm);
   const int total_units = nvalid * nchunks;
-  const int nunits = slice < total_units ? (total_units - slice + a.ksplit - 1) / a.ksplit : 0;
+  // slices of THIS tile: tiles in the grid's outer z planes reach fewer (dx, dz) groups than inner ones (21 against 28 of a (7, 7, 5)
+  // kernel) - a tile takes as many of the launch's slices as keeps a workgroup's share near the launcher's target; the slices it
+  // does not take store zeros (the reduction sums all of them)
+  int nsl = a.ksplit;
+  if (a.grid_upw > 0) {
+    nsl = (total_units + (a.grid_upw >> 1)) / a.grid_upw;
+    nsl = nsl < 1 ? 1 : (nsl > a.ksplit ? a.ksplit : nsl);
+  }
+  const int nunits = (slice < nsl && slice < total_units) ? (total_units - slice + nsl - 1) / nsl : 0;
   const int nstages = nunits * ky;
 
   if (nstages > 0) {
@@ -110,7 +120,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_grid(ConvArgsH a) {
     struct Unit {
       int n, vi, g, c;
     };
-    const int kq = a.ksplit / nchunks, kr = a.ksplit - kq * nchunks;
+    const int kq = nsl / nchunks, kr = nsl - kq * nchunks;
     const int inv_kx = 65536 / kx + 1;                      // g / kx = (g * inv_kx) >> 16 for g < 64, kx <= 9
     auto first_unit = [&]() {
       Unit u;
@@ -425,6 +435,34 @@ int ph_conv_grid_try(const ConvArgsH &a_in, hipStream_t st) {
     double us = rounds * (ceil(units / ks) * ky * stage_us + fixed_us);
     if (ks > 1) us += (double)ks * (double)a.n_out * a.cout * 4.0 / 3.0e6 + 5.0;
     if (us < best_us) best_us = us, best = ks;
+  }
+  if (const char *e = PH_DEV_ENV("PASCO_GRID_KS")) {              // development build: the number of slices by hand (tools/grid_ab.py)
+    const int ks = atoi(e);
+    if (ks >= 1 && (ks == 1 || (a.tail_ws != nullptr && a.tail_ws_bytes >= (int64_t)ks * a.n_out * a.cout * 4))) best = ks;
+  }
+  a.grid_upw = 0;
+  if (best > 1 && tiles * best <= 256) {
+    // ONE round of workgroups: the launch lasts as long as its longest workgroup, and the model's slices are for a tile with the
+    // AVERAGE number of reachable groups - tiles in the grid's inner z planes reach a third more, a tile across two planes more still.
+    // Aim at the same units per workgroup everywhere, with as many slices in the launch as the fullest tile takes (measured on
+    // the 75-offset launches: -5 .. -8 %).  Launches of several rounds balance by themselves - their workgroups are handed out as CUs
+    // fall free - and lose 12 % to the extra slices (245 offsets: 9 -> 12): profiles/r6w_grid_balance.txt
+    const int upw = (int)(units / best + 0.5) > 0 ? (int)(units / best + 0.5) : 1;
+    int zmax = 0;
+    for (int z = 0; z < gd[3]; ++z) {
+      int c = 0;
+      for (int iz = 0; iz < kz; ++iz) c += (z + iz - kz / 2 >= 0 && z + iz - kz / 2 < gd[3]) ? 1 : 0;
+      zmax = c > zmax ? c : zmax;
+    }
+    const int zreach = zmax + 1 < kz ? zmax + 1 : kz;               // a tile across a plane boundary
+    int ksmax = (kx * zreach * nchunks + upw / 2) / upw;
+    ksmax = ksmax > 12 ? 12 : ksmax;
+    while (ksmax > best && a.tail_ws_bytes < (int64_t)ksmax * a.n_out * a.cout * 4) --ksmax;
+    const char *e = PH_DEV_ENV("PASCO_GRID_UPW");                  // development build: 0 = the same slices for every tile
+    if (e == nullptr || atoi(e) != 0) {
+      if (ksmax > best) best = ksmax;
+      a.grid_upw = upw;
+    }
   }
   a.ksplit = best;
   a.partial = best > 1 ? (float *)a.tail_ws : nullptr;

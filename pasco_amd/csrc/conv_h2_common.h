@@ -63,6 +63,7 @@ struct ConvArgsH {
   void *tail_ws;              // host-side only: the caller's split scratch (ph_conv_desc.splitk_ws) for ph_conv_dma_try's tail split
   int64_t tail_ws_bytes;
   int gdim[4], gker[3];       // ph_conv_desc.grid_dims / grid_kernel (all zero: no dense-grid promise); conv_grid.hip
+  int grid_upw;               // k_conv_grid: units of work per workgroup the launcher aims at (a tile takes round(its units / this) slices)
   int64_t nbr_stride;         // k_conv_dma: rows of one offset's segment of `nbr` (= the map's n_out; a launch over a row range of
                               // the map has its own, smaller n_out and row-shifted pointers - ph_conv_dma_try's tail split)
 };

@@ -12,7 +12,7 @@ from pasco_amd.me.backend import ROUTE_GRID_NEVER, backend_for  # noqa: E402
 
 def main():
     masks = [int(m, 0) for m in os.environ.get("GRID_ABLATE", "").split(",") if m]
-    if masks:
+    if masks or os.environ.get("PASCO_GRID_KS"):          # PASCO_GRID_KS=n: the development library with n slices by hand
         from devlib import use_dev_library
         use_dev_library()
     dev = torch.device("cuda:0")

@@ -25,7 +25,9 @@ inner = be.conv_fwd
 def spy(x, weight, nbr, n_out, **kw):
     out = inner(x, weight, nbr, n_out, **kw)
     cfg = be.conv_last_config()
-    if cfg["kernel"] == kid and n_out >= min_rows and (best[0] is None or n_out > best[0][3]):
+    kvol = (weight.shape[0] if weight is not None and weight.dim() == 3 else 1) if weight is not None else kw["wshape"][0]
+    if cfg["kernel"] == kid and n_out >= min_rows and kvol >= int(os.environ.get("LAYER_ONLY_MIN_KVOL", "0")) and \
+            (best[0] is None or n_out > best[0][3]):
         best[0] = (x, weight, nbr, n_out, dict(kw))
     return out
 
