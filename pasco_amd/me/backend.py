@@ -750,20 +750,18 @@ class CBackend:
 
     @staticmethod
     def weight_fragments(w_split: torch.Tensor, kvol: int, cout: int, cpad: int) -> torch.Tensor:
-        """`ph_conv_desc.w_frag`: the rows of `w_split` (f16 [kvol * cout, cpad / 32, 2, 32]) in the fragment order of the window
-        kernels - f16 [kvol, cpad / 16, nb (column blocks of 32: 2 for cout <= 64, cout / 32 beyond), 2 (hi, lo), 64 (lane = l31 + 32 h), 8]:
-        lane's 8 channels 16 c + 8 h .. + 7 of column min(32 j + l31, cout - 1).  A pure permutation, made once per kernel tensor
-        (kept on it)."""
+        """`ph_conv_desc.w_frag`: the rows of `w_split` (f16 [kvol * cout, cpad / 32, 2, 32]) in the fragment order of the 64-wide
+        window kernel - f16 [kvol, cpad / 16, 2 (column block), 2 (hi, lo), 64 (lane = l31 + 32 h), 8]: lane's 8 channels
+        16 c + 8 h .. + 7 of column min(32 j + l31, cout - 1).  A pure permutation, made once per kernel tensor (kept on it)."""
         hit = getattr(w_split, "_ph_wfrag", None)
         if hit is not None and hit[0] == (w_split._version, kvol, cout, cpad):
             return hit[1]
         g = cpad // 32
-        nb = max(2, (cout + 31) // 32)
         ws = w_split.view(kvol, cout, g, 2, 2, 2, 8)               # [k, n, group, part, s = chunk parity, h, q]
-        rows = torch.arange(32 * nb, device=w_split.device).clamp_(max=cout - 1)
-        ws = ws.index_select(1, rows).view(kvol, nb, 32, g, 2, 2, 2, 8)    # [k, j, l31, group, part, s, h, q]
+        rows = torch.arange(64, device=w_split.device).clamp_(max=cout - 1)
+        ws = ws.index_select(1, rows).view(kvol, 2, 32, g, 2, 2, 2, 8)     # [k, j, l31, group, part, s, h, q]
         frag = ws.permute(0, 3, 5, 1, 4, 6, 2, 7).contiguous()     # [k, group, s, j, part, h, l31, q]: chunk c = 2 group + s
-        frag = frag.view(kvol, 2 * g, nb, 2, 64, 8)
+        frag = frag.view(kvol, 2 * g, 2, 2, 64, 8)
         try:
             w_split._ph_wfrag = ((w_split._version, kvol, cout, cpad), frag)
         except AttributeError:
