@@ -13,8 +13,13 @@
 // 16 KB + 33 KB / ky instead of 48 KB (k_conv_wide) or 2 x 32 KB (two k_conv_dma tiles): the address unit is ~25 % busy.
 // Whether a neighbour exists is a coordinate test per lane (x + dx and z + dz once per unit, y + dy per stage); rows without one read a
 // zero line of LDS.  Groups none of the tile's rows can reach (dz beyond the 4-deep grid: 30 % of a (7, 7, 5) kernel) are dropped
-// from the tile's unit list; the launch is split over the UNITS, interleaved (slice s walks units s, s + ksplit, ...), partial
-// sums reduced in slice order by k_splitk_epilogue - any number of slices balances to one unit.
+// from the tile's unit list; the launch is split over the UNITS, interleaved (slice s of a tile walks its units s, s + slices, ...),
+// partial sums reduced in slice order by k_splitk_epilogue - any number of slices balances to one unit; in a launch of one round of
+// workgroups a tile takes as many slices as its unit count asks for (inner z planes reach a third more groups than outer ones).
+//
+// Measured (profiles/r6t_grid_ab.txt, r6w_grid_balance.txt, r6v_pmc_grid_wide2.txt): 455 / 177 / 51 us per launch for the 245 / 75 / 9-offset
+// shapes against k_conv_dma's 470 - 540 / 195 - 213 / 52; matrix pipe 43 % busy.  The address unit is no longer what bounds it; a
+// barrier-free variant with wave-private windows and a variant with wave roles were built, are parity-green and no faster (r6s).
 //
 // Pipeline = k_conv_wide's: two weight stage buffers, fragments at half-stage granularity, ONE barrier per stage in its middle;
 // two window buffers - the next unit's window is fetched under this unit's first ky - 1 stages.
