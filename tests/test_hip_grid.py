@@ -32,7 +32,9 @@ def test_grid_offsets_order(hip):
 @pytest.mark.parametrize("dims,ks,cin,cout", [((1, 38, 44, 4), (7, 7, 5), 256, 256), ((1, 38, 44, 4), (5, 5, 3), 256, 256),
                                               ((1, 38, 44, 4), (3, 3, 1), 256, 256), ((2, 9, 11, 3), (7, 7, 5), 64, 128),
                                               ((1, 17, 13, 5), (3, 5, 3), 96, 128), ((3, 5, 7, 2), (5, 3, 1), 32, 256),
-                                              ((1, 40, 40, 4), (5, 7, 5), 128, 128), ((1, 3, 300, 1), (3, 7, 1), 64, 128)])
+                                              ((1, 40, 40, 4), (5, 7, 5), 128, 128), ((1, 3, 300, 1), (3, 7, 1), 64, 128),
+                                              ((1, 2, 2, 2), (3, 3, 3), 32, 128), ((4, 1, 5, 1), (1, 5, 1), 32, 128),
+                                              ((1, 64, 2, 8), (7, 3, 5), 64, 256)])     # tiny grids, y shorter than the kernel, 8 planes
 def test_grid_conv_matches_oracle_fp64_and_the_gather_kernel(hip, oracle, dims, ks, cin, cout):
     from pasco_amd.me.backend import ROUTE_GRID_NEVER
 
